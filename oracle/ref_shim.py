@@ -1,0 +1,58 @@
+"""TEST INFRASTRUCTURE ONLY - import the reference's OWN modules from /root/reference (this container
+only; the GPU box has no /root/reference) so the restatement in hcodec_ref.py can be validated against
+them and golden vectors generated (oracle/gen_golden.py).
+
+Recipe: put oracle/stubs (vector_quantize_pytorch, torchaudio) and the version's
+directory on sys.path; the three H-Codec trees all expose a top-level package called `vq`, so
+sys.modules is purged between versions.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+
+REFERENCE_ROOT = os.environ.get("QA_REFERENCE_ROOT", "/root/reference")
+_STUBS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stubs")
+_VERSIONS = {
+    "1.0": "QuarkAudio-HCodec/HCodec-1.0",
+    "1.5": "QuarkAudio-HCodec/HCodec-1.5",
+    "2.0": "QuarkAudio-HCodec/HCodec-2.0",
+}
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, _VERSIONS["1.0"], "vq"))
+
+
+def load_reference_codec(version: str = "1.0"):
+    """Construct the reference `vq.Codec` (eval mode, random init) for the given H-Codec version."""
+    if not reference_available():
+        raise RuntimeError(f"reference tree not found under {REFERENCE_ROOT}")
+    for name in [m for m in sys.modules if m == "vq" or m.startswith("vq.") or m == "adaptive"
+                 or m.startswith("adaptive.")]:
+        del sys.modules[name]
+    root = os.path.join(REFERENCE_ROOT, _VERSIONS[version])
+    sys.path[:0] = [_STUBS, root]
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            from vq import Codec  # type: ignore
+            if version != "1.0":
+                raise NotImplementedError("only H-Codec 1.0 is wired so far")
+            model = Codec(None, None, None)
+    finally:
+        sys.path.remove(_STUBS)
+        sys.path.remove(root)
+    return model.eval()
+
+
+def load_state(model, sd, strict_subset: bool = True):
+    """Load a synth state_dict; keys the synth generator leaves out (training-only semantic_decoder.*)
+    keep their random init."""
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    if strict_subset:
+        bad = [k for k in missing if not k.startswith("semantic_decoder.")]
+        assert not bad, bad
+    return model
