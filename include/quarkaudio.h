@@ -1,0 +1,175 @@
+/*
+ * quarkaudio.h - C-ABI of libquarkaudio_hip.so: the MI355X (gfx950) hot path of alibaba/unified-audio
+ * (QuarkAudio): H-Codec encode -> RVQ -> decode, and the UniSE decoder-only AR-LM generate loop.
+ *
+ * The reference is 100 % Python and has no FFI of its own; the drop-in boundary is the tensor-in /
+ * tensor-out method pair a maintainer would rebind (see INTEGRATION.md for the ctypes stub):
+ *
+ *   qa_hcodec_encode   <-> Codec.encode(x, feat)            QuarkAudio-HCodec/HCodec-1.0/vq/codec.py:166-175
+ *   qa_hcodec_decode   <-> Codec.decode(ac, sc)             QuarkAudio-HCodec/HCodec-1.0/vq/codec.py:178-187
+ *   qa_hcodec_create   <-> Codec(...) + load_state_dict     QuarkAudio-HCodec/HCodec-1.0/audio_tokenizer.py:23-26
+ *   qa_rvq_search      <-> ResidualVQ.forward (eval)        call sites vq/codec.py:171-172 (algorithm: vq/core_vq.py:223-231,394-404)
+ *   qa_rvq_lookup      <-> ResidualVQ.get_output_from_indices  call sites vq/codec.py:183-184 (vq/core_vq.py:406-412)
+ *   qa_lm_create       <-> LLM_SFT(...) + load_state_dict   QuarkAudio-UniSE/model/llm/llm_sft.py:13-33, model/model.py:82-91
+ *   qa_lm_generate     <-> LLM_SFT.generate(...)            QuarkAudio-UniSE/model/llm/llm_sft.py:93-195
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative qa_status; nothing throws across the ABI;
+ *     qa_last_error() returns a thread-local, NUL-terminated description of the last failure.
+ *   - all data pointers are DEVICE pointers owned by the caller (e.g. torch tensor.data_ptr()),
+ *     contiguous unless strides are passed, except the weight table of *_create which is HOST memory
+ *     in the reference's own state_dict layout (the library folds weight-norm, re-lays filters out for
+ *     its kernels and keeps its own device copy).
+ *   - work is enqueued on `stream` (a hipStream_t; NULL = the default stream) and is asynchronous;
+ *     a handle owns its workspaces and must not be used from two streams / threads at once.
+ *   - there is no CPU fallback: on a machine without a gfx950 device every compute entry point fails.
+ */
+#ifndef QUARKAUDIO_H_
+#define QUARKAUDIO_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QA_VERSION 100 /* 0.1.0 */
+
+typedef enum qa_status {
+    QA_OK = 0,
+    QA_ERR_INVALID = -1,   /* bad argument / shape (the reference raises AssertionError / RuntimeError) */
+    QA_ERR_HIP = -2,       /* a HIP runtime call failed (no device, launch failure, out of memory) */
+    QA_ERR_MISSING = -3,   /* a tensor the architecture needs is not in the weight table (KeyError) */
+    QA_ERR_UNSUPPORTED = -4
+} qa_status;
+
+/* One named fp32 tensor of a state_dict.  `data` is HOST memory, row-major, `numel` elements. */
+typedef struct qa_tensor {
+    const char* name;
+    const float* data;
+    int64_t numel;
+} qa_tensor;
+
+/* Architecture constants of an H-Codec model (hard-coded in the reference: vq/codec.py:30-136). */
+typedef struct qa_hcodec_spec {
+    int32_t n_filters;        /* 32            codec.py:33  */
+    int32_t n_ratios;         /* 4 */
+    int32_t ratios[8];        /* encoder order 2,4,5,8  (codec.py:33 reversed by seanet.py:114) */
+    int32_t dimension;        /* 512 */
+    int32_t enc_heads;        /* 8   seanet.py:166 */
+    int32_t enc_layers;       /* 2   seanet.py:167 */
+    int32_t sem_in;           /* 768 codec.py:122 */
+    int32_t sem_ch;           /* 768 codec.py:123 */
+    int32_t n_sem_strides;    /* 2 */
+    int32_t sem_strides[4];   /* 2,1 codec.py:126 */
+    int32_t code_dim;         /* 512 */
+    int32_t codebook_size;    /* 1024 */
+    int32_t num_quantizers;   /* 4 */
+    int32_t dec_dim;          /* 768 codec.py:44 */
+    int32_t dec_inter;        /* 2304 */
+    int32_t dec_heads;        /* 8 */
+    int32_t dec_layers;       /* 2 */
+    int32_t convnext_layers;  /* 12 */
+    int32_t n_fft;            /* 1280 */
+    int32_t hop;              /* 320 */
+    int32_t gn_groups;        /* 32 */
+} qa_hcodec_spec;
+
+typedef struct qa_hcodec qa_hcodec;
+
+int qa_version(void);
+const char* qa_last_error(void);
+/* number of visible HIP devices (0 if none / runtime unavailable); never fails */
+int qa_device_count(void);
+
+/* ---- H-Codec ------------------------------------------------------------------------------------ */
+
+int qa_hcodec_create(qa_hcodec** out, const qa_hcodec_spec* spec, const qa_tensor* tensors, int64_t n_tensors,
+                     int device);
+void qa_hcodec_destroy(qa_hcodec* h);
+
+/* Codec.encode.  wav: [B, T] fp32, T a multiple of the encoder hop (2*prod(ratios); HCodecTokenizer.pad_wav
+ * guarantees it, audio_tokenizer.py:50-53).  feat: fp32 [B, sem_in, N50] addressed through element strides
+ * (so the [B, N50, sem_in] tensor the SSL model returns can be passed without the transpose copy the reference
+ * makes at audio_tokenizer.py:59).  Outputs: int64 [B, num_quantizers, N25] each, contiguous. */
+int qa_hcodec_encode(qa_hcodec* h, const float* wav, int64_t B, int64_t T,
+                     const float* feat, int64_t feat_stride_b, int64_t feat_stride_c, int64_t feat_stride_t,
+                     int64_t n_feat_frames, int64_t* acoustic_codes, int64_t* semantic_codes, void* stream);
+
+/* Codec.decode.  codes: int64 [B, num_quantizers, N]; wav_out: fp32 [B, 2*N*hop]. */
+int qa_hcodec_decode(qa_hcodec* h, const int64_t* acoustic_codes, const int64_t* semantic_codes, int64_t B,
+                     int64_t N, float* wav_out, void* stream);
+
+/* Test hook: copy the named intermediate of the LAST encode/decode (still in the handle's workspace) into
+ * `dst` (device, fp32, capacity `cap` elements).  Returns the element count or a negative status.  Layout is
+ * the library's: time-major, channel-last ([B, frames, channels]).  Names: see DESIGN.md "taps". */
+int64_t qa_hcodec_tap(qa_hcodec* h, const char* name, float* dst, int64_t cap, void* stream);
+
+/* ---- kernel-level entry points (used by the parity tests and available to integrators) ------------- */
+
+/* Residual nearest-codebook search.  x: [n_vec, D]; codebooks: [Q, K, D]; indices out: int64 [n_vec, Q];
+ * quantized_out (nullable): [n_vec, D] = sum_q E_q[idx_q].  Ties resolve to the lowest index. */
+int qa_rvq_search(const float* x, int64_t n_vec, const float* codebooks, int32_t Q, int32_t K, int32_t D,
+                  int64_t* indices, float* quantized_out, void* stream);
+/* indices: int64 [n_vec, Q] -> out [n_vec, D] = sum_q E_q[idx_q].  Out-of-range indices -> QA_ERR_INVALID is
+ * NOT detected on device; the caller guarantees 0 <= idx < K (the reference would raise IndexError). */
+int qa_rvq_lookup(const int64_t* indices, int64_t n_vec, const float* codebooks, int32_t Q, int32_t K, int32_t D,
+                  float* out, void* stream);
+
+/* Implicit-GEMM Conv1d over channel-last activations (covers nn.Linear with ksize = 1):
+ *   y[b, t, n] = post( res[b,t,n] + gamma[n] * act( bias[n] + sum_{j,c} pro(x[b, src(t,j), c]) * w[n, j, c] ) )
+ * with src(t,j) = t*stride - pad_left + j resolved by pad_mode (0 zero, 1 reflect as SConv1d does).
+ * Exposed for kernel-level parity tests.  See DESIGN.md for the full argument contract. */
+typedef struct qa_conv_args {
+    const float* x;        /* [B, T_in, C_in] */
+    const float* w;        /* [N, ksize, C_in]  (library layout) */
+    const float* bias;     /* [N] or NULL */
+    const float* gamma;    /* [N] or NULL */
+    const float* residual; /* [B, T_out, N] (row stride ldr) or NULL */
+    const float* gate;     /* [B, T_out, N] (row stride ldg) or NULL: y = silu(gate) * (acc + bias) */
+    float* y;              /* [B, T_out, N] with row stride ldy */
+    int64_t B, T_in, C_in, T_out, N;
+    int64_t ldx;           /* row stride of x in floats (>= C_in) */
+    int64_t ldy, ldr, ldg;
+    int32_t ksize, stride, pad_left, pad_right, pad_mode;
+    int32_t prologue;      /* 0 none, 1 ELU applied to x on load */
+    int32_t act;           /* 0 none, 1 ELU, 2 GELU(erf), 3 SiLU */
+    int32_t post_act;      /* applied after the residual add: 0 none, 1 ELU */
+} qa_conv_args;
+int qa_conv1d_cl(const qa_conv_args* args, void* stream);
+
+/* ---- UniSE AR-LM ------------------------------------------------------------------------------------ */
+
+typedef struct qa_lm_spec {
+    int32_t hidden;        /* 512   QuarkAudio-UniSE/conf/config.yaml:131-146 */
+    int32_t n_layers;      /* 12 */
+    int32_t n_heads;       /* 8 */
+    int32_t intermediate;  /* 2048 = 4*hidden (llm.py:69) */
+    int32_t global_size;   /* 4096 */
+    int32_t semantic_size; /* 8192 */
+    int32_t feats_dim;     /* 768 */
+    int32_t num_tasks;     /* 3 */
+    float rope_theta;      /* 10000 */
+    float rms_eps;         /* 1e-6 */
+} qa_lm_spec;
+
+typedef struct qa_lm qa_lm;
+
+int qa_lm_create(qa_lm** out, const qa_lm_spec* spec, const qa_tensor* tensors, int64_t n_tensors, int device);
+void qa_lm_destroy(qa_lm* lm);
+
+/* LLM_SFT.generate with do_sample=False (the reference's test path, model/model.py:173): greedy decoding of
+ * `global_length`+1 global tokens (last one discarded) then `semantic_length` semantic tokens.
+ *   task        0 se, 1 tse, 2 rtse (config.yaml:132-136)
+ *   enroll_feats [B, n_enroll, feats_dim] or NULL (SE prompt); mix_feats [B, n_mix, feats_dim]
+ *   global_ids  int64 [B, global_length]; semantic_ids int64 [B, semantic_length]  (offsets already subtracted)
+ * top_k / top_p / temperature are accepted for signature parity; with greedy decoding they cannot change the
+ * argmax (llm.py:262-286) and are validated only (0 < temperature <= 1, llm.py:278). */
+int qa_lm_generate(qa_lm* lm, int32_t task, const float* enroll_feats, int64_t n_enroll, const float* mix_feats,
+                   int64_t n_mix, int64_t B, int32_t global_length, int32_t semantic_length, float temperature,
+                   int32_t top_k, float top_p, int64_t* global_ids, int64_t* semantic_ids, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUARKAUDIO_H_ */

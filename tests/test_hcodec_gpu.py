@@ -1,0 +1,99 @@
+"""Whole-graph parity of the HIP H-Codec path (through Codec.encode / Codec.decode -> C-ABI) against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hcodec_ref as R
+from oracle import rvq_c, synth
+from tests.util import MINI, mini_oracle_spec, rel_err
+
+pytestmark = pytest.mark.gpu
+
+STAGE_TOL = 5e-5  # relative RMS per stage, fp32 everywhere; only summation order / libm differ
+
+
+def _cl(t):  # oracle [B,C,T] -> library layout [B,T,C], flattened
+    return t.transpose(1, 2).contiguous().flatten()
+
+
+def _make(spec_kwargs, seed, device):
+    import unified_audio_amd as qa
+
+    ospec = R.HCodecSpec(**spec_kwargs)
+    sd = synth.hcodec10_state_dict(seed, ospec)
+    codec = qa.Codec(None, None, None, spec=qa.HCodecSpec(**spec_kwargs), device=device).load_state_dict(sd)
+    return ospec, sd, codec
+
+
+def _run_parity(spec_kwargs, B, T, device, seed=11):
+    ospec, sd, codec = _make(spec_kwargs, seed, device)
+    wav = synth.synth_wav(seed + 1, B, T)
+    feat = synth.synth_feat(seed + 2, B, T // (ospec.enc_hop // 2), ospec.sem_in)
+    taps = {}
+    ac_o, sc_o = R.encode(sd, wav.unsqueeze(1), feat, ospec, taps)
+    ac, sc = codec.encode(wav.to(device).unsqueeze(1), feat.to(device))
+    torch.cuda.synchronize()
+    report = {}
+    for name in ["enc.conv0"] + [f"enc.stage{i}" for i in range(len(ospec.ratios))] + ["enc.transformer", "enc.emb", "enc.sem"]:
+        report[name] = rel_err(codec.tap(name), _cl(taps[name]))
+    tr = f"encoder.model.{3 * len(ospec.ratios) + 2}.layers.0.self_attn.rnn"
+    report[tr] = rel_err(codec.tap(tr), taps[tr].flatten())
+    # RVQ at the kernel boundary: feed the LIBRARY's own embeddings to the double-precision checker
+    emb = codec.tap("enc.emb").view(-1, ospec.code_dim).cpu().numpy()
+    sem = codec.tap("enc.sem").view(-1, ospec.code_dim).cpu().numpy()
+    cb_a = R.rvq_codebooks(sd, "quantizer", ospec.num_quantizers).numpy()
+    cb_s = R.rvq_codebooks(sd, "semantic_quantizer", ospec.num_quantizers).numpy()
+    for e, cb, codes in ((emb, cb_a, ac), (sem, cb_s, sc)):
+        got = codes.transpose(1, 2).reshape(-1, ospec.num_quantizers).cpu().numpy()
+        excess, best, gap = rvq_c.check_f64(e, cb, got)
+        tol = 2e-5 * float((e.astype(np.float64) ** 2).sum(1).mean())
+        assert excess.max() <= tol
+        assert (got[gap > tol] == best[gap > tol]).all()
+    agree = ((ac.cpu() == ac_o).float().mean().item(), (sc.cpu() == sc_o).float().mean().item())
+    # decode from the ORACLE's codes so that both sides start from identical integers
+    dtaps = {}
+    wav_o = R.decode(sd, ac_o, sc_o, ospec, dtaps)
+    wav_g = codec.decode(ac_o.to(device), sc_o.to(device))
+    torch.cuda.synchronize()
+    for name in ["dec.embed", "dec.prior_res1", "dec.transformer", "dec.prior"]:
+        report[name] = rel_err(codec.tap(name), _cl(dtaps[name]))
+    report["dec.backbone"] = rel_err(codec.tap("dec.backbone"), dtaps["dec.backbone"].flatten())
+    report["wav"] = rel_err(wav_g, wav_o)
+    return report, agree, (wav_g.cpu(), wav_o)
+
+
+def test_mini_codec_parity(qa_lib, gpu_device):
+    report, agree, (wav_g, wav_o) = _run_parity(MINI, B=3, T=16 * 40, device=gpu_device)
+    print(report, agree)
+    bad = {k: v for k, v in report.items() if not v < STAGE_TOL}
+    assert not bad, bad
+    assert min(agree) > 0.98
+    assert wav_g.shape == wav_o.shape
+
+
+def test_hcodec10_full_size_parity(qa_lib, gpu_device):
+    """The real H-Codec 1.0 architecture (141 M parameters) on 2 clips x 2 s (+ragged pad), seeded weights."""
+    spec_kwargs = {f: getattr(R.SPEC_10, f) for f in R.SPEC_10.__dataclass_fields__}
+    report, agree, (wav_g, wav_o) = _run_parity(spec_kwargs, B=2, T=640 * 51, device=gpu_device, seed=1234)
+    print(report, agree)
+    bad = {k: v for k, v in report.items() if not v < STAGE_TOL}
+    assert not bad, bad
+    assert min(agree) > 0.99
+    # north_star tolerance: <= 1e-3 RMS on the reconstructed waveform (we hold it relative to the signal RMS too)
+    assert float((wav_g - wav_o).pow(2).mean().sqrt()) < 1e-3
+    assert report["wav"] < 1e-3
+
+
+def test_encode_rejects_unpadded_wav(qa_lib, gpu_device):
+    import unified_audio_amd as qa
+
+    _, _, codec = _make(MINI, 3, gpu_device)
+    with pytest.raises(qa.QuarkAudioError):
+        codec.encode(torch.zeros(1, 1, 16 * 4 + 3, device=gpu_device), torch.zeros(1, 64, 8, device=gpu_device))
+
+
+def test_decode_rejects_out_of_range_codes(qa_lib, gpu_device):
+    _, _, codec = _make(MINI, 3, gpu_device)
+    bad = torch.full((1, 3, 4), 64, dtype=torch.int64)
+    with pytest.raises(IndexError):
+        codec.decode(bad, bad)

@@ -1,0 +1,160 @@
+"""Kernel-level parity through the C-ABI (qa_conv1d_cl, qa_rvq_search, qa_rvq_lookup) against CPU restatements."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import hcodec_ref as R
+from oracle import rvq_c
+from tests.util import act_ref, conv1d_cl, rel_err
+
+pytestmark = pytest.mark.gpu
+
+CONV_CASES = [
+    # B, T, Cin, N, k, stride, mode, prologue, act, post, gamma, res, gate
+    dict(B=1, T=300, Cin=64, N=70, k=1),                                     # plain linear, ragged M and N
+    dict(B=2, T=50, Cin=64, N=96, k=3, mode="zero"),                          # "same" conv
+    dict(B=3, T=37, Cin=32, N=64, k=8, stride=4, mode="reflect"),             # SConv1d with extra right padding
+    dict(B=2, T=2, Cin=32, N=32, k=16, stride=8, mode="reflect"),             # input shorter than the reflect pad
+    dict(B=2, T=5, Cin=32, N=32, k=10, stride=5, mode="reflect"),             # odd stride: asymmetric padding
+    dict(B=2, T=40, Cin=32, N=16, k=3, mode="reflect", prologue=1, act=1),    # SEANet residual branch, N < tile
+    dict(B=2, T=64, Cin=32, N=32, k=1, res=True, post=1),                     # shortcut + block, ELU after the add
+    dict(B=1, T=200, Cin=128, N=384, k=1, act=2),                             # GELU epilogue
+    dict(B=1, T=200, Cin=384, N=128, k=1, gamma=True, res=True),              # ConvNeXt pwconv2
+    dict(B=1, T=130, Cin=128, N=256, k=1, gate=True),                         # SwiGLU product
+    dict(B=2, T=100, Cin=64, N=64, k=4, stride=2, mode="zero1"),              # semantic strided conv (pad 1,1)
+    dict(B=4, T=250, Cin=256, N=300, k=3, mode="zero"),                       # 128x128 tiles, ragged N
+    dict(B=1, T=1, Cin=32, N=32, k=1),                                        # single row
+]
+
+
+def _ref_conv(x, w, bias, case):
+    """x [B,T,C], w [N,k,C] -> [B,T_out,N] with torch ops on CPU (the reference's own op sequence)."""
+    xc = x.transpose(1, 2)  # [B,C,T]
+    wc = w.permute(0, 2, 1).contiguous()  # [N,C,k]
+    k, stride = case["k"], case.get("stride", 1)
+    if case.get("prologue"):
+        xc = F.elu(xc)
+    mode = case.get("mode")
+    if mode == "reflect":
+        y = R.sconv1d(xc, wc, bias, stride)
+    elif mode == "zero":
+        y = F.conv1d(xc, wc, bias, stride=stride, padding=(k - 1) // 2)
+    elif mode == "zero1":
+        y = F.conv1d(xc, wc, bias, stride=stride, padding=1)
+    else:
+        y = F.conv1d(xc, wc, bias, stride=stride)
+    return y.transpose(1, 2)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
+def test_conv1d_cl_matches_torch(qa_lib, gpu_device, case):
+    g = torch.Generator().manual_seed(17)
+    B, T, Cin, N, k = case["B"], case["T"], case["Cin"], case["N"], case["k"]
+    stride = case.get("stride", 1)
+    x = torch.randn(B, T, Cin, generator=g)
+    w = torch.randn(N, k, Cin, generator=g) / (k * Cin) ** 0.5
+    bias = torch.randn(N, generator=g)
+    ref = _ref_conv(x, w, bias, case)
+    T_out = ref.shape[1]
+    gamma = torch.rand(N, generator=g) + 0.5 if case.get("gamma") else None
+    res = torch.randn(B, T_out, N, generator=g) if case.get("res") else None
+    gate = torch.randn(B, T_out, N, generator=g) if case.get("gate") else None
+    if gate is not None:
+        ref = F.silu(gate) * ref
+    ref = act_ref(ref, case.get("act", 0))
+    if gamma is not None:
+        ref = ref * gamma
+    if res is not None:
+        ref = ref + res
+    ref = act_ref(ref, case.get("post", 0))
+
+    mode = case.get("mode")
+    if mode == "reflect":
+        pt = k - stride
+        right = pt // 2
+        left = pt - right
+        extra = T_out * stride - T
+        pad, pm = (left, right + extra), 1
+    elif mode == "zero":
+        pad, pm = ((k - 1) // 2, (k - 1) // 2), 0
+    elif mode == "zero1":
+        pad, pm = (1, 1), 0
+    else:
+        pad, pm = (0, 0), 0
+    dev = gpu_device
+    y = conv1d_cl(qa_lib, x.to(dev), w.to(dev), bias.to(dev), stride=stride, pad=pad, pad_mode=pm,
+                  prologue=case.get("prologue", 0), act=case.get("act", 0), post_act=case.get("post", 0),
+                  gamma=None if gamma is None else gamma.to(dev), residual=None if res is None else res.to(dev),
+                  gate=None if gate is None else gate.to(dev), T_out=T_out)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    err = rel_err(y, ref)
+    assert err < 2e-6, f"rel err {err}"  # fp32 tolerance: only the summation order differs
+
+
+def _rvq_problem(n, Q, K, D, seed):
+    rng = np.random.default_rng(seed)
+    cb = np.stack([rng.standard_normal((K, D)).astype(np.float32) * (0.6 * 0.5 ** q) for q in range(Q)])
+    x = (rng.standard_normal((n, D)) * 0.6).astype(np.float32)
+    return x, cb
+
+
+@pytest.mark.parametrize("n,Q,K,D", [(1000, 4, 1024, 512), (33, 3, 64, 128), (1, 1, 1, 8), (257, 2, 100, 64)])
+def test_rvq_search_exact(qa_lib, gpu_device, n, Q, K, D):
+    """Indices are integer output: bit-exact against the fp32 oracle except where the two best codes are closer than
+    fp32 summation-order noise, and ALWAYS an exact arg-min of the double-precision distance up to that noise."""
+    from unified_audio_amd import _lib
+
+    x, cb = _rvq_problem(n, Q, K, D, seed=5)
+    xd, cbd = torch.from_numpy(x).to(gpu_device), torch.from_numpy(cb).to(gpu_device)
+    idx = torch.full((n, Q), -1, dtype=torch.int64, device=gpu_device)
+    qout = torch.empty((n, D), device=gpu_device)
+    _lib.check(qa_lib.qa_rvq_search(xd.data_ptr(), n, cbd.data_ptr(), Q, K, D, idx.data_ptr(), qout.data_ptr(), None))
+    torch.cuda.synchronize()
+    got = idx.cpu().numpy()
+    assert got.min() >= 0 and got.max() < K
+    excess, best, gap = rvq_c.check_f64(x, cb, got)
+    scale = float((x.astype(np.float64) ** 2).sum(1).mean())
+    tol = 2e-5 * scale  # fp32 dot products over D terms
+    assert excess.max() <= tol, f"non-optimal code chosen: excess {excess.max()} vs tol {tol}"
+    # wherever the decision is not a near-tie the index must equal the double-precision arg-min exactly
+    clear = gap > tol
+    assert (got[clear] == best[clear]).all()
+    # and agreement with the free-running fp32 C oracle and the torch restatement is (near-)total
+    ref_c = rvq_c.search_f32(x, cb)
+    ref_t, _ = R.rvq_search(torch.from_numpy(x), torch.from_numpy(cb))
+    frac_c = (got == ref_c).all(axis=1).mean()
+    frac_t = (got == ref_t.numpy()).all(axis=1).mean()
+    assert frac_c >= 0.999 and frac_t >= 0.999, (frac_c, frac_t)
+    # quantized_out = stage-ordered sum of the chosen codes, bit-exact
+    assert np.array_equal(qout.cpu().numpy(), rvq_c.lookup_f32(got, cb))
+
+
+def test_rvq_ties_resolve_to_lowest_index(qa_lib, gpu_device):
+    """Engineered exact ties: duplicated code vectors - the first copy must win (torch.max returns the first maximum)."""
+    from unified_audio_amd import _lib
+
+    rng = np.random.default_rng(3)
+    K, D, n = 96, 64, 64
+    cb = rng.standard_normal((1, K, D)).astype(np.float32)
+    cb[0, 40:80] = cb[0, 0:40]  # codes 40..79 duplicate 0..39, which sit in other 32-code tiles / other waves
+    x = cb[0, rng.integers(0, 40, size=n)] + 0.01 * rng.standard_normal((n, D)).astype(np.float32)
+    xd, cbd = torch.from_numpy(x).to(gpu_device), torch.from_numpy(cb).to(gpu_device)
+    idx = torch.empty((n, 1), dtype=torch.int64, device=gpu_device)
+    _lib.check(qa_lib.qa_rvq_search(xd.data_ptr(), n, cbd.data_ptr(), 1, K, D, idx.data_ptr(), None, None))
+    got = idx.cpu().numpy()[:, 0]
+    assert (got < 40).all()
+    assert np.array_equal(got, rvq_c.search_f32(x, cb)[:, 0])
+
+
+def test_rvq_lookup_exact(qa_lib, gpu_device):
+    from unified_audio_amd import _lib
+
+    x, cb = _rvq_problem(10, 4, 256, 128, seed=9)
+    rng = np.random.default_rng(1)
+    idx = rng.integers(0, 256, size=(777, 4)).astype(np.int64)
+    out = torch.empty((777, 128), device=gpu_device)
+    idx_d, cb_d = torch.from_numpy(idx).to(gpu_device), torch.from_numpy(cb).to(gpu_device)
+    _lib.check(qa_lib.qa_rvq_lookup(idx_d.data_ptr(), 777, cb_d.data_ptr(), 4, 256, 128, out.data_ptr(), None))
+    assert np.array_equal(out.cpu().numpy(), rvq_c.lookup_f32(idx, cb))

@@ -1,0 +1,53 @@
+"""Shared helpers of the test-suite (oracle side on CPU, product side through the C-ABI)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from oracle.hcodec_ref import HCodecSpec as OracleSpec
+
+# small architecture with the same block vocabulary as H-Codec 1.0 (channel ladder 32 -> 64 -> 128, hidden 16 in the
+# first residual block like the real model) so that whole-graph parity runs in seconds on CPU
+MINI = dict(n_filters=32, ratios=(2, 4), dimension=128, enc_heads=2, enc_layers=1, sem_in=64, sem_ch=64,
+            sem_strides=(2, 1), code_dim=128, codebook_size=64, num_quantizers=3, dec_dim=128, dec_inter=256,
+            dec_heads=4, dec_layers=1, convnext_layers=2, n_fft=32, hop=8, gn_groups=32)
+
+
+def mini_oracle_spec() -> OracleSpec:
+    return OracleSpec(**MINI)
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """RMS(a - b) / RMS(b)."""
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30))
+
+
+def conv1d_cl(lib, x, w, bias=None, *, stride=1, pad=(0, 0), pad_mode=0, prologue=0, act=0, gamma=None, residual=None,
+              gate=None, post_act=0, T_out=None):
+    """Call qa_conv1d_cl.  x [B,T,C] cuda, w [N,k,C] cuda (library layout).  Returns y [B,T_out,N]."""
+    from unified_audio_amd import _lib
+
+    B, T, Cin = x.shape
+    N, k, _ = w.shape
+    if T_out is None:
+        T_out = (T + pad[0] + pad[1] - k) // stride + 1
+    y = torch.full((B, T_out, N), float("nan"), device=x.device)
+    a = _lib.qa_conv_args()
+    a.x, a.w, a.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.gamma = gamma.data_ptr() if gamma is not None else None
+    a.residual = residual.data_ptr() if residual is not None else None
+    a.gate = gate.data_ptr() if gate is not None else None
+    a.B, a.T_in, a.C_in, a.T_out, a.N = B, T, Cin, T_out, N
+    a.ldx, a.ldy, a.ldr, a.ldg = Cin, N, N, N
+    a.ksize, a.stride, a.pad_left, a.pad_right, a.pad_mode = k, stride, pad[0], pad[1], pad_mode
+    a.prologue, a.act, a.post_act = prologue, act, post_act
+    _lib.check(lib.qa_conv1d_cl(C.byref(a), torch.cuda.current_stream().cuda_stream))
+    return y
+
+
+def act_ref(v, code):
+    return {0: lambda t: t, 1: F.elu, 2: F.gelu, 3: F.silu}[code](v)

@@ -1,0 +1,11 @@
+"""unified_audio_amd - MI355X-native (gfx950) hot path of alibaba/unified-audio (QuarkAudio).
+
+Only the path BASELINE.json's north_star names lives here: H-Codec encode -> RVQ -> decode and the UniSE AR-LM generate
+loop, as hand-written HIP kernels behind the C-ABI in include/quarkaudio.h, plus the thin Python mirror of the
+reference's own interface (`Codec.encode/decode`, `HCodecTokenizer.tokenize/detokenize`, `LLM_SFT.generate`).
+There is no CPU / PyTorch fallback: if libquarkaudio_hip.so is missing or no gfx950 device is visible, calls raise.
+"""
+from ._lib import QuarkAudioError, lib_path, load_library  # noqa: F401
+from .hcodec import Codec, HCodecSpec, HCodecTokenizer, SPEC_10  # noqa: F401
+
+__all__ = ["Codec", "HCodecSpec", "HCodecTokenizer", "SPEC_10", "QuarkAudioError", "load_library", "lib_path"]

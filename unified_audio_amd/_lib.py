@@ -1,0 +1,126 @@
+"""ctypes binding of libquarkaudio_hip.so (declarations mirror include/quarkaudio.h one to one)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libquarkaudio_hip.so"
+_lib: Optional[C.CDLL] = None
+
+
+class QuarkAudioError(RuntimeError):
+    """Raised for every non-zero qa_status; carries qa_last_error()."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"[qa_status {status}] {message}")
+        self.status = status
+
+
+class qa_tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
+
+
+class qa_hcodec_spec(C.Structure):
+    _fields_ = [
+        ("n_filters", C.c_int32), ("n_ratios", C.c_int32), ("ratios", C.c_int32 * 8), ("dimension", C.c_int32),
+        ("enc_heads", C.c_int32), ("enc_layers", C.c_int32), ("sem_in", C.c_int32), ("sem_ch", C.c_int32),
+        ("n_sem_strides", C.c_int32), ("sem_strides", C.c_int32 * 4), ("code_dim", C.c_int32),
+        ("codebook_size", C.c_int32), ("num_quantizers", C.c_int32), ("dec_dim", C.c_int32), ("dec_inter", C.c_int32),
+        ("dec_heads", C.c_int32), ("dec_layers", C.c_int32), ("convnext_layers", C.c_int32), ("n_fft", C.c_int32),
+        ("hop", C.c_int32), ("gn_groups", C.c_int32),
+    ]
+
+
+class qa_conv_args(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("gamma", C.c_void_p), ("residual", C.c_void_p),
+        ("gate", C.c_void_p), ("y", C.c_void_p),
+        ("B", C.c_int64), ("T_in", C.c_int64), ("C_in", C.c_int64), ("T_out", C.c_int64), ("N", C.c_int64),
+        ("ldx", C.c_int64), ("ldy", C.c_int64), ("ldr", C.c_int64), ("ldg", C.c_int64),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("pad_left", C.c_int32), ("pad_right", C.c_int32),
+        ("pad_mode", C.c_int32), ("prologue", C.c_int32), ("act", C.c_int32), ("post_act", C.c_int32),
+    ]
+
+
+class qa_lm_spec(C.Structure):
+    _fields_ = [
+        ("hidden", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("intermediate", C.c_int32),
+        ("global_size", C.c_int32), ("semantic_size", C.c_int32), ("feats_dim", C.c_int32), ("num_tasks", C.c_int32),
+        ("rope_theta", C.c_float), ("rms_eps", C.c_float),
+    ]
+
+
+# every symbol include/quarkaudio.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "qa_version": (C.c_int, []),
+    "qa_last_error": (C.c_char_p, []),
+    "qa_device_count": (C.c_int, []),
+    "qa_hcodec_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(qa_hcodec_spec), C.POINTER(qa_tensor), C.c_int64, C.c_int]),
+    "qa_hcodec_destroy": (None, [C.c_void_p]),
+    "qa_hcodec_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                   C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qa_hcodec_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "qa_hcodec_tap": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "qa_rvq_search": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                C.c_void_p, C.c_void_p]),
+    "qa_rvq_lookup": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                C.c_void_p]),
+    "qa_conv1d_cl": (C.c_int, [C.POINTER(qa_conv_args), C.c_void_p]),
+    "qa_lm_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(qa_lm_spec), C.POINTER(qa_tensor), C.c_int64, C.c_int]),
+    "qa_lm_destroy": (None, [C.c_void_p]),
+    "qa_lm_generate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                 C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
+                                 C.c_void_p]),
+}
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+def load_library() -> C.CDLL:
+    """Load the shared library (once).  Raises - never falls back - when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise QuarkAudioError(-2, f"{path} not found: build it with `python -m unified_audio_amd.build` "
+                                  "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI drifted
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise QuarkAudioError(status, load_library().qa_last_error().decode("utf-8", "replace"))
+
+
+def require_device() -> None:
+    if load_library().qa_device_count() <= 0:
+        raise QuarkAudioError(-2, "no HIP device visible: the quarkaudio hot path only runs on an MI355X (gfx950)")
+
+
+def tensor_table(state_dict):
+    """state_dict (name -> torch CPU tensor) -> (qa_tensor array, keep-alive list).  fp32 tensors only."""
+    import torch
+
+    keep, names = [], []
+    items = [(k, v) for k, v in state_dict.items() if torch.is_tensor(v) and v.dtype == torch.float32]
+    arr = (qa_tensor * len(items))()
+    for i, (k, v) in enumerate(items):
+        t = v.detach().to("cpu").contiguous()
+        nm = k.encode()
+        keep.append(t)
+        names.append(nm)
+        arr[i].name = nm
+        arr[i].data = t.data_ptr()
+        arr[i].numel = t.numel()
+    return arr, len(items), (keep, names)

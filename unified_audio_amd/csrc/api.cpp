@@ -1,0 +1,68 @@
+// api.cpp - error channel and the kernel-level C-ABI entry points.
+#include <cstdarg>
+#include <cstdio>
+
+#include "kernels.h"
+
+namespace qa {
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace qa
+
+using namespace qa;
+
+extern "C" {
+
+int qa_version(void) { return QA_VERSION; }
+const char* qa_last_error(void) { return g_err; }
+
+int qa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int qa_rvq_search(const float* x, int64_t n_vec, const float* codebooks, int32_t Q, int32_t K, int32_t D,
+                  int64_t* indices, float* quantized_out, void* stream) {
+    if (!x || !codebooks || !indices) {
+        set_error("qa_rvq_search: null argument");
+        return QA_ERR_INVALID;
+    }
+    QA_REQUIRE(n_vec >= 0 && Q > 0 && K > 0 && D > 0, "qa_rvq_search: bad shape");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* e2 = nullptr;
+    QA_HIP(hipMallocAsync(reinterpret_cast<void**>(&e2), sizeof(float) * (size_t)Q * K, s));
+    int st = launch_rvq_norms(codebooks, e2, Q * K, D, s);
+    if (st == QA_OK)
+        st = launch_rvq_search(x, n_vec, codebooks, e2, Q, K, D, reinterpret_cast<long long*>(indices), quantized_out, D, s);
+    (void)hipFreeAsync(e2, s);
+    return st;
+}
+
+int qa_rvq_lookup(const int64_t* indices, int64_t n_vec, const float* codebooks, int32_t Q, int32_t K, int32_t D,
+                  float* out, void* stream) {
+    if (!indices || !codebooks || !out) {
+        set_error("qa_rvq_lookup: null argument");
+        return QA_ERR_INVALID;
+    }
+    QA_REQUIRE(n_vec >= 0 && Q > 0 && K > 0 && D > 0, "qa_rvq_lookup: bad shape");
+    return launch_rvq_lookup(reinterpret_cast<const long long*>(indices), n_vec, codebooks, Q, K, D, out, D,
+                             static_cast<hipStream_t>(stream));
+}
+
+int qa_conv1d_cl(const qa_conv_args* args, void* stream) {
+    if (!args) {
+        set_error("qa_conv1d_cl: null argument");
+        return QA_ERR_INVALID;
+    }
+    ConvParams p;
+    QA_TRY(conv_params_from_args(*args, &p));
+    return launch_conv_gemm(p, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

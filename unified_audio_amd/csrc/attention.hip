@@ -1,0 +1,169 @@
+// attention.hip - fp32 flash-style attention on the f32 matrix cores.
+//
+// Reference semantics: softmax(Q K^T * head_dim^-0.5, fp32) V, no mask for the codec transformers
+// (QuarkAudio-HCodec/HCodec-1.0/vq/encoder_modules/transformer.py:158-180) and a causal mask over a KV cache for the
+// UniSE Llama layers (QuarkAudio-UniSE/model/llm/llm.py:182-211).  RoPE has already been applied to q / k.
+//
+// One wave64 owns 32 queries and walks the keys 32 at a time; both products run TRANSPOSED on
+// v_mfma_f32_32x32x2_f32 so that every softmax statistic is per lane (no cross-lane row reductions):
+//   S^T[key, q] = sum_d K[key, d] Q[q, d]     A = K tile (LDS, ds_read_b128), B = Q (registers)
+//   O^T[d,  q] += sum_key V[key, d] P[q, key] A = V tile (LDS),               B = P = exp(S - m) (registers)
+// The 32x32 accumulator layout gives lane (q = lane & 31, h = lane >> 5) the keys (r&3) + 8*(r>>2) + 4*h for r = 0..15,
+// which is exactly the k-slot order used for the second product, so P never leaves the registers.
+#include "kernels.h"
+
+namespace qa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int HD>
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, long long ldq,
+                                                        const float* __restrict__ k, const float* __restrict__ v,
+                                                        long long ldkv, long long kv_bstride, float* __restrict__ out,
+                                                        long long ldo, int n_q, int n_keys, float scale, int causal) {
+    constexpr int LD = HD + 4;
+    constexpr int DT = HD / 32;
+    constexpr int NG = HD / 8;
+    __shared__ __attribute__((aligned(16))) float sK[32 * LD];
+    __shared__ __attribute__((aligned(16))) float sV[32 * LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int q_blk0 = blockIdx.x * 128;
+    const int qi = q_blk0 + wave * 32 + ql;
+    const int off = n_keys - n_q;  // causal: key j visible iff j <= qi + off
+
+    // Q fragment: lane (q, h) keeps d = 8g + 4h + e  ->  qreg[4g + e]
+    float qreg[HD / 2];
+    {
+        const int qrow = qi < n_q ? qi : n_q - 1;
+        const float* qp = q + ((long long)b * n_q + qrow) * ldq + head * HD + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float4 t = *reinterpret_cast<const float4*>(qp + 8 * g);
+            qreg[4 * g + 0] = t.x; qreg[4 * g + 1] = t.y; qreg[4 * g + 2] = t.z; qreg[4 * g + 3] = t.w;
+        }
+    }
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const float* kb = k + (long long)b * kv_bstride + head * HD;
+    const float* vb = v + (long long)b * kv_bstride + head * HD;
+
+    int last_key = n_keys - 1;
+    if (causal) {
+        const int q_last = min(q_blk0 + 127, n_q - 1);
+        last_key = min(last_key, q_last + off);
+    }
+    const int n_tiles = last_key / 32 + 1;
+    const int wave_last_key = causal ? min(n_keys - 1, min(q_blk0 + wave * 32 + 31, n_q - 1) + off) : n_keys - 1;
+
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        __syncthreads();
+        // stage K / V tile (32 keys x HD), zero-filled past n_keys
+        for (int i = tid; i < 32 * (HD / 4); i += 256) {
+            const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
+            const int key = kt * 32 + row;
+            float4 kk4 = make_float4(0.f, 0.f, 0.f, 0.f), vv4 = kk4;
+            if (key < n_keys) {
+                kk4 = *reinterpret_cast<const float4*>(kb + (long long)key * ldkv + c4);
+                vv4 = *reinterpret_cast<const float4*>(vb + (long long)key * ldkv + c4);
+            }
+            *reinterpret_cast<float4*>(sK + row * LD + c4) = kk4;
+            *reinterpret_cast<float4*>(sV + row * LD + c4) = vv4;
+        }
+        __syncthreads();
+        if (kt * 32 > wave_last_key) continue;  // wave-uniform: whole tile masked for this wave
+
+        // S^T = K Q^T
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const float* kp = sK + ql * LD + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(kp + 8 * g);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * g + 0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * g + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * g + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * g + 3], s, 0, 0, 0);
+        }
+        // online softmax (per lane = per query; the two halves of the wave hold interleaved key groups)
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const bool ok = key < n_keys && (!causal || key <= qi + off);
+            s[r] = ok ? s[r] * scale : -INFINITY;
+            tmax = fmaxf(tmax, s[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = expf(m_run - m_use);  // m_run = -inf -> 0
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = expf(s[r] - m_use);
+            psum += s[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        // O^T += V^T P^T ; k-slot (step st, half h) <-> key (st&3) + 8*(st>>2) + 4*h
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int key = (st & 3) + 8 * (st >> 2) + 4 * hh;
+            const float* vp = sV + key * LD + ql;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * t], s[st], o[t], 0, 0, 0);
+        }
+    }
+
+    if (qi < n_q) {
+        const float inv = 1.f / l_run;
+        float* op = out + ((long long)b * n_q + qi) * ldo + head * HD + 4 * hh;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float4 w;
+                w.x = o[t][4 * c + 0] * inv; w.y = o[t][4 * c + 1] * inv;
+                w.z = o[t][4 * c + 2] * inv; w.w = o[t][4 * c + 3] * inv;
+                *reinterpret_cast<float4*>(op + 32 * t + 8 * c) = w;
+            }
+    }
+}
+
+int launch_attention(const float* q, long long ldq, const float* k, const float* v, long long ldkv, float* out,
+                     long long ldo, int B, int n_q, int n_keys, long long kv_batch_stride, int H, int hd, float scale,
+                     int causal, hipStream_t s) {
+    QA_REQUIRE(n_q > 0 && n_keys > 0 && (!causal || n_keys >= n_q), "attention: n_q=%d n_keys=%d", n_q, n_keys);
+    QA_REQUIRE((ldq % 4) == 0 && (ldkv % 4) == 0 && (ldo % 4) == 0, "attention: strides must be multiples of 4");
+    dim3 grid((unsigned)ceil_div(n_q, 128), H, B);
+#define QA_ATT(HD)                                                                                                  \
+    hipLaunchKernelGGL(attention_kernel<HD>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, \
+                       n_keys, scale, causal)
+    switch (hd) {
+        case 32: QA_ATT(32); break;
+        case 64: QA_ATT(64); break;
+        case 96: QA_ATT(96); break;
+        case 128: QA_ATT(128); break;
+        default: qa::set_error("attention: head_dim=%d unsupported (32/64/96/128)", hd); return QA_ERR_UNSUPPORTED;
+    }
+#undef QA_ATT
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+}  // namespace qa

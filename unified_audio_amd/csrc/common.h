@@ -1,0 +1,103 @@
+// common.h - shared host/device helpers for libquarkaudio_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "quarkaudio.h"
+
+namespace qa {
+
+void set_error(const char* fmt, ...);
+
+#define QA_HIP(expr)                                                                                    \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            qa::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);   \
+            return QA_ERR_HIP;                                                                          \
+        }                                                                                               \
+    } while (0)
+
+#define QA_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            qa::set_error(__VA_ARGS__);       \
+            return QA_ERR_INVALID;            \
+        }                                     \
+    } while (0)
+
+#define QA_TRY(expr)               \
+    do {                           \
+        int s_ = (expr);           \
+        if (s_ != QA_OK) return s_; \
+    } while (0)
+
+#define QA_LAUNCH_CHECK() QA_HIP(hipGetLastError())
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+// ---- activation codes shared by kernels (match qa_conv_args) ----
+enum { ACT_NONE = 0, ACT_ELU = 1, ACT_GELU = 2, ACT_SILU = 3 };
+enum { PAD_ZERO = 0, PAD_REFLECT = 1 };
+
+__device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case ACT_ELU: return elu_f(v);
+        case ACT_GELU: return gelu_erf_f(v);
+        case ACT_SILU: return silu_f(v);
+        default: return v;
+    }
+}
+
+// Source-frame resolution for the padded convolutions.
+//   zero:    frames outside [0, L) read as 0 (returns -1)
+//   reflect: SConv1d's pad1d (encoder_modules/conv.py:79-96 of the reference): when L <= max_pad the
+//            signal is first zero-extended to Lp = max_pad + 1 frames, reflected, then trimmed, so a
+//            reflected index may land in the zero extension (returns -1).
+__host__ __device__ __forceinline__ int resolve_frame(int r, int L, int Lp, int pad_mode) {
+    if (pad_mode == PAD_REFLECT) {
+        if (r < 0) r = -r;
+        else if (r >= Lp) r = 2 * (Lp - 1) - r;
+        return (r >= 0 && r < L) ? r : -1;
+    }
+    return (r >= 0 && r < L) ? r : -1;
+}
+
+// wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- kernel launchers (host) ----
+struct ConvParams {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* gamma;
+    const float* res;
+    const float* gate;
+    float* y;
+    long long ldx, ldy, ldr, ldg;
+    int B, T_in, C_in, T_out, N, K, M;
+    int ksize, stride, pad_left, pad_mode, Lp;
+    int prologue, act, post_act;
+};
+int launch_conv_gemm(const ConvParams& p, hipStream_t stream);
+int conv_params_from_args(const qa_conv_args& a, ConvParams* p);
+
+}  // namespace qa

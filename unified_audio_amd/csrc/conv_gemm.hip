@@ -1,0 +1,215 @@
+// conv_gemm.hip - implicit-GEMM Conv1d / Linear over channel-last activations on the fp32 matrix cores.
+//
+// Replaces every Conv1d / Linear of the reference's codec and LM graphs (SURVEY.md 2.2 K1,K2,K5-K7,K10-K13,K17):
+//   y[m, n] = post( res[m,n] + gamma[n] * act( silu(gate[m,n]) * (bias[n] + sum_k A[m,k] * W[n,k]) ) )
+// where row m = (b, t) of a [B, T_out] grid and A[m, (j, c)] = pro(x[b, src(t, j), c]) is gathered on the fly:
+// in channel-last layout the im2col row of a 1-D convolution is `ksize` contiguous C_in-long segments, so no
+// im2col buffer and no padded copy ever exist in HBM (reflect / zero padding are resolved per segment).
+//
+// gfx950 mapping: 256-thread workgroups (4 wave64), block tile BM x BN x 32, each wave owns a grid of 32x32
+// accumulators fed by v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 157 TFLOP/s peak).  Operands are staged
+// global -> registers -> LDS (double buffered, one barrier per K step, next tile's global loads issued before
+// the current tile's MFMAs).  LDS rows are padded to 36 floats so that the ds_read_b128 fragment loads are
+// bank-conflict free; each lane fetches 4 consecutive k per read and the (lane>>5) halves take k-groups
+// {0..3},{4..7}: the K order inside a step is permuted identically for A and B, which leaves the sum unchanged.
+#include "common.h"
+
+namespace qa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+    constexpr int BK = 32;
+    constexpr int LDS = BK + 4;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS];
+    float* sA = smem;
+    float* sB = smem + 2 * BM * LDS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM;
+    const int n0 = (blockIdx.x % tiles_n) * BN;
+
+    const int ld_row = tid >> 3;       // 0..31
+    const int ld_c4 = (tid & 7) * 4;   // float offset inside the 32-wide K chunk
+
+    // Per-thread A rows: batch base pointer and first source frame.
+    long long a_base[A_IT];
+    int a_t0[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + ld_row + 32 * i;
+        if (m < p.M) {
+            const int b = m / p.T_out;
+            const int t = m - b * p.T_out;
+            a_base[i] = (long long)b * p.T_in * p.ldx;
+            a_t0[i] = t * p.stride - p.pad_left;
+        } else {
+            a_base[i] = -1;
+            a_t0[i] = 0;
+        }
+    }
+    const float* b_ptr[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int n = n0 + ld_row + 32 * i;
+        b_ptr[i] = (n < p.N) ? p.w + (long long)n * p.K + ld_c4 : nullptr;
+    }
+
+    float4 a_reg[A_IT], b_reg[B_IT];
+    auto load_global = [&](int kc) {
+        const int k0 = kc * BK;
+        const int j = k0 / p.C_in;
+        const int c = k0 - j * p.C_in + ld_c4;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_base[i] >= 0) {
+                const int src = resolve_frame(a_t0[i] + j, p.T_in, p.Lp, p.pad_mode);
+                if (src >= 0) v = *reinterpret_cast<const float4*>(p.x + a_base[i] + (long long)src * p.ldx + c);
+            }
+            a_reg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            b_reg[i] = b_ptr[i] ? *reinterpret_cast<const float4*>(b_ptr[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_lds = [&](int buf) {
+        float* a = sA + buf * BM * LDS;
+        float* b = sB + buf * BN * LDS;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            float4 v = a_reg[i];
+            if (p.prologue == ACT_ELU) {
+                v.x = elu_f(v.x); v.y = elu_f(v.y); v.z = elu_f(v.z); v.w = elu_f(v.w);
+            }
+            *reinterpret_cast<float4*>(a + (ld_row + 32 * i) * LDS + ld_c4) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4*>(b + (ld_row + 32 * i) * LDS + ld_c4) = b_reg[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 4;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < nk) load_global(kc + 1);
+        const float* a = sA + cur * BM * LDS + (wm * WTM + frag_row) * LDS + frag_k;
+        const float* b = sB + cur * BN * LDS + (wn * WTN + frag_row) * LDS + frag_k;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS + kk * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kc + 1 < nk) store_lds(cur ^ 1);
+        __syncthreads();
+    }
+
+    // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    const int col_l = lane & 31, row_h = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WTN + j * 32 + col_l;
+            if (n >= p.N) continue;
+            const float bias = p.bias ? p.bias[n] : 0.f;
+            const float gamma = p.gamma ? p.gamma[n] : 1.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (p.gate) v = silu_f(p.gate[(long long)m * p.ldg + n]) * v;
+                v = apply_act(v, p.act);
+                if (p.gamma) v *= gamma;
+                if (p.res) v += p.res[(long long)m * p.ldr + n];
+                v = apply_act(v, p.post_act);
+                p.y[(long long)m * p.ldy + n] = v;
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const ConvParams& p, hipStream_t stream) {
+    const long long tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
+    QA_REQUIRE(p.K % 32 == 0 && p.C_in % 32 == 0, "conv_gemm: K=%d / C_in=%d must be multiples of 32", p.K, p.C_in);
+    QA_REQUIRE((p.ldx % 4) == 0, "conv_gemm: ldx=%lld must be a multiple of 4 floats", p.ldx);
+    QA_REQUIRE(((uintptr_t)p.x % 16) == 0 && ((uintptr_t)p.w % 16) == 0, "conv_gemm: x / w must be 16-byte aligned");
+    if (p.M <= 0 || p.N <= 0) return QA_OK;
+    QA_REQUIRE(ceil_div(p.M, 64) * ceil_div(p.N, 32) < (1LL << 31), "conv_gemm: grid too large");
+    if (p.N <= 32) return launch_cfg<256, 32, 4, 1>(p, stream);
+    if (p.N <= 64) return launch_cfg<128, 64, 2, 2>(p, stream);
+    // few tiles: prefer the narrower tile so that more than one wave of workgroups exists
+    const long long big = ceil_div(p.M, 128) * ceil_div(p.N, 128);
+    if (big < 512) return launch_cfg<128, 64, 2, 2>(p, stream);
+    return launch_cfg<128, 128, 2, 2>(p, stream);
+}
+
+int conv_params_from_args(const qa_conv_args& a, ConvParams* out) {
+    ConvParams p{};
+    QA_REQUIRE(a.x && a.w && a.y, "conv1d_cl: x, w, y must be non-null");
+    QA_REQUIRE(a.B > 0 && a.T_in > 0 && a.C_in > 0 && a.N > 0 && a.T_out >= 0, "conv1d_cl: bad shape");
+    QA_REQUIRE(a.ksize >= 1 && a.stride >= 1 && a.pad_left >= 0 && a.pad_right >= 0, "conv1d_cl: bad geometry");
+    QA_REQUIRE(a.B * a.T_out < (1LL << 31) && a.ksize * a.C_in < (1LL << 31), "conv1d_cl: shape too large");
+    p.x = a.x; p.w = a.w; p.bias = a.bias; p.gamma = a.gamma; p.res = a.residual; p.gate = a.gate; p.y = a.y;
+    p.ldx = a.ldx ? a.ldx : a.C_in;
+    p.ldy = a.ldy ? a.ldy : a.N;
+    p.ldr = a.ldr ? a.ldr : a.N;
+    p.ldg = a.ldg ? a.ldg : a.N;
+    p.B = (int)a.B; p.T_in = (int)a.T_in; p.C_in = (int)a.C_in; p.T_out = (int)a.T_out; p.N = (int)a.N;
+    p.K = (int)(a.ksize * a.C_in);
+    p.M = (int)(a.B * a.T_out);
+    p.ksize = a.ksize; p.stride = a.stride; p.pad_left = a.pad_left; p.pad_mode = a.pad_mode;
+    const int max_pad = a.pad_left > a.pad_right ? a.pad_left : a.pad_right;
+    p.Lp = (p.T_in <= max_pad) ? max_pad + 1 : p.T_in;
+    // every window must stay inside the padded signal
+    QA_REQUIRE(a.T_out == 0 || (a.T_out - 1) * (int64_t)a.stride + a.ksize <= a.pad_left + a.T_in + a.pad_right,
+               "conv1d_cl: T_out=%lld windows do not fit pad_left=%d + T_in=%lld + pad_right=%d", (long long)a.T_out,
+               a.pad_left, (long long)a.T_in, a.pad_right);
+    p.prologue = a.prologue; p.act = a.act; p.post_act = a.post_act;
+    *out = p;
+    return QA_OK;
+}
+
+}  // namespace qa

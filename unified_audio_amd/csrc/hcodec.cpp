@@ -1,0 +1,766 @@
+// hcodec.cpp - H-Codec 1.0 encode / decode graphs on top of the HIP kernels (host orchestration, C-ABI handle).
+//
+// Mirrors, stage for stage, Codec.encode / Codec.decode of the reference
+// (QuarkAudio-HCodec/HCodec-1.0/vq/codec.py:166-187) with every activation kept time-major / channel-last
+// ([B, frames, C] rows) so that all convolutions and linears are one implicit-GEMM kernel (conv_gemm.hip).
+// Weights arrive in the reference's state_dict layout; weight-norm is folded and filters re-laid out here, once.
+#include <memory>
+
+#include "host_util.h"
+
+namespace qa {
+
+namespace {
+
+struct TransformerLayerW {
+    const float *ln1, *ln2;
+    ConvW ih;            // [4d][d] rows in (unit, gate) order, bias = b_ih + b_hh
+    const float* w_hh;   // [4d][d] rows in (unit, gate) order
+    ConvW qkv, o, w1, w3, w2;
+};
+
+struct TransformerW {
+    std::vector<TransformerLayerW> layers;
+    int d = 0, heads = 0;
+    const float* rope = nullptr;  // [MAX_POS][hd/2][2]
+};
+
+struct ResBlockW {  // SEANetResnetBlock
+    ConvW k3, pw, sc;
+};
+struct DecResW {  // ResnetBlock (GroupNorm + swish)
+    const float *n1w, *n1b, *n2w, *n2b;
+    ConvW c1, c2;
+};
+struct ConvNeXtW {
+    const float *dw, *dwb, *lnw, *lnb, *gamma;
+    ConvW pw1, pw2;
+};
+
+constexpr int MAX_POS = 8192;
+
+}  // namespace
+
+}  // namespace qa
+
+using namespace qa;
+
+struct qa_hcodec {
+    qa_hcodec_spec spec{};
+    int device = 0;
+    WeightStore store;
+    // encoder
+    const float *conv0_w = nullptr, *conv0_b = nullptr;
+    std::vector<ResBlockW> res;
+    std::vector<ConvW> down;
+    TransformerW enc_tr;
+    ConvW enc_out;
+    // semantic encoder
+    ConvW sem_in;
+    struct SemBlock {
+        ConvW u1[2], u2[2], conv;
+        int stride;
+    };
+    std::vector<SemBlock> sem_blocks;
+    ConvW sem_out;
+    // rvq
+    const float *cb_a = nullptr, *cb_s = nullptr, *e2_a = nullptr, *e2_s = nullptr;
+    float* e2_dev = nullptr;
+    // decoder
+    ConvW up;
+    const float *up_dw = nullptr, *up_dwb = nullptr;
+    DecResW dres[4];
+    TransformerW dec_tr;
+    const float *gn_w = nullptr, *gn_b = nullptr, *norm_w = nullptr, *norm_b = nullptr, *fnorm_w = nullptr,
+                *fnorm_b = nullptr;
+    std::vector<ConvNeXtW> cnx;
+    ConvW head, basis;
+    const float* window = nullptr;
+    int spec_ld = 0;
+    // workspace
+    char* ws = nullptr;
+    size_t ws_cap = 0;
+    Ctx ctx;
+};
+
+namespace qa {
+namespace {
+
+// ---------------------------------------------------------------- weight folding (host)
+
+struct Folder {
+    const HostTable& tab;
+    WeightStore& store;
+    bool ok = true;
+    int status = QA_OK;
+
+    const float* need(const std::string& name, int64_t numel) {
+        const float* p = tab.get(name, numel);
+        if (!p) {
+            ok = false;
+            status = QA_ERR_MISSING;
+        }
+        return p;
+    }
+    size_t vec(const std::string& name, int64_t n) {
+        const float* p = need(name, n);
+        if (!p) return 0;
+        return store.add(p, n);
+    }
+    // Conv weight [N][C_in][k] (optionally weight-normed: prefix.weight_g / weight_v) -> [Np][k][Cp], bias -> [Np]
+    // returns offsets through the out params (pointers are resolved after upload)
+    void conv(const std::string& p, int N, int C_in, int k, bool wn, bool bias, int Np, int Cp, size_t* w_off,
+              size_t* b_off) {
+        std::vector<float> w((size_t)Np * k * Cp, 0.f);
+        const int64_t numel = (int64_t)N * C_in * k;
+        const float* v = need(p + (wn ? ".weight_v" : ".weight"), numel);
+        const float* g = wn ? need(p + ".weight_g", N) : nullptr;
+        if (v && (!wn || g)) {
+            for (int n = 0; n < N; ++n) {
+                float scale = 1.f;
+                if (wn) {
+                    // torch._weight_norm: w = v * (g / ||v||_2), norm over (C_in, k), computed in fp32
+                    double ss = 0.0;
+                    for (int64_t i = 0; i < (int64_t)C_in * k; ++i) {
+                        const float a = v[(int64_t)n * C_in * k + i];
+                        ss += (double)a * a;
+                    }
+                    scale = g[n] / (float)std::sqrt(ss);
+                }
+                for (int c = 0; c < C_in; ++c)
+                    for (int j = 0; j < k; ++j)
+                        w[((size_t)n * k + j) * Cp + c] = v[((int64_t)n * C_in + c) * k + j] * scale;
+            }
+        }
+        *w_off = store.add(w);
+        if (bias) {
+            std::vector<float> b(Np, 0.f);
+            const float* bp = need(p + ".bias", N);
+            if (bp) std::memcpy(b.data(), bp, sizeof(float) * N);
+            *b_off = store.add(b);
+        }
+    }
+};
+
+struct PendingConv {
+    ConvW* dst;
+    size_t w_off, b_off;
+    bool has_bias;
+};
+
+struct Builder {
+    Folder f;
+    std::vector<PendingConv> pend;
+    std::vector<std::pair<const float**, size_t>> pend_vec;
+
+    void conv(ConvW* dst, const std::string& p, int N, int C_in, int k, bool wn, bool bias, int Np = -1, int Cp = -1) {
+        if (Np < 0) Np = N;
+        if (Cp < 0) Cp = C_in;
+        PendingConv pc{dst, 0, 0, bias};
+        f.conv(p, N, C_in, k, wn, bias, Np, Cp, &pc.w_off, &pc.b_off);
+        dst->N = Np;
+        dst->C_in = Cp;
+        dst->ksize = k;
+        pend.push_back(pc);
+    }
+    void vec(const float** dst, const std::string& name, int64_t n) { pend_vec.push_back({dst, f.vec(name, n)}); }
+    void raw(const float** dst, const std::vector<float>& v) { pend_vec.push_back({dst, f.store.add(v)}); }
+    void resolve() {
+        for (auto& pc : pend) {
+            pc.dst->w = f.store.ptr(pc.w_off);
+            pc.dst->b = pc.has_bias ? f.store.ptr(pc.b_off) : nullptr;
+        }
+        for (auto& pv : pend_vec) *pv.first = f.store.ptr(pv.second);
+    }
+};
+
+// rows of an LSTM matrix / bias go from PyTorch's gate-major order (i,f,g,o blocks of d) to (unit, gate)
+void build_transformer(Builder& b, TransformerW* tw, const std::string& p, int d, int n_layers, int heads) {
+    tw->d = d;
+    tw->heads = heads;
+    tw->layers.resize(n_layers);
+    for (int l = 0; l < n_layers; ++l) {
+        TransformerLayerW& L = tw->layers[l];
+        const std::string lp = p + ".layers." + std::to_string(l);
+        const std::string ap = lp + ".self_attn";
+        b.vec(&L.ln1, lp + ".input_layernorm.weight", d);
+        b.vec(&L.ln2, lp + ".post_attention_layernorm.weight", d);
+        const float* wih = b.f.need(ap + ".rnn.weight_ih_l0", (int64_t)4 * d * d);
+        const float* whh = b.f.need(ap + ".rnn.weight_hh_l0", (int64_t)4 * d * d);
+        const float* bih = b.f.need(ap + ".rnn.bias_ih_l0", 4 * d);
+        const float* bhh = b.f.need(ap + ".rnn.bias_hh_l0", 4 * d);
+        std::vector<float> wi((size_t)4 * d * d, 0.f), wh((size_t)4 * d * d, 0.f), bb((size_t)4 * d, 0.f);
+        if (wih && whh && bih && bhh) {
+            for (int u = 0; u < d; ++u)
+                for (int g = 0; g < 4; ++g) {
+                    const size_t dst = (size_t)u * 4 + g, src = (size_t)g * d + u;
+                    std::memcpy(&wi[dst * d], &wih[src * d], sizeof(float) * d);
+                    std::memcpy(&wh[dst * d], &whh[src * d], sizeof(float) * d);
+                    bb[dst] = bih[src] + bhh[src];
+                }
+        }
+        L.ih.N = 4 * d; L.ih.C_in = d; L.ih.ksize = 1;
+        b.raw(&L.ih.w, wi);
+        b.raw(&L.ih.b, bb);
+        b.raw(&L.w_hh, wh);
+        // fused QKV
+        std::vector<float> wq((size_t)3 * d * d, 0.f), bq((size_t)3 * d, 0.f);
+        const char* names[3] = {".q_proj", ".k_proj", ".v_proj"};
+        for (int i = 0; i < 3; ++i) {
+            const float* w = b.f.need(ap + names[i] + ".weight", (int64_t)d * d);
+            const float* bi = b.f.need(ap + names[i] + ".bias", d);
+            if (w) std::memcpy(&wq[(size_t)i * d * d], w, sizeof(float) * d * d);
+            if (bi) std::memcpy(&bq[(size_t)i * d], bi, sizeof(float) * d);
+        }
+        L.qkv.N = 3 * d; L.qkv.C_in = d; L.qkv.ksize = 1;
+        b.raw(&L.qkv.w, wq);
+        b.raw(&L.qkv.b, bq);
+        L.o.N = d; L.o.C_in = d; L.o.ksize = 1;
+        b.vec(&L.o.w, ap + ".o_proj.weight", (int64_t)d * d);
+        L.w1.N = 4 * d; L.w1.C_in = d; L.w1.ksize = 1;
+        b.vec(&L.w1.w, lp + ".mlp.w1.weight", (int64_t)4 * d * d);
+        L.w3.N = 4 * d; L.w3.C_in = d; L.w3.ksize = 1;
+        b.vec(&L.w3.w, lp + ".mlp.w3.weight", (int64_t)4 * d * d);
+        L.w2.N = d; L.w2.C_in = 4 * d; L.w2.ksize = 1;
+        b.vec(&L.w2.w, lp + ".mlp.w2.weight", (int64_t)4 * d * d);
+    }
+    // RoPE table, RotaryEmbedding of transformer.py:8-74 evaluated in fp32 like the reference
+    const int hd = d / heads, half = hd / 2;
+    std::vector<float> cs((size_t)MAX_POS * half * 2);
+    for (int i = 0; i < half; ++i) {
+        const float expo = (float)(2 * i) / (float)hd;
+        const float inv = 1.0f / std::pow(10000.0f, expo);
+        for (int t = 0; t < MAX_POS; ++t) {
+            const float fr = (float)t * inv;
+            cs[((size_t)t * half + i) * 2] = (float)std::cos((double)fr);
+            cs[((size_t)t * half + i) * 2 + 1] = (float)std::sin((double)fr);
+        }
+    }
+    b.raw(&tw->rope, cs);
+}
+
+// ---------------------------------------------------------------- graph helpers
+
+int conv_op(Ctx& c, const float* x, int64_t ldx, int B, int T_in, const ConvW& w, float* y, int64_t ldy, int T_out,
+            int stride, int pad_left, int pad_right, int pad_mode, int prologue, int act, const float* gamma,
+            const float* res, int64_t ldr, const float* gate, int post_act) {
+    if (c.dry) return QA_OK;
+    qa_conv_args a{};
+    a.x = x; a.w = w.w; a.bias = w.b; a.gamma = gamma; a.residual = res; a.gate = gate; a.y = y;
+    a.B = B; a.T_in = T_in; a.C_in = w.C_in; a.T_out = T_out; a.N = w.N;
+    a.ldx = ldx; a.ldy = ldy; a.ldr = ldr; a.ldg = w.N;
+    a.ksize = w.ksize; a.stride = stride; a.pad_left = pad_left; a.pad_right = pad_right; a.pad_mode = pad_mode;
+    a.prologue = prologue; a.act = act; a.post_act = post_act;
+    ConvParams p;
+    QA_TRY(conv_params_from_args(a, &p));
+    return launch_conv_gemm(p, c.stream);
+}
+
+// plain linear over `rows` rows
+int linear_op(Ctx& c, const float* x, int64_t rows, const ConvW& w, float* y, int act = ACT_NONE,
+              const float* res = nullptr, const float* gate = nullptr, const float* gamma = nullptr) {
+    return conv_op(c, x, w.C_in, 1, (int)rows, w, y, w.N, (int)rows, 1, 0, 0, PAD_ZERO, ACT_NONE, act, gamma, res, w.N,
+                   gate, ACT_NONE);
+}
+
+// "same" zero-padded stride-1 conv (vq/conv.py:33-56, semantic_module.py:28-31)
+int conv_same(Ctx& c, const float* x, int B, int T, const ConvW& w, float* y, int prologue = ACT_NONE,
+              int act = ACT_NONE, const float* res = nullptr) {
+    const int pad = (w.ksize - 1) / 2;
+    return conv_op(c, x, w.C_in, B, T, w, y, w.N, T, 1, pad, pad, PAD_ZERO, prologue, act, nullptr, res, w.N, nullptr,
+                   ACT_NONE);
+}
+
+// SConv1d geometry (encoder_modules/conv.py:195-211, non-causal): returns T_out and the paddings
+struct SGeom {
+    int T_out, left, right;
+};
+SGeom sconv_geom(int L, int k, int stride) {
+    const int pad_total = k - stride;
+    const int T_out = (int)ceil_div(L, stride);
+    const int extra = T_out * stride - L;
+    const int right = pad_total / 2, left = pad_total - right;
+    return {T_out, left, right + extra};
+}
+
+int transformer_op(Ctx& c, const TransformerW& tw, float* x, int B, int N, const std::string& tap_prefix) {
+    const int d = tw.d, H = tw.heads, hd = d / H;
+    const int64_t rows = (int64_t)B * N;
+    QA_REQUIRE(N <= MAX_POS, "transformer: sequence of %d frames exceeds %d", N, MAX_POS);
+    const size_t mark = c.arena.mark();
+    float* hn = c.arena.alloc<float>(rows * d);
+    float* big = c.arena.alloc<float>(rows * 4 * d);   // xw / gate buffer
+    float* big2 = c.arena.alloc<float>(rows * 4 * d);  // swiglu product
+    float* hl = c.arena.alloc<float>(rows * d);
+    float* qkv = c.arena.alloc<float>(rows * 3 * d);
+    float* att = c.arena.alloc<float>(rows * d);
+    float* cst = c.arena.alloc<float>((size_t)B * d);
+    for (size_t l = 0; l < tw.layers.size(); ++l) {
+        const TransformerLayerW& L = tw.layers[l];
+        if (!c.dry) {
+            QA_TRY(launch_rmsnorm(x, L.ln1, hn, rows, d, 1e-6f, c.stream));
+            QA_TRY(linear_op(c, hn, rows, L.ih, big));
+            QA_TRY(launch_lstm(big, L.w_hh, hl, cst, B, N, d, c.stream));
+            c.tap(tap_prefix + ".layers." + std::to_string(l) + ".self_attn.rnn", hl, rows * d);
+            QA_TRY(linear_op(c, hl, rows, L.qkv, qkv));
+            QA_TRY(launch_rope(qkv, tw.rope, B, N, H, hd, 3 * d, 0, c.stream));
+            QA_TRY(launch_attention(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, B, N, N, (long long)N * 3 * d, H, hd,
+                                    1.0f / std::sqrt((float)hd), 0, c.stream));
+            QA_TRY(linear_op(c, att, rows, L.o, x, ACT_NONE, x));
+            QA_TRY(launch_rmsnorm(x, L.ln2, hn, rows, d, 1e-6f, c.stream));
+            QA_TRY(linear_op(c, hn, rows, L.w1, big));
+            QA_TRY(linear_op(c, hn, rows, L.w3, big2, ACT_NONE, nullptr, big));
+            QA_TRY(linear_op(c, big2, rows, L.w2, x, ACT_NONE, x));
+        }
+    }
+    c.arena.release(mark);
+    return QA_OK;
+}
+
+int groupnorm_op(Ctx& c, const float* x, const float* w, const float* b, float* y, int B, int T, int C, int G,
+                 int swish) {
+    const size_t mark = c.arena.mark();
+    double* scratch = c.arena.alloc<double>(groupnorm_scratch_bytes(B, T, G) / sizeof(double));
+    int st = QA_OK;
+    if (!c.dry) st = launch_groupnorm(x, w, b, y, scratch, B, T, C, G, 1e-6f, swish, c.stream);
+    c.arena.release(mark);
+    return st;
+}
+
+int dec_resblock_op(Ctx& c, const DecResW& w, float* x, int B, int T, int C, int G) {
+    const size_t mark = c.arena.mark();
+    float* t1 = c.arena.alloc<float>((size_t)B * T * C);
+    float* t2 = c.arena.alloc<float>((size_t)B * T * C);
+    QA_TRY(groupnorm_op(c, x, w.n1w, w.n1b, t1, B, T, C, G, 1));
+    QA_TRY(conv_same(c, t1, B, T, w.c1, t2));
+    QA_TRY(groupnorm_op(c, t2, w.n2w, w.n2b, t1, B, T, C, G, 1));
+    QA_TRY(conv_same(c, t1, B, T, w.c2, x, ACT_NONE, ACT_NONE, x));
+    c.arena.release(mark);
+    return QA_OK;
+}
+
+// ---------------------------------------------------------------- encode / decode graphs
+
+int encode_graph(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const float* feat, int64_t fsb, int64_t fsc,
+                 int64_t fst, int n_feat, long long* ac_out, long long* sc_out) {
+    const qa_hcodec_spec& sp = h->spec;
+    // ---- SEANet encoder
+    int C = sp.n_filters, L = T;
+    float* x = c.arena.alloc<float>((size_t)B * L * C);
+    if (!c.dry) QA_TRY(launch_conv_in(wav, h->conv0_w, h->conv0_b, x, B, L, C, 7, c.stream));
+    c.tap("enc.conv0", x, (int64_t)B * L * C);
+    for (int i = 0; i < sp.n_ratios; ++i) {
+        const int r = sp.ratios[i];
+        const ResBlockW& rb = h->res[i];
+        const size_t mark = c.arena.mark();
+        float* sc = c.arena.alloc<float>((size_t)B * L * C);
+        float* hh = c.arena.alloc<float>((size_t)B * L * rb.k3.N);
+        // shortcut_1x1(x)
+        QA_TRY(conv_op(c, x, C, B, L, rb.sc, sc, C, L, 1, 0, 0, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, nullptr, 0, nullptr,
+                       ACT_NONE));
+        // ELU(k3(ELU(x)))  (reflect pad 1,1)
+        QA_TRY(conv_op(c, x, C, B, L, rb.k3, hh, rb.k3.N, L, 1, 1, 1, PAD_REFLECT, ACT_ELU, ACT_ELU, nullptr, nullptr, 0,
+                       nullptr, ACT_NONE));
+        // ELU(shortcut + 1x1(.))  -> the activation in front of the down-sampling conv is fused here
+        QA_TRY(conv_op(c, hh, rb.pw.C_in, B, L, rb.pw, sc, C, L, 1, 0, 0, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, sc, C,
+                       nullptr, ACT_ELU));
+        const SGeom g = sconv_geom(L, 2 * r, r);
+        // the strided conv writes below the mark: allocate its output after releasing the block temporaries is not
+        // possible (sc is its input), so the output is carved above them and compacted by pointer swap.
+        float* y = c.arena.alloc<float>((size_t)B * g.T_out * 2 * C);
+        QA_TRY(conv_op(c, sc, C, B, L, h->down[i], y, 2 * C, g.T_out, r, g.left, g.right, PAD_REFLECT, ACT_NONE, ACT_NONE,
+                       nullptr, nullptr, 0, nullptr, ACT_NONE));
+        (void)mark;
+        x = y;
+        L = g.T_out;
+        C *= 2;
+        c.tap("enc.stage" + std::to_string(i), x, (int64_t)B * L * C);
+    }
+    QA_REQUIRE(C == sp.dimension, "encoder: channel ladder ends at %d, spec.dimension is %d", C, sp.dimension);
+    const int N50 = L;
+    QA_TRY(transformer_op(c, h->enc_tr, x, B, N50, "encoder.model." + std::to_string(3 * sp.n_ratios + 2)));
+    c.tap("enc.transformer", x, (int64_t)B * N50 * C);
+    const SGeom g = sconv_geom(N50, 4, 2);
+    const int N25 = g.T_out;
+    float* emb = c.arena.alloc<float>((size_t)B * N25 * sp.code_dim);
+    QA_TRY(conv_op(c, x, C, B, N50, h->enc_out, emb, sp.code_dim, N25, 2, g.left, g.right, PAD_REFLECT, ACT_ELU, ACT_NONE,
+                   nullptr, nullptr, 0, nullptr, ACT_NONE));
+    c.tap("enc.emb", emb, (int64_t)B * N25 * sp.code_dim);
+
+    // ---- semantic encoder
+    QA_REQUIRE(n_feat > 0, "encode: feat has no frames");
+    const float* f = feat;
+    const int SC = sp.sem_ch;
+    if (!(fsc == 1 && fst == sp.sem_in && fsb == (int64_t)n_feat * sp.sem_in)) {
+        float* fcl = c.arena.alloc<float>((size_t)B * n_feat * sp.sem_in);
+        if (!c.dry) QA_TRY(launch_to_channel_last(feat, fsb, fsc, fst, fcl, B, sp.sem_in, n_feat, c.stream));
+        f = fcl;
+    }
+    int Ls = n_feat;
+    float* s = c.arena.alloc<float>((size_t)B * Ls * SC);
+    float* tmp = c.arena.alloc<float>((size_t)B * Ls * SC);
+    QA_TRY(conv_same(c, f, B, Ls, h->sem_in, s));
+    for (size_t bi = 0; bi < h->sem_blocks.size(); ++bi) {
+        const auto& blk = h->sem_blocks[bi];
+        for (int u = 0; u < 2; ++u) {
+            QA_TRY(conv_same(c, s, B, Ls, blk.u1[u], tmp, ACT_ELU, ACT_ELU));       // ELU(conv1(ELU(s)))
+            QA_TRY(conv_same(c, tmp, B, Ls, blk.u2[u], s, ACT_NONE, ACT_NONE, s));  // s + conv2(.)
+        }
+        const int k = blk.conv.ksize, pad = (k - 1) / 2;
+        const int To = (Ls + 2 * pad - k) / blk.stride + 1;
+        float* y = c.arena.alloc<float>((size_t)B * To * SC);
+        QA_TRY(conv_op(c, s, SC, B, Ls, blk.conv, y, SC, To, blk.stride, pad, pad, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr,
+                       nullptr, 0, nullptr, ACT_NONE));
+        s = y;
+        Ls = To;
+    }
+    QA_REQUIRE(Ls == N25, "encode: semantic stream has %d frames, acoustic stream %d (feat must have T/%d frames)", Ls,
+               N25, T / std::max(1, N50));
+    float* sem = c.arena.alloc<float>((size_t)B * Ls * sp.code_dim);
+    QA_TRY(conv_same(c, s, B, Ls, h->sem_out, sem));
+    c.tap("enc.sem", sem, (int64_t)B * Ls * sp.code_dim);
+
+    // ---- RVQ (both streams)
+    const int Q = sp.num_quantizers;
+    long long* ia = c.arena.alloc<long long>((size_t)B * N25 * Q);
+    long long* is = c.arena.alloc<long long>((size_t)B * N25 * Q);
+    if (!c.dry) {
+        QA_TRY(launch_rvq_search(emb, (long long)B * N25, h->cb_a, h->e2_a, Q, sp.codebook_size, sp.code_dim, ia, nullptr, 0,
+                                 c.stream));
+        QA_TRY(launch_rvq_search(sem, (long long)B * N25, h->cb_s, h->e2_s, Q, sp.codebook_size, sp.code_dim, is, nullptr, 0,
+                                 c.stream));
+        QA_TRY(launch_codes_to_bqn(ia, ac_out, B, N25, Q, c.stream));
+        QA_TRY(launch_codes_to_bqn(is, sc_out, B, N25, Q, c.stream));
+    }
+    return QA_OK;
+}
+
+int decode_graph(qa_hcodec* h, Ctx& c, const long long* ac, const long long* scodes, int B, int N, float* wav_out) {
+    const qa_hcodec_spec& sp = h->spec;
+    const int Q = sp.num_quantizers, D = sp.code_dim, d = sp.dec_dim;
+    const int64_t rows25 = (int64_t)B * N;
+    long long* ia = c.arena.alloc<long long>(rows25 * Q);
+    long long* is = c.arena.alloc<long long>(rows25 * Q);
+    float* cat = c.arena.alloc<float>(rows25 * 2 * D);
+    if (!c.dry) {
+        QA_TRY(launch_codes_from_bqn(ac, ia, B, N, Q, c.stream));
+        QA_TRY(launch_codes_from_bqn(scodes, is, B, N, Q, c.stream));
+        QA_TRY(launch_rvq_lookup(ia, rows25, h->cb_a, Q, sp.codebook_size, D, cat, 2 * D, c.stream));
+        QA_TRY(launch_rvq_lookup(is, rows25, h->cb_s, Q, sp.codebook_size, D, cat + D, 2 * D, c.stream));
+    }
+    // sub-pixel upsampler: 1x1 conv to 2*d channels; in channel-last layout the pixel shuffle (vq/conv.py:86-88) is a
+    // pure reinterpretation [B, N, 2, d] -> [B, 2N, d]
+    float* up = c.arena.alloc<float>(rows25 * 2 * d);
+    QA_TRY(linear_op(c, cat, rows25, h->up, up));
+    const int N50 = 2 * N;
+    const int64_t rows = (int64_t)B * N50;
+    float* x = c.arena.alloc<float>(rows * d);
+    if (!c.dry) QA_TRY(launch_dwconv(up, h->up_dw, h->up_dwb, nullptr, nullptr, x, B, N50, d, 5, 0.f, c.stream));
+    c.tap("dec.embed", x, rows * d);
+    QA_TRY(dec_resblock_op(c, h->dres[0], x, B, N50, d, sp.gn_groups));
+    QA_TRY(dec_resblock_op(c, h->dres[1], x, B, N50, d, sp.gn_groups));
+    c.tap("dec.prior_res1", x, rows * d);
+    QA_TRY(transformer_op(c, h->dec_tr, x, B, N50, "decoder.prior_net.3"));
+    c.tap("dec.transformer", x, rows * d);
+    QA_TRY(dec_resblock_op(c, h->dres[2], x, B, N50, d, sp.gn_groups));
+    QA_TRY(dec_resblock_op(c, h->dres[3], x, B, N50, d, sp.gn_groups));
+    float* t1 = c.arena.alloc<float>(rows * d);
+    float* u = c.arena.alloc<float>(rows * sp.dec_inter);
+    QA_TRY(groupnorm_op(c, x, h->gn_w, h->gn_b, t1, B, N50, d, sp.gn_groups, 0));
+    if (!c.dry) QA_TRY(launch_layernorm(t1, h->norm_w, h->norm_b, x, rows, d, 1e-6f, c.stream));
+    c.tap("dec.prior", x, rows * d);
+    for (const ConvNeXtW& w : h->cnx) {
+        if (c.dry) break;
+        QA_TRY(launch_dwconv(x, w.dw, w.dwb, w.lnw, w.lnb, t1, B, N50, d, 7, 1e-6f, c.stream));
+        QA_TRY(linear_op(c, t1, rows, w.pw1, u, ACT_GELU));
+        QA_TRY(linear_op(c, u, rows, w.pw2, x, ACT_NONE, x, nullptr, w.gamma));
+    }
+    if (!c.dry) QA_TRY(launch_layernorm(x, h->fnorm_w, h->fnorm_b, t1, rows, d, 1e-6f, c.stream));
+    c.tap("dec.backbone", t1, rows * d);
+    // ISTFT head
+    const int nb = sp.n_fft / 2 + 1;
+    float* y = c.arena.alloc<float>(rows * 2 * nb);
+    float* S = c.arena.alloc<float>(rows * h->spec_ld);
+    float* frames = c.arena.alloc<float>(rows * sp.n_fft);
+    QA_TRY(linear_op(c, t1, rows, h->head, y));
+    if (!c.dry) QA_TRY(launch_istft_spec(y, S, rows, nb, 2 * nb, h->spec_ld, c.stream));
+    c.tap("dec.spec", S, rows * h->spec_ld);
+    QA_TRY(linear_op(c, S, rows, h->basis, frames));
+    if (!c.dry) QA_TRY(launch_istft_ola(frames, h->window, wav_out, B, N50, sp.n_fft, sp.hop, c.stream));
+    return QA_OK;
+}
+
+int ensure_workspace(qa_hcodec* h, size_t bytes) {
+    if (bytes <= h->ws_cap) return QA_OK;
+    if (h->ws) QA_HIP(hipFree(h->ws));  // synchronises with outstanding work
+    h->ws = nullptr;
+    h->ws_cap = 0;
+    const size_t cap = bytes + bytes / 8;
+    QA_HIP(hipMalloc(reinterpret_cast<void**>(&h->ws), cap));
+    h->ws_cap = cap;
+    return QA_OK;
+}
+
+int build(qa_hcodec* h, const HostTable& tab) {
+    const qa_hcodec_spec& sp = h->spec;
+    QA_REQUIRE(sp.n_ratios >= 1 && sp.n_ratios <= 8 && sp.n_sem_strides >= 1 && sp.n_sem_strides <= 4, "spec: bad counts");
+    QA_REQUIRE(sp.n_filters % 32 == 0, "spec: n_filters=%d must be a multiple of 32", sp.n_filters);
+    QA_REQUIRE(sp.dimension % 128 == 0 && sp.dec_dim % 128 == 0, "spec: transformer widths must be multiples of 128");
+    QA_REQUIRE(sp.sem_in % 32 == 0 && sp.sem_ch % 32 == 0 && sp.code_dim % 32 == 0 && sp.dec_inter % 32 == 0,
+               "spec: channel counts must be multiples of 32");
+    QA_REQUIRE(sp.n_fft % 2 == 0 && sp.hop > 0 && sp.n_fft > sp.hop && (sp.n_fft - sp.hop) % 2 == 0, "spec: bad STFT geometry");
+    QA_REQUIRE(sp.dec_dim % sp.gn_groups == 0, "spec: dec_dim %% gn_groups != 0");
+    Builder b{Folder{tab, h->store}};
+    // --- SEANet encoder (seanet.py:121-187)
+    const std::string em = "encoder.model.";
+    {
+        std::vector<float> w0((size_t)7 * sp.n_filters), b0(sp.n_filters);
+        const float* v = b.f.need(em + "0.conv.conv.weight_v", (int64_t)sp.n_filters * 7);
+        const float* g = b.f.need(em + "0.conv.conv.weight_g", sp.n_filters);
+        const float* bi = b.f.need(em + "0.conv.conv.bias", sp.n_filters);
+        if (v && g && bi) {
+            for (int n = 0; n < sp.n_filters; ++n) {
+                double ss = 0;
+                for (int j = 0; j < 7; ++j) ss += (double)v[n * 7 + j] * v[n * 7 + j];
+                const float sc = g[n] / (float)std::sqrt(ss);
+                for (int j = 0; j < 7; ++j) w0[(size_t)j * sp.n_filters + n] = v[n * 7 + j] * sc;
+                b0[n] = bi[n];
+            }
+        }
+        b.raw(&h->conv0_w, w0);
+        b.raw(&h->conv0_b, b0);
+    }
+    h->res.resize(sp.n_ratios);
+    h->down.resize(sp.n_ratios);
+    int C = sp.n_filters;
+    for (int i = 0; i < sp.n_ratios; ++i) {
+        const std::string rp = em + std::to_string(1 + 3 * i);
+        const int hid = C / 2, hp = pad32(hid);
+        b.conv(&h->res[i].k3, rp + ".block.1.conv.conv", hid, C, 3, true, true, hp, C);
+        b.conv(&h->res[i].pw, rp + ".block.3.conv.conv", C, hid, 1, true, true, C, hp);
+        b.conv(&h->res[i].sc, rp + ".shortcut.conv.conv", C, C, 1, true, true);
+        b.conv(&h->down[i], em + std::to_string(3 + 3 * i) + ".conv.conv", 2 * C, C, 2 * sp.ratios[i], true, true);
+        C *= 2;
+    }
+    QA_REQUIRE(C == sp.dimension, "spec: n_filters * 2^n_ratios = %d != dimension %d", C, sp.dimension);
+    build_transformer(b, &h->enc_tr, em + std::to_string(3 * sp.n_ratios + 2), sp.dimension, sp.enc_layers, sp.enc_heads);
+    b.conv(&h->enc_out, em + std::to_string(3 * sp.n_ratios + 5) + ".conv.conv", sp.dimension, sp.dimension, 4, true, true);
+    QA_REQUIRE(sp.code_dim == sp.dimension, "spec: code_dim must equal dimension");
+    // --- semantic encoder (semantic_module.py:157-201)
+    const std::string se = "semantic_encoder.";
+    b.conv(&h->sem_in, se + "conv.conv", sp.sem_ch, sp.sem_in, 3, false, false);
+    h->sem_blocks.resize(sp.n_sem_strides);
+    for (int i = 0; i < sp.n_sem_strides; ++i) {
+        auto& blk = h->sem_blocks[i];
+        const std::string bp = se + "conv_blocks." + std::to_string(i);
+        for (int u = 0; u < 2; ++u) {
+            b.conv(&blk.u1[u], bp + ".res_units." + std::to_string(u) + ".conv1.conv", sp.sem_ch, sp.sem_ch, 3, false, false);
+            b.conv(&blk.u2[u], bp + ".res_units." + std::to_string(u) + ".conv2", sp.sem_ch, sp.sem_ch, 1, false, false);
+        }
+        blk.stride = sp.sem_strides[i];
+        b.conv(&blk.conv, bp + ".conv.conv", sp.sem_ch, sp.sem_ch, blk.stride == 1 ? 3 : 2 * blk.stride, false, true);
+    }
+    b.conv(&h->sem_out, se + "conv2.conv", sp.code_dim, sp.sem_ch, 3, false, false);
+    // --- codebooks (vector_quantize_pytorch layout: layers.{q}._codebook.embed [1, K, D])
+    {
+        const int64_t kd = (int64_t)sp.codebook_size * sp.code_dim;
+        std::vector<float> cba((size_t)sp.num_quantizers * kd), cbs((size_t)sp.num_quantizers * kd);
+        for (int q = 0; q < sp.num_quantizers; ++q) {
+            const float* a = b.f.need("quantizer.layers." + std::to_string(q) + "._codebook.embed", kd);
+            const float* s = b.f.need("semantic_quantizer.layers." + std::to_string(q) + "._codebook.embed", kd);
+            if (a) std::memcpy(&cba[(size_t)q * kd], a, sizeof(float) * kd);
+            if (s) std::memcpy(&cbs[(size_t)q * kd], s, sizeof(float) * kd);
+        }
+        b.raw(&h->cb_a, cba);
+        b.raw(&h->cb_s, cbs);
+    }
+    // --- decoder (codec_decoder.py:14-67)
+    const int d = sp.dec_dim;
+    b.conv(&h->up, "decoder.embed.up", 2 * d, 2 * sp.code_dim, 1, false, true);
+    auto dw_fold = [&](const float** dst, const std::string& name, int k) {
+        std::vector<float> w((size_t)k * d, 0.f);
+        const float* p = b.f.need(name, (int64_t)d * k);
+        if (p)
+            for (int c = 0; c < d; ++c)
+                for (int j = 0; j < k; ++j) w[(size_t)j * d + c] = p[c * k + j];
+        b.raw(dst, w);
+    };
+    dw_fold(&h->up_dw, "decoder.embed.dw.weight", 5);
+    b.vec(&h->up_dwb, "decoder.embed.dw.bias", d);
+    const int ridx[4] = {0, 1, 5, 6};
+    for (int i = 0; i < 4; ++i) {
+        const std::string rp = "decoder.prior_net." + std::to_string(ridx[i]);
+        b.vec(&h->dres[i].n1w, rp + ".norm1.weight", d);
+        b.vec(&h->dres[i].n1b, rp + ".norm1.bias", d);
+        b.vec(&h->dres[i].n2w, rp + ".norm2.weight", d);
+        b.vec(&h->dres[i].n2b, rp + ".norm2.bias", d);
+        b.conv(&h->dres[i].c1, rp + ".conv1.conv", d, d, 3, false, true);
+        b.conv(&h->dres[i].c2, rp + ".conv2.conv", d, d, 3, false, true);
+    }
+    build_transformer(b, &h->dec_tr, "decoder.prior_net.3", d, sp.dec_layers, sp.dec_heads);
+    b.vec(&h->gn_w, "decoder.prior_net.7.weight", d);
+    b.vec(&h->gn_b, "decoder.prior_net.7.bias", d);
+    b.vec(&h->norm_w, "decoder.norm.weight", d);
+    b.vec(&h->norm_b, "decoder.norm.bias", d);
+    b.vec(&h->fnorm_w, "decoder.final_layer_norm.weight", d);
+    b.vec(&h->fnorm_b, "decoder.final_layer_norm.bias", d);
+    h->cnx.resize(sp.convnext_layers);
+    for (int i = 0; i < sp.convnext_layers; ++i) {
+        ConvNeXtW& w = h->cnx[i];
+        const std::string cp = "decoder.post_net." + std::to_string(i);
+        dw_fold(&w.dw, cp + ".dwconv.conv.weight", 7);
+        b.vec(&w.dwb, cp + ".dwconv.conv.bias", d);
+        b.vec(&w.lnw, cp + ".norm.weight", d);
+        b.vec(&w.lnb, cp + ".norm.bias", d);
+        b.vec(&w.gamma, cp + ".gamma", d);
+        w.pw1.N = sp.dec_inter; w.pw1.C_in = d; w.pw1.ksize = 1;
+        b.vec(&w.pw1.w, cp + ".pwconv1.linear.weight", (int64_t)sp.dec_inter * d);
+        b.vec(&w.pw1.b, cp + ".pwconv1.linear.bias", sp.dec_inter);
+        w.pw2.N = d; w.pw2.C_in = sp.dec_inter; w.pw2.ksize = 1;
+        b.vec(&w.pw2.w, cp + ".pwconv2.linear.weight", (int64_t)sp.dec_inter * d);
+        b.vec(&w.pw2.b, cp + ".pwconv2.linear.bias", d);
+    }
+    const int nb = sp.n_fft / 2 + 1;
+    h->head.N = 2 * nb; h->head.C_in = d; h->head.ksize = 1;
+    b.vec(&h->head.w, "decoder.head.out.weight", (int64_t)2 * nb * d);
+    b.vec(&h->head.b, "decoder.head.out.bias", 2 * nb);
+    // inverse real DFT (norm="backward") with the synthesis window folded in (spectral_ops.py:55-56):
+    //   frame[n] = w[n]/N * sum_k c_k (Re_k cos(2 pi k n / N) - Im_k sin(2 pi k n / N)),  c_0 = c_{N/2} = 1, else 2
+    {
+        const int Nf = sp.n_fft;
+        h->spec_ld = pad32(2 * nb);
+        std::vector<float> win(Nf);
+        if (tab.has("decoder.head.istft.window")) {
+            const float* wp = b.f.need("decoder.head.istft.window", Nf);
+            if (wp) std::memcpy(win.data(), wp, sizeof(float) * Nf);
+        } else {
+            for (int n = 0; n < Nf; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / Nf));
+        }
+        std::vector<float> basis((size_t)Nf * h->spec_ld, 0.f);
+        for (int n = 0; n < Nf; ++n)
+            for (int k = 0; k < nb; ++k) {
+                const double ck = (k == 0 || k == Nf / 2) ? 1.0 : 2.0;
+                const double ang = 2.0 * M_PI * (double)(((int64_t)k * n) % Nf) / Nf;
+                basis[(size_t)n * h->spec_ld + k] = (float)(win[n] * ck * std::cos(ang) / Nf);
+                basis[(size_t)n * h->spec_ld + nb + k] = (k == 0 || k == Nf / 2) ? 0.f : (float)(-win[n] * ck * std::sin(ang) / Nf);
+            }
+        h->basis.N = Nf; h->basis.C_in = h->spec_ld; h->basis.ksize = 1;
+        b.raw(&h->basis.w, basis);
+        b.raw(&h->window, win);
+    }
+    if (!b.f.ok) return b.f.status;
+    QA_TRY(h->store.upload());
+    b.resolve();
+    // |e|^2 tables
+    const int QK = sp.num_quantizers * sp.codebook_size;
+    QA_HIP(hipMalloc(reinterpret_cast<void**>(&h->e2_dev), sizeof(float) * 2 * QK));
+    QA_TRY(launch_rvq_norms(h->cb_a, h->e2_dev, QK, sp.code_dim, nullptr));
+    QA_TRY(launch_rvq_norms(h->cb_s, h->e2_dev + QK, QK, sp.code_dim, nullptr));
+    QA_HIP(hipDeviceSynchronize());
+    h->e2_a = h->e2_dev;
+    h->e2_s = h->e2_dev + QK;
+    return QA_OK;
+}
+
+}  // namespace
+}  // namespace qa
+
+extern "C" {
+
+int qa_hcodec_create(qa_hcodec** out, const qa_hcodec_spec* spec, const qa_tensor* tensors, int64_t n_tensors, int device) {
+    if (!out || !spec || !tensors) {
+        set_error("qa_hcodec_create: null argument");
+        return QA_ERR_INVALID;
+    }
+    *out = nullptr;
+    QA_HIP(hipSetDevice(device));
+    std::unique_ptr<qa_hcodec> h(new qa_hcodec());
+    h->spec = *spec;
+    h->device = device;
+    HostTable tab(tensors, n_tensors);
+    const int st = build(h.get(), tab);
+    if (st != QA_OK) {
+        h->store.release();
+        if (h->e2_dev) (void)hipFree(h->e2_dev);
+        return st;
+    }
+    *out = h.release();
+    return QA_OK;
+}
+
+void qa_hcodec_destroy(qa_hcodec* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    h->store.release();
+    if (h->e2_dev) (void)hipFree(h->e2_dev);
+    if (h->ws) (void)hipFree(h->ws);
+    delete h;
+}
+
+int qa_hcodec_encode(qa_hcodec* h, const float* wav, int64_t B, int64_t T, const float* feat, int64_t fsb, int64_t fsc,
+                     int64_t fst, int64_t n_feat, int64_t* ac, int64_t* sc, void* stream) {
+    if (!h || !wav || !feat || !ac || !sc) {
+        set_error("qa_hcodec_encode: null argument");
+        return QA_ERR_INVALID;
+    }
+    int hop = 2;
+    for (int i = 0; i < h->spec.n_ratios; ++i) hop *= h->spec.ratios[i];
+    QA_REQUIRE(B > 0 && T > 0 && T % hop == 0, "qa_hcodec_encode: wav is [%lld, %lld]; T must be a positive multiple of %d "
+               "(HCodecTokenizer.pad_wav)", (long long)B, (long long)T, hop);
+    QA_REQUIRE(B * T < (1LL << 31), "qa_hcodec_encode: batch of %lld x %lld samples is too large", (long long)B, (long long)T);
+    QA_HIP(hipSetDevice(h->device));
+    Ctx& c = h->ctx;
+    c.stream = static_cast<hipStream_t>(stream);
+    c.dry = true;
+    c.arena.begin(nullptr, 0);
+    QA_TRY(encode_graph(h, c, wav, (int)B, (int)T, feat, fsb, fsc, fst, (int)n_feat, (long long*)ac, (long long*)sc));
+    QA_TRY(ensure_workspace(h, c.arena.peak()));
+    c.dry = false;
+    c.taps.clear();
+    c.arena.begin(h->ws, h->ws_cap);
+    return encode_graph(h, c, wav, (int)B, (int)T, feat, fsb, fsc, fst, (int)n_feat, (long long*)ac, (long long*)sc);
+}
+
+int qa_hcodec_decode(qa_hcodec* h, const int64_t* ac, const int64_t* sc, int64_t B, int64_t N, float* wav_out, void* stream) {
+    if (!h || !ac || !sc || !wav_out) {
+        set_error("qa_hcodec_decode: null argument");
+        return QA_ERR_INVALID;
+    }
+    QA_REQUIRE(B > 0 && N > 0, "qa_hcodec_decode: codes are [%lld, Q, %lld]", (long long)B, (long long)N);
+    QA_REQUIRE(B * N * 2 * (int64_t)h->spec.hop < (1LL << 31), "qa_hcodec_decode: output too large");
+    QA_HIP(hipSetDevice(h->device));
+    Ctx& c = h->ctx;
+    c.stream = static_cast<hipStream_t>(stream);
+    c.dry = true;
+    c.arena.begin(nullptr, 0);
+    QA_TRY(decode_graph(h, c, (const long long*)ac, (const long long*)sc, (int)B, (int)N, wav_out));
+    QA_TRY(ensure_workspace(h, c.arena.peak()));
+    c.dry = false;
+    c.taps.clear();
+    c.arena.begin(h->ws, h->ws_cap);
+    return decode_graph(h, c, (const long long*)ac, (const long long*)sc, (int)B, (int)N, wav_out);
+}
+
+int64_t qa_hcodec_tap(qa_hcodec* h, const char* name, float* dst, int64_t cap, void* stream) {
+    if (!h || !name) {
+        set_error("qa_hcodec_tap: null argument");
+        return QA_ERR_INVALID;
+    }
+    auto it = h->ctx.taps.find(name);
+    if (it == h->ctx.taps.end()) {
+        set_error("qa_hcodec_tap: no intermediate named '%s' in the last call", name);
+        return QA_ERR_MISSING;
+    }
+    if (dst) {
+        if (cap < it->second.numel) {
+            set_error("qa_hcodec_tap: '%s' has %lld elements, capacity %lld", name, (long long)it->second.numel, (long long)cap);
+            return QA_ERR_INVALID;
+        }
+        QA_HIP(hipMemcpyAsync(dst, it->second.ptr, sizeof(float) * it->second.numel, hipMemcpyDeviceToDevice,
+                              static_cast<hipStream_t>(stream)));
+    }
+    return it->second.numel;
+}
+
+}  // extern "C"

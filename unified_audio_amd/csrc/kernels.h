@@ -1,0 +1,48 @@
+// kernels.h - host-side launchers of every HIP kernel in libquarkaudio_hip.
+#pragma once
+#include <algorithm>
+
+#include "common.h"
+
+namespace qa {
+
+// ew.hip
+int launch_conv_in(const float* x, const float* w_kc, const float* bias, float* y, int B, int T, int Cout, int ksize,
+                   hipStream_t s);
+int launch_rmsnorm(const float* x, const float* w, float* y, long long rows, int C, float eps, hipStream_t s);
+int launch_layernorm(const float* x, const float* w, const float* b, float* y, long long rows, int C, float eps,
+                     hipStream_t s);
+int launch_dwconv(const float* x, const float* w_kc, const float* bias, const float* lnw, const float* lnb, float* y,
+                  int B, int T, int C, int ksize, float eps, hipStream_t s);
+size_t groupnorm_scratch_bytes(int B, int T, int G);
+int launch_groupnorm(const float* x, const float* w, const float* bias, float* y, double* scratch, int B, int T, int C,
+                     int G, float eps, int swish, hipStream_t s);
+int launch_rope(float* qkv, const float* cos_sin, int B, int N, int H, int hd, long long ld, int pos0, hipStream_t s);
+int launch_to_channel_last(const float* x, long long sb, long long sc, long long st, float* y, int B, int C, int T,
+                           hipStream_t s);
+int launch_codes_to_bqn(const long long* src, long long* dst, int B, int N, int Q, hipStream_t s);
+int launch_codes_from_bqn(const long long* src, long long* dst, int B, int N, int Q, hipStream_t s);
+int launch_istft_spec(const float* y, float* S, long long rows, int nb, int ldy, int ldS, hipStream_t s);
+int launch_istft_ola(const float* frames, const float* win, float* out, int B, int T, int n_fft, int hop, hipStream_t s);
+
+// attention.hip : softmax(Q K^T * scale) V over a fused [B*N, 3*H*hd] QKV buffer (RoPE already applied)
+//   causal = 0: full attention over the N keys of the same batch item (codec transformers)
+//   causal = 1: key j visible to query i iff j <= i + (n_keys - n_q) (LM prefill / decode over a KV cache)
+int launch_attention(const float* q, long long ldq, const float* k, const float* v, long long ldkv, float* out,
+                     long long ldo, int B, int n_q, int n_keys, long long kv_batch_stride, int H, int hd, float scale,
+                     int causal, hipStream_t s);
+
+// lstm.hip : one nn.LSTM layer (batch_first, zero initial state) given the precomputed input projection
+//   xw [B, T, 4d] = x W_ih^T + b_ih + b_hh with the 4d axis permuted to (unit, gate) order,
+//   w_hh [4d, d] rows permuted the same way.  h_out [B, T, d].  c_state [B, d] scratch.
+int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d,
+                hipStream_t s);
+
+// rvq.hip
+int launch_rvq_search(const float* x, long long n_vec, const float* codebooks, const float* e2, int Q, int K, int D,
+                      long long* indices, float* quantized, long long ldq, hipStream_t s);
+int launch_rvq_norms(const float* codebooks, float* e2, int QK, int D, hipStream_t s);
+int launch_rvq_lookup(const long long* indices, long long n_vec, const float* codebooks, int Q, int K, int D, float* out,
+                      long long ldo, hipStream_t s);
+
+}  // namespace qa

@@ -1,0 +1,208 @@
+// rvq.hip - multi-stage residual vector quantisation: nearest-codebook search and index look-up.
+//
+// Reference: the third-party vector_quantize_pytorch.ResidualVQ called at QuarkAudio-HCodec/HCodec-1.0/vq/codec.py:171-172
+// and :183-184; arithmetic as stated in-tree by vq/core_vq.py:223-231 (dist = |x|^2 - 2 x.e + |e|^2, arg-max of the negative,
+// first maximum wins), :394-404 (r <- r - e_idx per stage) and :406-412 (decode = sum of look-ups).
+//
+// All Q stages run in ONE launch: a workgroup keeps the residuals of 32 vectors in LDS (fp32), each of its 4 waves sweeps
+// a quarter of the codebook 32 codes at a time with v_mfma_f32_32x32x2_f32 (A = residual tile from LDS, B = code rows straight
+// from L2: the 2 MB stage codebook is shared by every workgroup), keeps a per-lane running arg-min, then the winners are
+// reduced with wave shuffles and one LDS exchange, ties resolving to the lowest index, and the residual update is fused.
+#include "kernels.h"
+
+namespace qa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void argmin_merge(float& d, int& i, float d2, int i2) {
+    if (d2 < d || (d2 == d && i2 < i)) {
+        d = d2;
+        i = i2;
+    }
+}
+
+__global__ __launch_bounds__(256) void rvq_search_kernel(const float* __restrict__ x, long long n_vec,
+                                                         const float* __restrict__ cb, const float* __restrict__ e2,
+                                                         int Q, int K, int D, long long* __restrict__ indices) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LD = D + 4;
+    float* sR = smem;                                   // [32][LD] residuals
+    float* sX2 = smem + 32 * LD;                        // [32]
+    float* sCd = sX2 + 32;                              // [4][32] candidate distance per wave
+    int* sCi = reinterpret_cast<int*>(sCd + 4 * 32);    // [4][32] candidate index per wave
+    int* sBest = sCi + 4 * 32;                          // [32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int jl = lane & 31, hh = lane >> 5;
+    const long long v0 = (long long)blockIdx.x * 32;
+    const int d4 = D >> 2;
+
+    for (int i = tid; i < 32 * d4; i += 256) {
+        const int r = i / d4, c = (i % d4) * 4;
+        const long long v = v0 + r;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v < n_vec) t = *reinterpret_cast<const float4*>(x + v * D + c);
+        *reinterpret_cast<float4*>(sR + r * LD + c) = t;
+    }
+    __syncthreads();
+
+    for (int q = 0; q < Q; ++q) {
+        const float* cbq = cb + (long long)q * K * D;
+        const float* e2q = e2 + (long long)q * K;
+        // |r|^2 per vector: wave w handles vectors w*8 .. w*8+7
+        for (int r = wave * 8; r < wave * 8 + 8; ++r) {
+            float s = 0.f;
+            for (int c = lane * 4; c < D; c += 256) {
+                const float4 t = *reinterpret_cast<const float4*>(sR + r * LD + c);
+                s += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+            }
+            s = wave_sum(s);
+            if (lane == 0) sX2[r] = s;
+        }
+        __syncthreads();
+
+        float best_d[16];
+        int best_i[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            best_d[r] = INFINITY;
+            best_i[r] = 0x7fffffff;
+        }
+        const float* ap = sR + jl * LD + 4 * hh;
+        for (int tile = wave; tile * 32 < K; tile += 4) {
+            const int code = tile * 32 + jl;
+            const int code_c = code < K ? code : K - 1;
+            const float* bp = cbq + (long long)code_c * D + 4 * hh;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+            for (int g = 0; g < D; g += 8) {
+                const float4 a = *reinterpret_cast<const float4*>(ap + g);
+                const float4 b = *reinterpret_cast<const float4*>(bp + g);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            }
+            if (code < K) {
+                const float ee = e2q[code];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int vi = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const float dist = (sX2[vi] - 2.f * acc[r]) + ee;  // same association as core_vq.py:225-229
+                    if (dist < best_d[r]) {  // codes ascend per lane: strict '<' keeps the first minimum
+                        best_d[r] = dist;
+                        best_i[r] = code;
+                    }
+                }
+            }
+        }
+        // reduce over the 32 lanes (codes) that share a half
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                const float d2 = __shfl_xor(best_d[r], o, 64);
+                const int i2 = __shfl_xor(best_i[r], o, 64);
+                argmin_merge(best_d[r], best_i[r], d2, i2);
+            }
+            if (jl == 0) {
+                const int vi = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                sCd[wave * 32 + vi] = best_d[r];
+                sCi[wave * 32 + vi] = best_i[r];
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float d = sCd[tid];
+            int i = sCi[tid];
+            for (int w = 1; w < 4; ++w) argmin_merge(d, i, sCd[w * 32 + tid], sCi[w * 32 + tid]);
+            sBest[tid] = i;
+            if (v0 + tid < n_vec) indices[(v0 + tid) * Q + q] = i;
+        }
+        __syncthreads();
+        // residual update r <- r - e[idx]
+        for (int i = tid; i < 32 * d4; i += 256) {
+            const int r = i / d4, c = (i % d4) * 4;
+            const float4 e = *reinterpret_cast<const float4*>(cbq + (long long)sBest[r] * D + c);
+            float4 t = *reinterpret_cast<float4*>(sR + r * LD + c);
+            t.x -= e.x; t.y -= e.y; t.z -= e.z; t.w -= e.w;
+            *reinterpret_cast<float4*>(sR + r * LD + c) = t;
+        }
+        __syncthreads();
+    }
+}
+
+// |e|^2 of every code vector: one wave per code
+__global__ __launch_bounds__(256) void rvq_norms_kernel(const float* __restrict__ cb, float* __restrict__ e2, int QK,
+                                                        int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= QK) return;
+    float s = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 t = *reinterpret_cast<const float4*>(cb + (long long)row * D + c);
+        s += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+    }
+    s = wave_sum(s);
+    if (lane == 0) e2[row] = s;
+}
+
+// out[v, :] = ((E_0[i_0] + E_1[i_1]) + ...) in stage order, like the reference's running sum
+__global__ __launch_bounds__(256) void rvq_lookup_kernel(const long long* __restrict__ indices, long long n_vec,
+                                                         const float* __restrict__ cb, int Q, int K, int D,
+                                                         float* __restrict__ out, long long ldo) {
+    const int d4 = D >> 2;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_vec * d4) return;
+    const long long v = gid / d4;
+    const int c = (int)(gid % d4) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < Q; ++q) {
+        long long idx = indices[v * Q + q];
+        idx = idx < 0 ? 0 : (idx >= K ? K - 1 : idx);  // memory safety only; callers validate
+        const float4 e = *reinterpret_cast<const float4*>(cb + ((long long)q * K + idx) * D + c);
+        acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w;
+    }
+    *reinterpret_cast<float4*>(out + v * ldo + c) = acc;
+}
+
+int launch_rvq_norms(const float* codebooks, float* e2, int QK, int D, hipStream_t s) {
+    QA_REQUIRE(D % 4 == 0, "rvq: D=%d must be a multiple of 4", D);
+    hipLaunchKernelGGL(rvq_norms_kernel, dim3((unsigned)ceil_div(QK, 4)), dim3(256), 0, s, codebooks, e2, QK, D);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+int launch_rvq_search(const float* x, long long n_vec, const float* codebooks, const float* e2, int Q, int K, int D,
+                      long long* indices, float* quantized, long long ldq, hipStream_t s) {
+    QA_REQUIRE(D % 8 == 0 && D >= 8, "rvq_search: D=%d must be a multiple of 8", D);
+    QA_REQUIRE(Q >= 1 && K >= 1, "rvq_search: Q=%d K=%d", Q, K);
+    if (n_vec <= 0) return QA_OK;
+    const size_t lds = (size_t)(32 * (D + 4) + 32 + 4 * 32) * sizeof(float) + (4 * 32 + 32) * sizeof(int);
+    QA_REQUIRE(lds <= 160 * 1024, "rvq_search: D=%d needs %zu B of LDS", D, lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_search_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(rvq_search_kernel, dim3((unsigned)ceil_div(n_vec, 32)), dim3(256), lds, s, x, n_vec, codebooks,
+                       e2, Q, K, D, indices);
+    QA_LAUNCH_CHECK();
+    if (quantized) return launch_rvq_lookup(indices, n_vec, codebooks, Q, K, D, quantized, ldq, s);
+    return QA_OK;
+}
+
+int launch_rvq_lookup(const long long* indices, long long n_vec, const float* codebooks, int Q, int K, int D, float* out,
+                      long long ldo, hipStream_t s) {
+    QA_REQUIRE(D % 4 == 0, "rvq_lookup: D=%d must be a multiple of 4", D);
+    if (n_vec <= 0) return QA_OK;
+    hipLaunchKernelGGL(rvq_lookup_kernel, dim3((unsigned)ceil_div(n_vec * (D / 4), 256)), dim3(256), 0, s, indices, n_vec,
+                       codebooks, Q, K, D, out, ldo);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+}  // namespace qa

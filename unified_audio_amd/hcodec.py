@@ -1,0 +1,216 @@
+"""Python mirror of the reference's H-Codec interface, backed by libquarkaudio_hip.so.
+
+    Codec            <-> QuarkAudio-HCodec/HCodec-1.0/vq/codec.py:21-187        (encode / decode / load_state_dict)
+    HCodecTokenizer  <-> QuarkAudio-HCodec/HCodec-1.0/audio_tokenizer.py:18-66  (pad_wav / tokenize / detokenize)
+
+Tensors stay PyTorch-ROCm CUDA tensors (allocation + streams only); all arithmetic happens in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+@dataclass(frozen=True)
+class HCodecSpec:
+    """Architecture constants of H-Codec 1.0, hard-coded in the reference at vq/codec.py:30-136."""
+
+    n_filters: int = 32
+    ratios: Tuple[int, ...] = (2, 4, 5, 8)  # encoder order (codec.py:33 lists [8,5,4,2]; seanet.py:114 reverses)
+    dimension: int = 512
+    enc_heads: int = 8
+    enc_layers: int = 2
+    sem_in: int = 768
+    sem_ch: int = 768
+    sem_strides: Tuple[int, ...] = (2, 1)
+    code_dim: int = 512
+    codebook_size: int = 1024
+    num_quantizers: int = 4
+    dec_dim: int = 768
+    dec_inter: int = 2304
+    dec_heads: int = 8
+    dec_layers: int = 2
+    convnext_layers: int = 12
+    n_fft: int = 1280
+    hop: int = 320
+    gn_groups: int = 32
+
+    @property
+    def enc_hop(self) -> int:
+        return int(math.prod(self.ratios)) * 2
+
+    def to_c(self) -> "_lib.qa_hcodec_spec":
+        s = _lib.qa_hcodec_spec()
+        s.n_filters, s.n_ratios = self.n_filters, len(self.ratios)
+        for i, r in enumerate(self.ratios):
+            s.ratios[i] = r
+        s.dimension, s.enc_heads, s.enc_layers = self.dimension, self.enc_heads, self.enc_layers
+        s.sem_in, s.sem_ch, s.n_sem_strides = self.sem_in, self.sem_ch, len(self.sem_strides)
+        for i, r in enumerate(self.sem_strides):
+            s.sem_strides[i] = r
+        s.code_dim, s.codebook_size, s.num_quantizers = self.code_dim, self.codebook_size, self.num_quantizers
+        s.dec_dim, s.dec_inter, s.dec_heads, s.dec_layers = self.dec_dim, self.dec_inter, self.dec_heads, self.dec_layers
+        s.convnext_layers, s.n_fft, s.hop, s.gn_groups = self.convnext_layers, self.n_fft, self.hop, self.gn_groups
+        return s
+
+
+SPEC_10 = HCodecSpec()
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class Codec:
+    """Drop-in for `vq.Codec` on the inference path: `encode(x, feat)` / `decode(acoustic_codes, semantic_codes)`.
+
+    The constructor signature keeps the reference's three (ignored) kwargs dicts (codec.py:22-27); weights come
+    through `load_state_dict` in the reference's own key layout (weight_g / weight_v, `layers.{q}._codebook.embed`).
+    """
+
+    def __init__(self, encoder_kwargs=None, decoder_kwargs=None, quantizer_kwargs=None, *, spec: HCodecSpec = SPEC_10,
+                 device: str | torch.device = "cuda:0"):
+        self.spec = spec
+        self.device = torch.device(device)
+        self._handle = C.c_void_p()
+        self._lib = _lib.load_library()
+
+    # -- weights -------------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        _lib.require_device()
+        if self.device.type != "cuda":
+            raise _lib.QuarkAudioError(-1, f"Codec lives on a HIP device, got {self.device}")
+        self._free()
+        table, n, keep = _lib.tensor_table(state_dict)
+        spec_c = self.spec.to_c()
+        handle = C.c_void_p()
+        _lib.check(self._lib.qa_hcodec_create(C.byref(handle), C.byref(spec_c), table, n, self.device.index or 0))
+        del keep
+        self._handle = handle
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self.device:
+            raise _lib.QuarkAudioError(-4, "move the handle by constructing Codec(device=...) and reloading the weights")
+        return self
+
+    def _free(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.qa_hcodec_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
+
+    def _require_loaded(self):
+        if not self._handle.value:
+            raise _lib.QuarkAudioError(-3, "Codec has no weights: call load_state_dict first")
+
+    # -- hot path ------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, feat: torch.Tensor):
+        """codec.py:166-175.  x [B,1,T] fp32, feat [B, sem_in, N50] fp32 (any strides) -> two int64 [B, nq, N25]."""
+        self._require_loaded()
+        if x.dim() != 3 or x.shape[1] != 1:
+            raise _lib.QuarkAudioError(-1, f"encode expects x of shape [B,1,T], got {tuple(x.shape)}")
+        if feat.dim() != 3 or feat.shape[0] != x.shape[0] or feat.shape[1] != self.spec.sem_in:
+            raise _lib.QuarkAudioError(-1, f"encode expects feat of shape [B,{self.spec.sem_in},N], got {tuple(feat.shape)}")
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        feat = feat.to(device=self.device, dtype=torch.float32)
+        B, _, T = x.shape
+        n25 = T // self.spec.enc_hop
+        q = self.spec.num_quantizers
+        ac = torch.empty((B, q, n25), dtype=torch.int64, device=self.device)
+        sc = torch.empty((B, q, n25), dtype=torch.int64, device=self.device)
+        sb, sch, st = feat.stride()
+        _lib.check(self._lib.qa_hcodec_encode(self._handle, x.data_ptr(), B, T, feat.data_ptr(), sb, sch, st,
+                                              feat.shape[2], ac.data_ptr(), sc.data_ptr(), _stream_ptr(self.device)))
+        return ac, sc
+
+    @torch.no_grad()
+    def decode(self, acoustic_codes: torch.Tensor, semantic_codes: torch.Tensor):
+        """codec.py:178-187.  int64 [B, nq, N25] x2 -> wav [B, N25 * 2 * hop]."""
+        self._require_loaded()
+        q = self.spec.num_quantizers
+        if acoustic_codes.shape != semantic_codes.shape or acoustic_codes.dim() != 3 or acoustic_codes.shape[1] != q:
+            raise _lib.QuarkAudioError(-1, f"decode expects two [B,{q},N] code tensors, got "
+                                           f"{tuple(acoustic_codes.shape)} / {tuple(semantic_codes.shape)}")
+        ac = acoustic_codes.to(device=self.device, dtype=torch.int64).contiguous()
+        sc = semantic_codes.to(device=self.device, dtype=torch.int64).contiguous()
+        for name, c in (("acoustic_codes", ac), ("semantic_codes", sc)):
+            if c.numel() and (int(c.min()) < 0 or int(c.max()) >= self.spec.codebook_size):
+                raise IndexError(f"{name} out of range [0, {self.spec.codebook_size})")  # reference: F.embedding raises
+        B, _, N = ac.shape
+        wav = torch.empty((B, N * 2 * self.spec.hop), dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.qa_hcodec_decode(self._handle, ac.data_ptr(), sc.data_ptr(), B, N, wav.data_ptr(),
+                                              _stream_ptr(self.device)))
+        return wav
+
+    def tap(self, name: str) -> torch.Tensor:
+        """Test hook: flat fp32 copy of a named intermediate of the last encode/decode (channel-last layout)."""
+        n = self._lib.qa_hcodec_tap(self._handle, name.encode(), None, 0, None)
+        if n < 0:
+            _lib.check(int(n))
+        out = torch.empty(int(n), dtype=torch.float32, device=self.device)
+        n2 = self._lib.qa_hcodec_tap(self._handle, name.encode(), out.data_ptr(), n, _stream_ptr(self.device))
+        if n2 < 0:
+            _lib.check(int(n2))
+        return out
+
+
+class HCodecTokenizer:
+    """Drop-in for the reference's HCodecTokenizer (audio_tokenizer.py:18-66).
+
+    `feature_extractor(wav[B,T+320]) -> hidden_states` stays a PyTorch module (third-party SSL model, SURVEY.md 2.1
+    #18); pass it in, or pass precomputed features to `tokenize(wav, feats=...)`.
+    """
+
+    def __init__(self, pt_path=None, *, state_dict=None, feature_extractor: Optional[Callable] = None,
+                 device: str | torch.device = "cuda:0", spec: HCodecSpec = SPEC_10, **kwargs):
+        if state_dict is None:
+            if pt_path is None:
+                raise ValueError("HCodecTokenizer needs pt_path or state_dict")
+            state_dict = torch.load(pt_path, map_location="cpu")  # audio_tokenizer.py:24
+        self.model = Codec(None, None, None, spec=spec, device=device).load_state_dict(state_dict)
+        self.feature_extractor = feature_extractor
+        self.hop_length = spec.enc_hop  # 640 = 25 Hz (audio_tokenizer.py:31)
+        self.device = torch.device(device)
+
+    @torch.no_grad()
+    def extract_wav2vec2_features(self, wavs: torch.Tensor) -> torch.Tensor:
+        """audio_tokenizer.py:35-48: pad (160,160), mean of all hidden states, sign*|x|^0.3 compression."""
+        if self.feature_extractor is None:
+            raise _lib.QuarkAudioError(-3, "no feature_extractor was given; pass feats= to tokenize()")
+        wavs = torch.nn.functional.pad(wavs, (160, 160))
+        feats = self.feature_extractor(wavs, output_hidden_states=True)
+        feats_mix = torch.stack(feats.hidden_states, dim=1).mean(1)
+        symbol = (feats_mix > 0).float() * 2 - 1
+        return symbol * feats_mix.abs() ** 0.3
+
+    def pad_wav(self, wav: torch.Tensor) -> torch.Tensor:
+        pad = math.ceil(wav.size(-1) / self.hop_length) * self.hop_length - wav.size(-1)
+        return torch.nn.functional.pad(wav, (0, pad))
+
+    @torch.no_grad()
+    def tokenize(self, wav: torch.Tensor, feats: Optional[torch.Tensor] = None):
+        wav = self.pad_wav(wav.to(self.device))
+        if feats is None:
+            feats = self.extract_wav2vec2_features(wav)  # (b, t, d)
+        feats = feats.to(self.device).transpose(-2, -1)  # (b, d, t) view; the library reads it through its strides
+        return self.model.encode(wav.unsqueeze(1), feats)
+
+    @torch.no_grad()
+    def detokenize(self, acoustic_codes: torch.Tensor, semantic_codes: torch.Tensor):
+        return self.model.decode(acoustic_codes, semantic_codes)
