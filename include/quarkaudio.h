@@ -100,7 +100,9 @@ int qa_hcodec_encode(qa_hcodec* h, const float* wav, int64_t B, int64_t T,
 int qa_hcodec_decode(qa_hcodec* h, const int64_t* acoustic_codes, const int64_t* semantic_codes, int64_t B,
                      int64_t N, float* wav_out, void* stream);
 
-/* Test hook: copy the named intermediate of the LAST encode/decode (still in the handle's workspace) into
+/* Test hook: when enabled, encode/decode snapshot their named intermediates (costs copies; off by default). */
+int qa_hcodec_enable_taps(qa_hcodec* h, int on);
+/* Test hook: copy the named snapshot of the LAST encode/decode (still in the handle's workspace) into
  * `dst` (device, fp32, capacity `cap` elements).  Returns the element count or a negative status.  Layout is
  * the library's: time-major, channel-last ([B, frames, channels]).  Names: see DESIGN.md "taps". */
 int64_t qa_hcodec_tap(qa_hcodec* h, const char* name, float* dst, int64_t cap, void* stream);

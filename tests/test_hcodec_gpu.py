@@ -22,6 +22,7 @@ def _make(spec_kwargs, seed, device):
     ospec = R.HCodecSpec(**spec_kwargs)
     sd = synth.hcodec10_state_dict(seed, ospec)
     codec = qa.Codec(None, None, None, spec=qa.HCodecSpec(**spec_kwargs), device=device).load_state_dict(sd)
+    codec.enable_taps()
     return ospec, sd, codec
 
 

@@ -62,6 +62,7 @@ SYMBOLS = {
     "qa_hcodec_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                    C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qa_hcodec_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "qa_hcodec_enable_taps": (C.c_int, [C.c_void_p, C.c_int]),
     "qa_hcodec_tap": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "qa_rvq_search": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),

@@ -742,6 +742,15 @@ int qa_hcodec_decode(qa_hcodec* h, const int64_t* ac, const int64_t* sc, int64_t
     return decode_graph(h, c, (const long long*)ac, (const long long*)sc, (int)B, (int)N, wav_out);
 }
 
+int qa_hcodec_enable_taps(qa_hcodec* h, int on) {
+    if (!h) {
+        set_error("qa_hcodec_enable_taps: null handle");
+        return QA_ERR_INVALID;
+    }
+    h->ctx.capture = on != 0;
+    return QA_OK;
+}
+
 int64_t qa_hcodec_tap(qa_hcodec* h, const char* name, float* dst, int64_t cap, void* stream) {
     if (!h || !name) {
         set_error("qa_hcodec_tap: null argument");

@@ -103,10 +103,15 @@ struct Tap {
 struct Ctx {
     Arena arena;
     hipStream_t stream = nullptr;
-    bool dry = false;  // planning pass: allocate, do not launch
+    bool dry = false;      // planning pass: allocate, do not launch
+    bool capture = false;  // test hook: snapshot named intermediates (buffers are reused / updated in place later)
     std::unordered_map<std::string, Tap> taps;
     void tap(const std::string& name, const float* p, int64_t n) {
-        if (!dry) taps[name] = Tap{p, n};
+        if (!capture) return;
+        float* copy = arena.alloc<float>((size_t)n);
+        if (dry) return;
+        (void)hipMemcpyAsync(copy, p, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, stream);
+        taps[name] = Tap{copy, n};
     }
 };
 

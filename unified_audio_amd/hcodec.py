@@ -158,6 +158,12 @@ class Codec:
                                               _stream_ptr(self.device)))
         return wav
 
+    def enable_taps(self, on: bool = True):
+        """Test hook: make encode/decode snapshot their named intermediates (see DESIGN.md "taps")."""
+        self._require_loaded()
+        _lib.check(self._lib.qa_hcodec_enable_taps(self._handle, int(on)))
+        return self
+
     def tap(self, name: str) -> torch.Tensor:
         """Test hook: flat fp32 copy of a named intermediate of the last encode/decode (channel-last layout)."""
         n = self._lib.qa_hcodec_tap(self._handle, name.encode(), None, 0, None)
