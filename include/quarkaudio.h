@@ -140,6 +140,13 @@ typedef struct qa_conv_args {
 } qa_conv_args;
 int qa_conv1d_cl(const qa_conv_args* args, void* stream);
 
+/* ---- measurement hook (bench.py) ------------------------------------------------------------------------
+ * Between qa_profile_begin() and qa_profile_end() every implicit-GEMM launch is bracketed by HIP events recorded on
+ * the stream it is launched on.  qa_profile_end fills out[cfg*3 + {0,1,2}] = {algorithmic FLOPs, elapsed ms, launches}
+ * for the three tile configurations cfg = 0 (256x32), 1 (128x64), 2 (128x128).  Not thread-safe; process-wide. */
+int qa_profile_begin(void);
+int qa_profile_end(double* out, int32_t n_out);
+
 /* ---- UniSE AR-LM ------------------------------------------------------------------------------------ */
 
 typedef struct qa_lm_spec {

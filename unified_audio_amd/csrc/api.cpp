@@ -1,6 +1,7 @@
 // api.cpp - error channel and the kernel-level C-ABI entry points.
 #include <cstdarg>
 #include <cstdio>
+#include <vector>
 
 #include "kernels.h"
 
@@ -14,9 +15,67 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace qa
 
+namespace qa {
+// ---- live GEMM profiler: (start, stop) event pairs per launch, reduced per tile configuration on read-out
+struct ProfRec {
+    hipEvent_t a, b;
+    int cfg;
+    double flops;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_pool;
+static hipEvent_t prof_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+bool profile_enabled() { return g_prof_on; }
+void profile_record_begin(int cfg, double flops, hipStream_t s) {
+    ProfRec r{prof_event(), prof_event(), cfg, flops};
+    (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+}
+void profile_record_end(hipStream_t s) { (void)hipEventRecord(g_prof.back().b, s); }
+}  // namespace qa
+
 using namespace qa;
 
 extern "C" {
+
+int qa_profile_begin(void) {
+    for (auto& r : g_prof) {
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_prof.clear();
+    g_prof_on = true;
+    return QA_OK;
+}
+
+// out[cfg*3 + {0,1,2}] = {algorithmic FLOPs, elapsed ms, launches} for cfg in {256x32, 128x64, 128x128}
+int qa_profile_end(double* out, int32_t n_out) {
+    g_prof_on = false;
+    if (!out || n_out < PROF_NCFG * 3) {
+        set_error("qa_profile_end: need room for %d doubles", PROF_NCFG * 3);
+        return QA_ERR_INVALID;
+    }
+    for (int i = 0; i < PROF_NCFG * 3; ++i) out[i] = 0.0;
+    for (auto& r : g_prof) {
+        QA_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        QA_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        out[r.cfg * 3 + 0] += r.flops;
+        out[r.cfg * 3 + 1] += ms;
+        out[r.cfg * 3 + 2] += 1.0;
+    }
+    return QA_OK;
+}
 
 int qa_version(void) { return QA_VERSION; }
 const char* qa_last_error(void) { return g_err; }

@@ -96,7 +96,15 @@ struct ConvParams {
     int B, T_in, C_in, T_out, N, K, M;
     int ksize, stride, pad_left, pad_mode, Lp;
     int prologue, act, post_act;
+    int algo_n, algo_k;  // un-padded N / K for the algorithmic FLOP count (0 = use N / K)
 };
+
+// Live measurement hook (bench.py): when enabled every conv_gemm launch is bracketed by HIP events on its own stream.
+enum { PROF_CFG_256x32 = 0, PROF_CFG_128x64 = 1, PROF_CFG_128x128 = 2, PROF_NCFG = 3 };
+bool profile_enabled();
+void profile_record_begin(int cfg, double flops, hipStream_t s);
+void profile_record_end(hipStream_t s);
+
 int launch_conv_gemm(const ConvParams& p, hipStream_t stream);
 int conv_params_from_args(const qa_conv_args& a, ConvParams* p);
 

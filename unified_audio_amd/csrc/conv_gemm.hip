@@ -167,7 +167,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const ConvParams& p, hipStream_t stream) {
     const long long tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+    const bool prof = profile_enabled();
+    if (prof) {
+        const int cfg = BN == 32 ? PROF_CFG_256x32 : (BN == 64 ? PROF_CFG_128x64 : PROF_CFG_128x128);
+        const double n = p.algo_n ? p.algo_n : p.N, k = p.algo_k ? p.algo_k : p.K;
+        profile_record_begin(cfg, 2.0 * (double)p.M * n * k, stream);
+    }
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
+    if (prof) profile_record_end(stream);
     QA_LAUNCH_CHECK();
     return QA_OK;
 }

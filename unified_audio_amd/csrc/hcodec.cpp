@@ -161,6 +161,8 @@ struct Builder {
         dst->N = Np;
         dst->C_in = Cp;
         dst->ksize = k;
+        dst->algo_n = N;
+        dst->algo_cin = C_in;
         pend.push_back(pc);
     }
     void vec(const float** dst, const std::string& name, int64_t n) { pend_vec.push_back({dst, f.vec(name, n)}); }
@@ -253,6 +255,8 @@ int conv_op(Ctx& c, const float* x, int64_t ldx, int B, int T_in, const ConvW& w
     a.prologue = prologue; a.act = act; a.post_act = post_act;
     ConvParams p;
     QA_TRY(conv_params_from_args(a, &p));
+    p.algo_n = w.algo_n;
+    p.algo_k = w.algo_cin ? w.algo_cin * w.ksize : 0;
     return launch_conv_gemm(p, c.stream);
 }
 

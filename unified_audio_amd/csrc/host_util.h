@@ -120,6 +120,7 @@ struct ConvW {
     const float* w = nullptr;
     const float* b = nullptr;
     int N = 0, C_in = 0, ksize = 1;
+    int algo_n = 0, algo_cin = 0;  // un-padded sizes (0 = same as N / C_in)
 };
 
 inline int pad32(int c) { return (int)round_up(c, 32); }
