@@ -140,6 +140,14 @@ typedef struct qa_conv_args {
 } qa_conv_args;
 int qa_conv1d_cl(const qa_conv_args* args, void* stream);
 
+/* ---- host logic exposed for CPU tests (no device needed) ------------------------------------------------
+ * SConv1d geometry of the reference (encoder_modules/conv.py:54-61,195-211, non-causal): for an input of L frames,
+ * kernel k (dilation 1) and stride s it yields T_out = ceil(L/s) and the (left, right + extra) reflect paddings. */
+int qa_sconv_geometry(int64_t L, int32_t ksize, int32_t stride, int64_t* T_out, int32_t* pad_left, int32_t* pad_right);
+/* Source frame read by padded position r of an L-frame signal: index in [0, L) or -1 for "reads zero".  pad_mode 0 zero,
+ * 1 reflect with the short-input rule of pad1d (encoder_modules/conv.py:79-96); max_pad = max(pad_left, pad_right). */
+int64_t qa_resolve_frame(int64_t r, int64_t L, int32_t max_pad, int32_t pad_mode);
+
 /* ---- measurement hook (bench.py) ------------------------------------------------------------------------
  * Between qa_profile_begin() and qa_profile_end() every implicit-GEMM launch is bracketed by HIP events recorded on
  * the stream it is launched on.  qa_profile_end fills out[cfg*3 + {0,1,2}] = {algorithmic FLOPs, elapsed ms, launches}

@@ -1,0 +1,36 @@
+"""HIP path against the committed golden vectors produced by the reference's own modules (tests/golden, oracle/gen_golden.py)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hcodec_ref as R
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hcodec10_*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_hip_path_reproduces_reference_golden(qa_lib, gpu_device, path):
+    import unified_audio_amd as qa
+
+    g = np.load(path)
+    seed = int(g["seed"])
+    sd = synth.hcodec10_state_dict(seed, head_logmag_bias=float(g["head_bias"]))
+    tok = qa.HCodecTokenizer(state_dict=sd, device=gpu_device)
+    wav = synth.synth_wav(seed + 1, int(g["batch"]), int(g["samples"]))  # un-padded: tokenize() pads like the reference
+    padded = R.pad_wav(wav)
+    feat = synth.synth_feat(seed + 2, int(g["batch"]), padded.shape[-1] // 320)
+    ac, sc = tok.tokenize(wav.to(gpu_device), feats=feat.transpose(1, 2).contiguous().to(gpu_device))
+    ref_ac = torch.from_numpy(g["acoustic_codes"].astype(np.int64))
+    ref_sc = torch.from_numpy(g["semantic_codes"].astype(np.int64))
+    assert ac.shape == ref_ac.shape and ac.dtype == torch.int64
+    # integer output: identical except for (rare) near-ties of the nearest-code search, see test_kernels_gpu.py
+    assert (ac.cpu() == ref_ac).float().mean() > 0.97 and (sc.cpu() == ref_sc).float().mean() > 0.97
+    rec = tok.detokenize(ref_ac.to(gpu_device), ref_sc.to(gpu_device)).cpu().numpy()
+    rms = float(np.sqrt(np.mean((rec - g["wav_rec"]) ** 2)))
+    assert rms < 1e-3 * max(1.0, float(np.sqrt(np.mean(g["wav_rec"] ** 2)))), rms  # north_star: <= 1e-3 RMS
+    assert rms / float(np.sqrt(np.mean(g["wav_rec"] ** 2))) < 1e-4

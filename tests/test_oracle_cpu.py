@@ -1,0 +1,86 @@
+"""Pins the CPU oracle: against the reference's own modules (where /root/reference exists), against the committed golden
+vectors (everywhere), and the C / torch RVQ restatements against each other."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hcodec_ref as R
+from oracle import ref_shim, rvq_c, synth
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hcodec10_*.npz")))
+
+
+def test_golden_fixtures_present():
+    assert len(GOLDEN) >= 3
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_oracle_reproduces_reference_golden(path):
+    """tests/golden/*.npz were produced by the reference's vq.Codec (oracle/gen_golden.py); the restatement must
+    reproduce the integer codes exactly and the waveform to fp32 round-off."""
+    g = np.load(path)
+    seed = int(g["seed"])
+    sd = synth.hcodec10_state_dict(seed, head_logmag_bias=float(g["head_bias"]))
+    wav = R.pad_wav(synth.synth_wav(seed + 1, int(g["batch"]), int(g["samples"])))
+    feat = synth.synth_feat(seed + 2, int(g["batch"]), wav.shape[-1] // 320)
+    taps = {}
+    with torch.no_grad():
+        ac, sc = R.encode(sd, wav.unsqueeze(1), feat, taps=taps)
+        rec = R.decode(sd, ac, sc)
+    assert np.array_equal(ac.numpy(), g["acoustic_codes"].astype(np.int64))
+    assert np.array_equal(sc.numpy(), g["semantic_codes"].astype(np.int64))
+    np.testing.assert_allclose(taps["enc.emb"][:, ::37, ::3].numpy(), g["emb_sample"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(taps["enc.sem"][:, ::37, ::3].numpy(), g["sem_sample"], rtol=0, atol=2e-5)
+    err = float(np.sqrt(np.mean((rec.numpy() - g["wav_rec"]) ** 2)) / np.sqrt(np.mean(g["wav_rec"] ** 2)))
+    assert err < 1e-5, err
+    assert rec.shape[-1] == wav.shape[-1]  # length rule len_out = ceil(len_in / hop) * hop
+
+
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference is only mounted in the build container")
+def test_restatement_matches_reference_modules():
+    sd = synth.hcodec10_state_dict(4321)
+    model = ref_shim.load_state(ref_shim.load_reference_codec("1.0"), sd)
+    ref_sd = model.state_dict()
+    for k, v in ref_sd.items():  # same key names and shapes as the reference's own state_dict
+        if not k.startswith("semantic_decoder."):
+            assert k in sd and tuple(sd[k].shape) == tuple(v.shape), k
+    assert not [k for k in sd if k not in ref_sd]
+    wav = R.pad_wav(synth.synth_wav(5, 2, 640 * 7 + 11))
+    feat = synth.synth_feat(6, 2, wav.shape[-1] // 320)
+    with torch.no_grad():
+        ac_r, sc_r = model.encode(wav.unsqueeze(1), feat)
+        ac, sc = R.encode(sd, wav.unsqueeze(1), feat)
+        assert torch.equal(ac, ac_r) and torch.equal(sc, sc_r)
+        w_r, w = model.decode(ac_r, sc_r), R.decode(sd, ac_r, sc_r)
+    assert float((w - w_r).abs().max()) < 1e-5 * float(w_r.abs().max())
+
+
+def test_rvq_c_and_torch_restatements_agree():
+    rng = np.random.default_rng(0)
+    cb = np.stack([rng.standard_normal((128, 64)).astype(np.float32) * 0.5 ** q for q in range(3)])
+    x = rng.standard_normal((500, 64)).astype(np.float32)
+    idx_c = rvq_c.search_f32(x, cb)
+    idx_t, quant_t = R.rvq_search(torch.from_numpy(x), torch.from_numpy(cb))
+    assert (idx_c == idx_t.numpy()).all(axis=1).mean() > 0.995
+    excess, best, gap = rvq_c.check_f64(x, cb, idx_c)
+    assert excess.max() < 1e-4 and (idx_c[gap > 1e-4] == best[gap > 1e-4]).all()
+    np.testing.assert_allclose(rvq_c.lookup_f32(idx_c, cb), R.rvq_lookup(torch.from_numpy(idx_c), torch.from_numpy(cb)).numpy(),
+                               rtol=0, atol=1e-6)
+    # core_vq.py:394-412 invariant: the quantised output is the sum of the looked-up codes
+    np.testing.assert_allclose(quant_t.numpy(), R.rvq_lookup(idx_t, torch.from_numpy(cb)).numpy(), rtol=0, atol=1e-6)
+
+
+def test_rvq_first_maximum_wins_on_exact_ties():
+    cb = np.zeros((1, 8, 4), np.float32)
+    cb[0, 3] = cb[0, 6] = [1, 0, 0, 0]
+    x = np.array([[1, 0, 0, 0]], np.float32)
+    assert rvq_c.search_f32(x, cb)[0, 0] == 3
+    assert int(R.rvq_search(torch.from_numpy(x), torch.from_numpy(cb))[0][0, 0]) == 3
+
+
+def test_pad_wav_rule():
+    assert R.pad_wav(torch.zeros(1, 78480)).shape[-1] == 78720  # H15/sample.flac -> wav_rec.wav
+    assert R.pad_wav(torch.zeros(1, 64000)).shape[-1] == 64000

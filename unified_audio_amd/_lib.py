@@ -69,6 +69,8 @@ SYMBOLS = {
     "qa_rvq_lookup": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                 C.c_void_p]),
     "qa_conv1d_cl": (C.c_int, [C.POINTER(qa_conv_args), C.c_void_p]),
+    "qa_sconv_geometry": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "qa_resolve_frame": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "qa_profile_begin": (C.c_int, []),
     "qa_profile_end": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
     "qa_lm_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(qa_lm_spec), C.POINTER(qa_tensor), C.c_int64, C.c_int]),

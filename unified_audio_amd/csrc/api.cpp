@@ -77,6 +77,21 @@ int qa_profile_end(double* out, int32_t n_out) {
     return QA_OK;
 }
 
+int qa_sconv_geometry(int64_t L, int32_t ksize, int32_t stride, int64_t* T_out, int32_t* pad_left, int32_t* pad_right) {
+    QA_REQUIRE(L > 0 && ksize >= stride && stride >= 1 && T_out && pad_left && pad_right, "qa_sconv_geometry: bad argument");
+    const int pad_total = ksize - stride;
+    const int64_t t = ceil_div(L, stride);
+    *T_out = t;
+    *pad_right = pad_total / 2 + (int32_t)(t * stride - L);
+    *pad_left = pad_total - pad_total / 2;
+    return QA_OK;
+}
+
+int64_t qa_resolve_frame(int64_t r, int64_t L, int32_t max_pad, int32_t pad_mode) {
+    const int Lp = (L <= max_pad) ? max_pad + 1 : (int)L;
+    return resolve_frame((int)r, (int)L, Lp, pad_mode);
+}
+
 int qa_version(void) { return QA_VERSION; }
 const char* qa_last_error(void) { return g_err; }
 

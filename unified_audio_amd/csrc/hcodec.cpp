@@ -280,11 +280,10 @@ struct SGeom {
     int T_out, left, right;
 };
 SGeom sconv_geom(int L, int k, int stride) {
-    const int pad_total = k - stride;
-    const int T_out = (int)ceil_div(L, stride);
-    const int extra = T_out * stride - L;
-    const int right = pad_total / 2, left = pad_total - right;
-    return {T_out, left, right + extra};
+    int64_t t = 0;
+    int32_t left = 0, right = 0;
+    (void)qa_sconv_geometry(L, k, stride, &t, &left, &right);
+    return {(int)t, left, right};
 }
 
 int transformer_op(Ctx& c, const TransformerW& tw, float* x, int B, int N, const std::string& tap_prefix) {
