@@ -7,5 +7,6 @@ There is no CPU / PyTorch fallback: if libquarkaudio_hip.so is missing or no gfx
 """
 from ._lib import QuarkAudioError, lib_path, load_library  # noqa: F401
 from .hcodec import Codec, HCodecSpec, HCodecTokenizer, SPEC_10  # noqa: F401
+from .llm import LLM_SFT  # noqa: F401
 
-__all__ = ["Codec", "HCodecSpec", "HCodecTokenizer", "SPEC_10", "QuarkAudioError", "load_library", "lib_path"]
+__all__ = ["LLM_SFT", "Codec", "HCodecSpec", "HCodecTokenizer", "SPEC_10", "QuarkAudioError", "load_library", "lib_path"]

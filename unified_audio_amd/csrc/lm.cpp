@@ -1,23 +1,305 @@
-// lm.cpp - UniSE decoder-only AR-LM (placeholder until the generate loop lands; fails loudly, never falls back).
+// lm.cpp - UniSE decoder-only AR-LM: prompt assembly, prefill and the greedy global + semantic decode loop.
+//
+// Mirrors LLM_SFT.generate (QuarkAudio-UniSE/model/llm/llm_sft.py:93-195) over the Llama body the reference lifts out of
+// HF transformers (model/llm/llm.py:63-79,150-227): RMSNorm -> QKV (no bias) -> rotate-half RoPE -> causal attention over
+// the KV cache -> O -> +res -> RMSNorm -> SwiGLU -> +res, final RMSNorm, output_head, vocabulary-range mask, greedy arg-max
+// (llm.py:253-288 with do_sample=False, the reference's test path: model/model.py:173).
+//
+// The whole loop is device-resident: token ids never visit the host between steps (embedding gather and arg-max read / write a
+// device int64 vector), the KV cache is owned by the handle's workspace, prefill runs on the implicit-GEMM / flash kernels
+// and each decode step on the weight-streaming skinny GEMM + single-query attention kernels.
+#include <memory>
+
 #include "host_util.h"
+
+namespace qa {
+int launch_assemble_prompt(float* x, const float* task_vec, const float* enroll_sos, const float* enroll_emb,
+                           const float* mix_sos, const float* mix_emb, int B, int Ne, int Nm, int d, hipStream_t s);
+int launch_kv_store(const float* qkv, float* kc, float* vc, int B, int n, int pos0, int max_len, int d, hipStream_t s);
+int launch_embed(const long long* tok, const float* table, float* x, int B, int d, hipStream_t s);
+int launch_fill_i64(long long* p, long long v, int n, hipStream_t s);
+int launch_argmax(const float* logits, int B, int width, long long ld, int lo, long long* tok, long long* ids,
+                  long long ids_ld, int col, hipStream_t s);
+int launch_skinny_gemm(const float* x, long long ldx, const float* w, const float* bias, const float* gate,
+                       long long ldg, const float* res, long long ldr, float* y, long long ldy, int M, int N, int K,
+                       int act, hipStream_t s);
+int launch_attention_decode(const float* q, long long ldq, const float* kc, const float* vc, long long kv_bstride,
+                            long long ldkv, float* out, long long ldo, int B, int H, int hd, int n_keys, float scale,
+                            hipStream_t s);
+}  // namespace qa
 
 using namespace qa;
 
-struct qa_lm {
-    int unused;
+namespace {
+struct LMLayer {
+    const float *ln1 = nullptr, *ln2 = nullptr;
+    ConvW qkv, o, gate, up, down;
 };
+constexpr int LM_MAX_POS = 4096;  // max_position_embeddings (conf/config.yaml:146)
+}  // namespace
+
+struct qa_lm {
+    qa_lm_spec spec{};
+    int device = 0;
+    WeightStore store;
+    const float *task_emb = nullptr, *enroll_sos = nullptr, *mix_sos = nullptr, *codec_emb = nullptr, *norm = nullptr,
+                *rope = nullptr;
+    ConvW adapter, head;
+    std::vector<LMLayer> layers;
+    char* ws = nullptr;
+    size_t ws_cap = 0;
+    Ctx ctx;
+};
+
+namespace {
+
+int vocab_of(const qa_lm_spec& s) { return 3 + s.global_size + s.semantic_size; }
+
+// y[rows, N] = epi(x[rows, K] W^T): skinny kernel for decode-sized M, implicit GEMM otherwise
+int lm_linear(Ctx& c, const float* x, int64_t rows, const ConvW& w, float* y, const float* res = nullptr,
+              const float* gate = nullptr, int n_rows_w = -1, const float* w_ptr = nullptr) {
+    if (c.dry) return QA_OK;
+    const int N = n_rows_w >= 0 ? n_rows_w : w.N;
+    const float* wp = w_ptr ? w_ptr : w.w;
+    if (rows <= 32 && w.C_in % 256 == 0)
+        return launch_skinny_gemm(x, w.C_in, wp, w.b, gate, N, res, N, y, N, (int)rows, N, w.C_in, ACT_NONE, c.stream);
+    qa_conv_args a{};
+    a.x = x; a.w = wp; a.bias = w.b; a.residual = res; a.gate = gate; a.y = y;
+    a.B = 1; a.T_in = rows; a.C_in = w.C_in; a.T_out = rows; a.N = N;
+    a.ldx = w.C_in; a.ldy = N; a.ldr = N; a.ldg = N;
+    a.ksize = 1; a.stride = 1;
+    ConvParams p;
+    QA_TRY(conv_params_from_args(a, &p));
+    return launch_conv_gemm(p, c.stream);
+}
+
+int build_lm(qa_lm* lm, const HostTable& tab) {
+    const qa_lm_spec& sp = lm->spec;
+    const int d = sp.hidden, V = vocab_of(sp), I = sp.intermediate;
+    QA_REQUIRE(sp.n_heads > 0 && d % sp.n_heads == 0, "lm spec: hidden %d not divisible by %d heads", d, sp.n_heads);
+    const int hd = d / sp.n_heads;
+    QA_REQUIRE(hd == 32 || hd == 64 || hd == 128, "lm spec: head_dim %d unsupported", hd);
+    QA_REQUIRE(d % 32 == 0 && I % 32 == 0 && sp.feats_dim % 32 == 0, "lm spec: widths must be multiples of 32");
+    WeightStore& st = lm->store;
+    bool ok = true;
+    std::vector<std::pair<const float**, size_t>> pend;
+    auto vec = [&](const float** dst, const std::string& name, int64_t n) {
+        const float* p = tab.get(name, n);
+        if (!p) {
+            ok = false;
+            return;
+        }
+        pend.push_back({dst, st.add(p, n)});
+    };
+    vec(&lm->task_emb, "task_embedding.weight", (int64_t)sp.num_tasks * d);
+    vec(&lm->enroll_sos, "enroll_sos_embedding.weight", d);
+    vec(&lm->mix_sos, "mix_sos_embedding.weight", d);
+    vec(&lm->codec_emb, "codec_embedding.weight", (int64_t)V * d);
+    vec(&lm->norm, "norm.weight", d);
+    lm->adapter.N = d; lm->adapter.C_in = sp.feats_dim;
+    vec(&lm->adapter.w, "adapter.weight", (int64_t)d * sp.feats_dim);
+    vec(&lm->adapter.b, "adapter.bias", d);
+    lm->head.N = V; lm->head.C_in = d;
+    vec(&lm->head.w, "output_head.weight", (int64_t)V * d);
+    lm->layers.resize(sp.n_layers);
+    for (int i = 0; i < sp.n_layers; ++i) {
+        LMLayer& L = lm->layers[i];
+        const std::string p = "layers." + std::to_string(i);
+        vec(&L.ln1, p + ".input_layernorm.weight", d);
+        vec(&L.ln2, p + ".post_attention_layernorm.weight", d);
+        std::vector<float> wq((size_t)3 * d * d, 0.f);
+        const char* nm[3] = {".self_attn.q_proj.weight", ".self_attn.k_proj.weight", ".self_attn.v_proj.weight"};
+        for (int j = 0; j < 3; ++j) {
+            const float* w = tab.get(p + nm[j], (int64_t)d * d);
+            if (!w) ok = false;
+            else std::memcpy(&wq[(size_t)j * d * d], w, sizeof(float) * d * d);
+        }
+        L.qkv.N = 3 * d; L.qkv.C_in = d;
+        pend.push_back({&L.qkv.w, st.add(wq)});
+        L.o.N = d; L.o.C_in = d;
+        vec(&L.o.w, p + ".self_attn.o_proj.weight", (int64_t)d * d);
+        L.gate.N = I; L.gate.C_in = d;
+        vec(&L.gate.w, p + ".mlp.gate_proj.weight", (int64_t)I * d);
+        L.up.N = I; L.up.C_in = d;
+        vec(&L.up.w, p + ".mlp.up_proj.weight", (int64_t)I * d);
+        L.down.N = d; L.down.C_in = I;
+        vec(&L.down.w, p + ".mlp.down_proj.weight", (int64_t)I * d);
+    }
+    if (!ok) return QA_ERR_MISSING;
+    // LlamaRotaryEmbedding (default rope): inv_freq = theta^(-2i/hd), cos / sin of pos * inv_freq in fp32
+    const int half = hd / 2;
+    std::vector<float> cs((size_t)LM_MAX_POS * half * 2);
+    for (int i = 0; i < half; ++i) {
+        const float inv = 1.0f / std::pow(sp.rope_theta, (float)(2 * i) / (float)hd);
+        for (int t = 0; t < LM_MAX_POS; ++t) {
+            const float fr = (float)t * inv;
+            cs[((size_t)t * half + i) * 2] = (float)std::cos((double)fr);
+            cs[((size_t)t * half + i) * 2 + 1] = (float)std::sin((double)fr);
+        }
+    }
+    pend.push_back({&lm->rope, st.add(cs)});
+    QA_TRY(st.upload());
+    for (auto& pv : pend) *pv.first = st.ptr(pv.second);
+    return QA_OK;
+}
+
+struct LMBuffers {
+    float *x, *hn, *qkv, *att, *g, *u, *logits;
+    float *kc, *vc;
+    long long* tok;
+};
+
+// one pass of the Llama body over `n` new positions per sequence, positions pos0..pos0+n-1
+int lm_body(qa_lm* lm, Ctx& c, LMBuffers& b, int B, int n, int pos0, int max_len, bool skip_last_mlp) {
+    const qa_lm_spec& sp = lm->spec;
+    const int d = sp.hidden, H = sp.n_heads, hd = d / H;
+    const int64_t rows = (int64_t)B * n;
+    const float scale = 1.0f / std::sqrt((float)hd);
+    const size_t cache_stride = (size_t)B * max_len * d;
+    for (int i = 0; i < sp.n_layers; ++i) {
+        const LMLayer& L = lm->layers[i];
+        float* kc = b.kc + i * cache_stride;
+        float* vc = b.vc + i * cache_stride;
+        if (!c.dry) {
+            QA_TRY(launch_rmsnorm(b.x, L.ln1, b.hn, rows, d, sp.rms_eps, c.stream));
+            QA_TRY(lm_linear(c, b.hn, rows, L.qkv, b.qkv));
+            QA_TRY(launch_rope(b.qkv, lm->rope, B, n, H, hd, 3 * d, pos0, c.stream));
+            QA_TRY(launch_kv_store(b.qkv, kc, vc, B, n, pos0, max_len, d, c.stream));
+            if (skip_last_mlp && i == sp.n_layers - 1) break;  // prefill: only the KV cache of the last layer is consumed
+            if (n == 1)
+                QA_TRY(launch_attention_decode(b.qkv, 3 * d, kc, vc, (long long)max_len * d, d, b.att, d, B, H, hd, pos0 + 1,
+                                               scale, c.stream));
+            else
+                QA_TRY(launch_attention(b.qkv, 3 * d, kc, vc, d, b.att, d, B, n, pos0 + n, (long long)max_len * d, H, hd, scale,
+                                        1, c.stream));
+            QA_TRY(lm_linear(c, b.att, rows, L.o, b.x, b.x));
+            QA_TRY(launch_rmsnorm(b.x, L.ln2, b.hn, rows, d, sp.rms_eps, c.stream));
+            QA_TRY(lm_linear(c, b.hn, rows, L.gate, b.g));
+            QA_TRY(lm_linear(c, b.hn, rows, L.up, b.u, nullptr, b.g));
+            QA_TRY(lm_linear(c, b.u, rows, L.down, b.x, b.x));
+        }
+    }
+    return QA_OK;
+}
+
+int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, const float* mix, int Nm, int B, int G,
+                   int S, long long* gids, long long* sids) {
+    const qa_lm_spec& sp = lm->spec;
+    const int d = sp.hidden, I = sp.intermediate;
+    const int L = 1 + (enroll ? 1 + Ne : 0) + 1 + Nm;
+    const int max_len = L + G + 1 + S;
+    QA_REQUIRE(max_len <= LM_MAX_POS, "generate: %d positions exceed max_position_embeddings %d", max_len, LM_MAX_POS);
+    const int64_t prow = (int64_t)B * L;
+    LMBuffers b{};
+    b.x = c.arena.alloc<float>(prow * d);
+    b.hn = c.arena.alloc<float>(prow * d);
+    b.qkv = c.arena.alloc<float>(prow * 3 * d);
+    b.att = c.arena.alloc<float>(prow * d);
+    b.g = c.arena.alloc<float>(prow * I);
+    b.u = c.arena.alloc<float>(prow * I);
+    const int wmax = std::max(sp.global_size, sp.semantic_size);
+    b.logits = c.arena.alloc<float>((size_t)B * wmax);
+    b.kc = c.arena.alloc<float>((size_t)sp.n_layers * B * max_len * d);
+    b.vc = c.arena.alloc<float>((size_t)sp.n_layers * B * max_len * d);
+    b.tok = c.arena.alloc<long long>(B);
+    float* emix = c.arena.alloc<float>((size_t)B * Nm * d);
+    float* eenr = enroll ? c.arena.alloc<float>((size_t)B * Ne * d) : nullptr;
+    if (c.dry) return QA_OK;
+
+    // ---- prompt (llm_sft.py:110-128) and prefill (llm_sft.py:130-135)
+    QA_TRY(lm_linear(c, mix, (int64_t)B * Nm, lm->adapter, emix));
+    if (enroll) QA_TRY(lm_linear(c, enroll, (int64_t)B * Ne, lm->adapter, eenr));
+    QA_TRY(launch_assemble_prompt(b.x, lm->task_emb + (size_t)task * d, enroll ? lm->enroll_sos : nullptr, eenr, lm->mix_sos,
+                                  emix, B, Ne, Nm, d, c.stream));
+    QA_TRY(lm_body(lm, c, b, B, L, 0, max_len, true));
+
+    // ---- decode: G+1 global tokens (the last is fed to the cache but discarded), then S semantic tokens
+    int pos = L;
+    auto phase = [&](long long first_id, int steps, int lo, int width, long long* ids, int ids_ld, int keep) -> int {
+        QA_TRY(launch_fill_i64(b.tok, first_id, B, c.stream));
+        for (int st = 0; st < steps; ++st, ++pos) {
+            QA_TRY(launch_embed(b.tok, lm->codec_emb, b.x, B, d, c.stream));
+            QA_TRY(lm_body(lm, c, b, B, 1, pos, max_len, false));
+            QA_TRY(launch_rmsnorm(b.x, lm->norm, b.hn, B, d, sp.rms_eps, c.stream));
+            // only the rows of output_head inside the active vocabulary slice are multiplied (the mask sets the rest to -inf)
+            QA_TRY(lm_linear(c, b.hn, B, lm->head, b.logits, nullptr, nullptr, width, lm->head.w + (size_t)lo * d));
+            QA_TRY(launch_argmax(b.logits, B, width, width, lo, b.tok, st < keep ? ids : nullptr, ids_ld, st, c.stream));
+        }
+        return QA_OK;
+    };
+    QA_TRY(phase(0, G + 1, 3, sp.global_size, gids, G, G));                            // llm_sft.py:137-164
+    QA_TRY(phase(1, S, 3 + sp.global_size, sp.semantic_size, sids, S, S));             // llm_sft.py:166-193
+    return QA_OK;
+}
+
+int ensure_ws(qa_lm* lm, size_t bytes) {
+    if (bytes <= lm->ws_cap) return QA_OK;
+    if (lm->ws) QA_HIP(hipFree(lm->ws));
+    lm->ws = nullptr;
+    lm->ws_cap = 0;
+    const size_t cap = bytes + bytes / 8;
+    QA_HIP(hipMalloc(reinterpret_cast<void**>(&lm->ws), cap));
+    lm->ws_cap = cap;
+    return QA_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
-int qa_lm_create(qa_lm** out, const qa_lm_spec*, const qa_tensor*, int64_t, int) {
-    if (out) *out = nullptr;
-    set_error("qa_lm_create: the UniSE LM path is not built into this library yet");
-    return QA_ERR_UNSUPPORTED;
+int qa_lm_create(qa_lm** out, const qa_lm_spec* spec, const qa_tensor* tensors, int64_t n_tensors, int device) {
+    if (!out || !spec || !tensors) {
+        set_error("qa_lm_create: null argument");
+        return QA_ERR_INVALID;
+    }
+    *out = nullptr;
+    QA_HIP(hipSetDevice(device));
+    std::unique_ptr<qa_lm> lm(new qa_lm());
+    lm->spec = *spec;
+    lm->device = device;
+    HostTable tab(tensors, n_tensors);
+    const int st = build_lm(lm.get(), tab);
+    if (st != QA_OK) {
+        lm->store.release();
+        return st;
+    }
+    *out = lm.release();
+    return QA_OK;
 }
-void qa_lm_destroy(qa_lm* lm) { delete lm; }
-int qa_lm_generate(qa_lm*, int32_t, const float*, int64_t, const float*, int64_t, int64_t, int32_t, int32_t, float,
-                   int32_t, float, int64_t*, int64_t*, void*) {
-    set_error("qa_lm_generate: the UniSE LM path is not built into this library yet");
-    return QA_ERR_UNSUPPORTED;
+
+void qa_lm_destroy(qa_lm* lm) {
+    if (!lm) return;
+    (void)hipSetDevice(lm->device);
+    (void)hipDeviceSynchronize();
+    lm->store.release();
+    if (lm->ws) (void)hipFree(lm->ws);
+    delete lm;
 }
+
+int qa_lm_generate(qa_lm* lm, int32_t task, const float* enroll_feats, int64_t n_enroll, const float* mix_feats,
+                   int64_t n_mix, int64_t B, int32_t global_length, int32_t semantic_length, float temperature,
+                   int32_t top_k, float top_p, int64_t* global_ids, int64_t* semantic_ids, void* stream) {
+    if (!lm || !mix_feats || !global_ids || !semantic_ids) {
+        set_error("qa_lm_generate: null argument");
+        return QA_ERR_INVALID;
+    }
+    QA_REQUIRE(task >= 0 && task < lm->spec.num_tasks, "qa_lm_generate: task %d out of range (KeyError in the reference)", task);
+    QA_REQUIRE(B > 0 && n_mix > 0 && global_length >= 0 && semantic_length >= 0, "qa_lm_generate: bad shape");
+    QA_REQUIRE(!enroll_feats || n_enroll > 0, "qa_lm_generate: enrollment given with no frames");
+    QA_REQUIRE(temperature > 0.f && temperature <= 1.0f, "qa_lm_generate: temperature must be in (0, 1] (llm.py:278)");
+    QA_REQUIRE(top_k >= 0 && top_p > 0.f, "qa_lm_generate: bad top_k / top_p");
+    QA_HIP(hipSetDevice(lm->device));
+    Ctx& c = lm->ctx;
+    c.stream = static_cast<hipStream_t>(stream);
+    c.dry = true;
+    c.arena.begin(nullptr, 0);
+    QA_TRY(generate_graph(lm, c, task, enroll_feats, (int)n_enroll, mix_feats, (int)n_mix, (int)B, global_length, semantic_length,
+                          (long long*)global_ids, (long long*)semantic_ids));
+    QA_TRY(ensure_ws(lm, c.arena.peak()));
+    c.dry = false;
+    c.arena.begin(lm->ws, lm->ws_cap);
+    return generate_graph(lm, c, task, enroll_feats, (int)n_enroll, mix_feats, (int)n_mix, (int)B, global_length, semantic_length,
+                          (long long*)global_ids, (long long*)semantic_ids);
 }
+
+}  // extern "C"
