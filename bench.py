@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--seconds", type=float, default=10.0, help="clip length (BASELINE configs[1]: 10 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=2, help="clips in the bounded CPU-baseline sample")
+    ap.add_argument("--no-lm", action="store_true", help="skip the secondary UniSE AR-LM tokens/sec measurement")
+    ap.add_argument("--lm-batch", type=int, default=16, help="UniSE segments per GPU (BASELINE configs[2]: batch=16)")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -83,6 +85,37 @@ def cpu_baseline(clips, seconds, reps=2):
     except Exception as e:  # noqa: BLE001 - a failed baseline must not lose the GPU measurement
         return {"value": None, "unit": "audio-seconds/sec", "cores": threads, "kind": "port",
                 "sample": f"FAILED: {type(e).__name__}: {str(e)[:300]}"}
+
+
+def lm_bench(dev, rank, world, dist, batch, reps=2):
+    """Secondary metric of BASELINE.json: UniSE AR tokens/sec = B * (33 + N) generated tokens / wall time of generate()
+    (prefill included), SE prompt of 252 embeddings (5 s segment), 283 greedy steps, features resident in HBM."""
+    import unified_audio_amd as qa
+    from oracle import llm_ref as L
+
+    sd = L.lm_state_dict(4321)
+    lm = qa.LLM_SFT(device=dev).load_state_dict(sd)
+    mix = L.synth_feats(50 + rank, batch, 250).to(dev)
+    mel = torch.zeros(batch, 250, 80)
+    best = float("inf")
+    for i in range(reps + 1):
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        lm.generate("se", None, None, mel, mix, do_sample=False)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if i:
+            best = min(best, dt)
+    return {"metric": "UniSE AR tokens/sec (greedy generate, prefill included)", "value": world * batch * 283 / best,
+            "unit": "tokens/sec", "ms_per_generate": 1e3 * best, "ms_per_decode_step_incl_prefill": 1e3 * best / 283,
+            "config": {"workload": f"LLM_SFT.generate SE task, {batch} segments x 5 s per GPU, prompt 252, 33 global + 250 semantic steps",
+                       "dtype": "f32"}}
 
 
 def log(msg):
@@ -159,6 +192,12 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(out).all()
 
+    lm_line = None
+    if not args.no_lm:
+        del out
+        log("UniSE LM generate ...")
+        lm_line = lm_bench(dev, rank, world, dist, args.lm_batch)
+
     if rank == 0:
         audio_s = world * B * T / SR * args.steps
         cfgs = []
@@ -190,6 +229,8 @@ def main():
                          "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
                          "gemm_share_of_step_time": gemm_ms * 1e-3 / elapsed, "all_gemm_configs": cfgs},
         }
+        if lm_line is not None:
+            line["unise_lm"] = lm_line
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline ...")
             line["cpu_baseline"] = cpu_baseline(args.cpu_clips, args.seconds)
