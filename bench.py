@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 SR = 16000
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD at 2.4 GHz
-CFG_NAMES = ["conv_gemm_kernel<256,32,4,1>", "conv_gemm_kernel<128,64,2,2>", "conv_gemm_kernel<128,128,2,2>"]
+CFG_NAMES = ["conv_gemm_kernel<128,32,4,1>", "conv_gemm_kernel<128,64,2,2>", "conv_gemm_kernel<128,128,2,2>"]
 
 
 def parse():

@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the implicit-GEMM kernel on the shapes H-Codec 1.0 (B=32 x 10 s) actually launches.
+usage: [QA_GEMM_CFG=0|1|2] [QA_GEMM_XCD=0|1] python tools/gemm_bench.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.util import conv1d_cl  # noqa: E402
+from unified_audio_amd import load_library  # noqa: E402
+
+SHAPES = [  # name, M(rows), N, Cin, k, stride
+    ("convnext.pw1", 16000, 2304, 768, 1, 1), ("convnext.pw2", 16000, 768, 2304, 1, 1),
+    ("dec.k3", 16000, 768, 768, 3, 1), ("dec.lstm_ih", 16000, 3072, 768, 1, 1), ("dec.qkv", 16000, 2304, 768, 1, 1),
+    ("dec.w2", 16000, 768, 3072, 1, 1), ("enc.lstm_ih", 16000, 2048, 512, 1, 1), ("enc.o", 16000, 512, 512, 1, 1),
+    ("sem.k3", 16000, 768, 768, 3, 1), ("istft.basis", 16000, 1280, 1312, 1, 1), ("enc.down3", 16000, 512, 256, 16, 8),
+    ("enc.down2", 128000, 256, 128, 10, 5), ("enc.down1", 640000, 128, 64, 8, 4), ("enc.down0", 2560000, 64, 32, 4, 2),
+    ("enc.res0.k3", 5120000, 32, 32, 3, 1), ("enc.res0.sc", 5120000, 32, 32, 1, 1), ("enc.res1.pw", 2560000, 64, 32, 1, 1),
+]
+
+
+def main():
+    lib = load_library()
+    dev = torch.device("cuda:0")
+    tot_t = tot_f = 0.0
+    for name, M, N, C, k, s in SHAPES:
+        T = M * s  # one batch item; zero padding, enough frames for M outputs
+        x = torch.randn(1, T + k, C, device=dev)
+        w = torch.randn(N, k, C, device=dev) * 0.05
+        b = torch.randn(N, device=dev)
+        for _ in range(2):
+            conv1d_cl(lib, x, w, b, stride=s, T_out=M)
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            conv1d_cl(lib, x, w, b, stride=s, T_out=M)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        fl = 2.0 * M * N * C * k
+        tot_t += ms
+        tot_f += fl
+        print(f"{name:14s} M={M:8d} N={N:5d} K={C * k:5d}  {ms * 1e3:9.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
+    print(f"TOTAL {tot_t:.3f} ms  {tot_f / tot_t / 1e9:.1f} TFLOP/s  cfg={os.environ.get('QA_GEMM_CFG', 'auto')} xcd={os.environ.get('QA_GEMM_XCD', '1')}")
+
+
+if __name__ == "__main__":
+    main()

@@ -58,7 +58,7 @@ int qa_profile_begin(void) {
     return QA_OK;
 }
 
-// out[cfg*3 + {0,1,2}] = {algorithmic FLOPs, elapsed ms, launches} for cfg in {256x32, 128x64, 128x128}
+// out[cfg*3 + {0,1,2}] = {algorithmic FLOPs, elapsed ms, launches} for cfg in {128x32, 128x64, 128x128}
 int qa_profile_end(double* out, int32_t n_out) {
     g_prof_on = false;
     if (!out || n_out < PROF_NCFG * 3) {

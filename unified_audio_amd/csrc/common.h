@@ -44,7 +44,10 @@ static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b
 enum { ACT_NONE = 0, ACT_ELU = 1, ACT_GELU = 2, ACT_SILU = 3 };
 enum { PAD_ZERO = 0, PAD_REFLECT = 1 };
 
-__device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
+// ELU(alpha=1).  exp(x) - 1 instead of expm1f: ocml's expm1f brings divergent slow paths (and scratch spills) into the GEMM
+// staging code; the absolute error of the difference is <= 1 ulp(1) = 6e-8, i.e. fp32 rounding noise of the O(0.1..1)
+// activations it feeds.
+__device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
@@ -97,10 +100,11 @@ struct ConvParams {
     int ksize, stride, pad_left, pad_mode, Lp;
     int prologue, act, post_act;
     int algo_n, algo_k;  // un-padded N / K for the algorithmic FLOP count (0 = use N / K)
+    int xcd_swizzle;
 };
 
 // Live measurement hook (bench.py): when enabled every conv_gemm launch is bracketed by HIP events on its own stream.
-enum { PROF_CFG_256x32 = 0, PROF_CFG_128x64 = 1, PROF_CFG_128x128 = 2, PROF_NCFG = 3 };
+enum { PROF_CFG_128x32 = 0, PROF_CFG_128x64 = 1, PROF_CFG_128x128 = 2, PROF_NCFG = 3 };
 bool profile_enabled();
 void profile_record_begin(int cfg, double flops, hipStream_t s);
 void profile_record_end(hipStream_t s);

@@ -12,6 +12,8 @@
 // the current tile's MFMAs).  LDS rows are padded to 36 floats so that the ds_read_b128 fragment loads are
 // bank-conflict free; each lane fetches 4 consecutive k per read and the (lane>>5) halves take k-groups
 // {0..3},{4..7}: the K order inside a step is permuted identically for A and B, which leaves the sum unchanged.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace qa {
@@ -19,7 +21,7 @@ namespace qa {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p) {
     constexpr int BK = 32;
     constexpr int LDS = BK + 4;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -35,68 +37,45 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int m0 = (blockIdx.x / tiles_n) * BM;
-    const int n0 = (blockIdx.x % tiles_n) * BN;
+    // XCD-aware tile order: workgroup b is dispatched to XCD b % 8 (observed, used for speed only).  Give every XCD a
+    // contiguous run of tile ids (n fastest inside it) so the A rows an XCD works on stay private to its L2 and the
+    // column tiles of W are re-read from that same L2.  Bijective for any grid size.
+    int tile = blockIdx.x;
+    if (p.xcd_swizzle) {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = tile & 7, local = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
 
     const int ld_row = tid >> 3;       // 0..31
     const int ld_c4 = (tid & 7) * 4;   // float offset inside the 32-wide K chunk
 
-    // Per-thread A rows: batch base pointer and first source frame.
+    // Per-thread A rows: batch base offset and first source frame.  Rows past M are clamped to row M-1 and columns past
+    // N to column N-1 (their results are never stored), so every load below is unconditional: hipcc would otherwise
+    // branch around each predicated load and drain vmcnt per element.
     long long a_base[A_IT];
     int a_t0[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + ld_row + 32 * i;
-        if (m < p.M) {
-            const int b = m / p.T_out;
-            const int t = m - b * p.T_out;
-            a_base[i] = (long long)b * p.T_in * p.ldx;
-            a_t0[i] = t * p.stride - p.pad_left;
-        } else {
-            a_base[i] = -1;
-            a_t0[i] = 0;
-        }
+        const int m = min(m0 + ld_row + 32 * i, p.M - 1);
+        const int b = m / p.T_out;
+        const int t = m - b * p.T_out;
+        a_base[i] = (long long)b * p.T_in * p.ldx + ld_c4;
+        a_t0[i] = t * p.stride - p.pad_left;
     }
     const float* b_ptr[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int n = n0 + ld_row + 32 * i;
-        b_ptr[i] = (n < p.N) ? p.w + (long long)n * p.K + ld_c4 : nullptr;
+        const int n = min(n0 + ld_row + 32 * i, p.N - 1);
+        b_ptr[i] = p.w + (long long)n * p.K + ld_c4;
     }
 
-    float4 a_reg[A_IT], b_reg[B_IT];
-    auto load_global = [&](int kc) {
-        const int k0 = kc * BK;
-        const int j = k0 / p.C_in;
-        const int c = k0 - j * p.C_in + ld_c4;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_base[i] >= 0) {
-                const int src = resolve_frame(a_t0[i] + j, p.T_in, p.Lp, p.pad_mode);
-                if (src >= 0) v = *reinterpret_cast<const float4*>(p.x + a_base[i] + (long long)src * p.ldx + c);
-            }
-            a_reg[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            b_reg[i] = b_ptr[i] ? *reinterpret_cast<const float4*>(b_ptr[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_lds = [&](int buf) {
-        float* a = sA + buf * BM * LDS;
-        float* b = sB + buf * BN * LDS;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            float4 v = a_reg[i];
-            if (p.prologue == ACT_ELU) {
-                v.x = elu_f(v.x); v.y = elu_f(v.y); v.z = elu_f(v.z); v.w = elu_f(v.w);
-            }
-            *reinterpret_cast<float4*>(a + (ld_row + 32 * i) * LDS + ld_c4) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4*>(b + (ld_row + 32 * i) * LDS + ld_c4) = b_reg[i];
-    };
+    const bool reflect = p.pad_mode == PAD_REFLECT;
+    const bool pro_elu = p.prologue == ACT_ELU;
+    const int ldx_i = (int)p.ldx;
+    const int nk = p.K / BK;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -106,16 +85,52 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.K / BK;
-    load_global(0);
-    store_lds(0);
+    // Staging registers of the NEXT K chunk.  No lambdas / conditionals around them: every iteration loads (the last one
+    // re-loads chunk nk-1, harmlessly) so that hipcc keeps them in VGPRs and issues the loads before the MFMAs.
+    float4 a_reg[A_IT], b_reg[B_IT];
+    float a_keep[A_IT];  // 0 for frames that fall into zero padding (select on the data at LDS-store time, not on the load)
+
+#define QA_LOAD_GLOBAL(KC)                                                                                     \
+    {                                                                                                          \
+        const int k0_ = (KC) * BK;                                                                             \
+        const int j_ = k0_ / p.C_in;                                                                           \
+        const int c_ = k0_ - j_ * p.C_in;                                                                      \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                                     \
+            int r_ = a_t0[i] + j_;                                                                             \
+            const int rr_ = r_ < 0 ? -r_ : (r_ >= p.Lp ? 2 * (p.Lp - 1) - r_ : r_); /* = resolve_frame() */    \
+            r_ = reflect ? rr_ : r_;                                                                           \
+            const bool ok_ = r_ >= 0 && r_ < p.T_in;                                                           \
+            a_keep[i] = ok_ ? 1.f : 0.f;                                                                       \
+            a_reg[i] = *reinterpret_cast<const float4*>(p.x + a_base[i] + (unsigned)((ok_ ? r_ : 0) * ldx_i + c_)); \
+        }                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) b_reg[i] = *reinterpret_cast<const float4*>(b_ptr[i] + k0_); \
+    }
+#define QA_STORE_LDS(BUF)                                                                                      \
+    {                                                                                                          \
+        float* a_ = sA + (BUF) * BM * LDS;                                                                     \
+        float* b_ = sB + (BUF) * BN * LDS;                                                                     \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                                     \
+            float4 v = a_reg[i];                                                                               \
+            v.x *= a_keep[i]; v.y *= a_keep[i]; v.z *= a_keep[i]; v.w *= a_keep[i];                            \
+            float4 e;                                                                                          \
+            e.x = elu_f(v.x); e.y = elu_f(v.y); e.z = elu_f(v.z); e.w = elu_f(v.w);                            \
+            v.x = pro_elu ? e.x : v.x; v.y = pro_elu ? e.y : v.y; v.z = pro_elu ? e.z : v.z; v.w = pro_elu ? e.w : v.w; \
+            *reinterpret_cast<float4*>(a_ + (ld_row + 32 * i) * LDS + ld_c4) = v;                              \
+        }                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i)                                                       \
+            *reinterpret_cast<float4*>(b_ + (ld_row + 32 * i) * LDS + ld_c4) = b_reg[i];                       \
+    }
+
+    QA_LOAD_GLOBAL(0)
+    QA_STORE_LDS(0)
     __syncthreads();
 
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = kc & 1;
-        if (kc + 1 < nk) load_global(kc + 1);
+        const int nxt = min(kc + 1, nk - 1);
+        QA_LOAD_GLOBAL(nxt)
         const float* a = sA + cur * BM * LDS + (wm * WTM + frag_row) * LDS + frag_k;
         const float* b = sB + cur * BN * LDS + (wn * WTN + frag_row) * LDS + frag_k;
 #pragma unroll
@@ -135,9 +150,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (kc + 1 < nk) store_lds(cur ^ 1);
+        QA_STORE_LDS(cur ^ 1)
         __syncthreads();
     }
+#undef QA_LOAD_GLOBAL
+#undef QA_STORE_LDS
 
     // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
     const int col_l = lane & 31, row_h = 4 * (lane >> 5);
@@ -169,7 +186,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
     const long long tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     const bool prof = profile_enabled();
     if (prof) {
-        const int cfg = BN == 32 ? PROF_CFG_256x32 : (BN == 64 ? PROF_CFG_128x64 : PROF_CFG_128x128);
+        const int cfg = BN == 32 ? PROF_CFG_128x32 : (BN == 64 ? PROF_CFG_128x64 : PROF_CFG_128x128);
         const double n = p.algo_n ? p.algo_n : p.N, k = p.algo_k ? p.algo_k : p.K;
         profile_record_begin(cfg, 2.0 * (double)p.M * n * k, stream);
     }
@@ -182,15 +199,35 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
 int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
     QA_REQUIRE(p.K % 32 == 0 && p.C_in % 32 == 0, "conv_gemm: K=%d / C_in=%d must be multiples of 32", p.K, p.C_in);
     QA_REQUIRE((p.ldx % 4) == 0, "conv_gemm: ldx=%lld must be a multiple of 4 floats", p.ldx);
+    QA_REQUIRE((long long)p.T_in * p.ldx < (1LL << 31), "conv_gemm: one batch item spans %lld floats (limit 2^31)",
+               (long long)p.T_in * p.ldx);
     QA_REQUIRE(((uintptr_t)p.x % 16) == 0 && ((uintptr_t)p.w % 16) == 0, "conv_gemm: x / w must be 16-byte aligned");
     if (p.M <= 0 || p.N <= 0) return QA_OK;
     QA_REQUIRE(ceil_div(p.M, 64) * ceil_div(p.N, 32) < (1LL << 31), "conv_gemm: grid too large");
-    if (p.N <= 32) return launch_cfg<256, 32, 4, 1>(p, stream);
-    if (p.N <= 64) return launch_cfg<128, 64, 2, 2>(p, stream);
-    // few tiles: prefer the narrower tile so that more than one wave of workgroups exists
-    const long long big = ceil_div(p.M, 128) * ceil_div(p.N, 128);
-    if (big < 512) return launch_cfg<128, 64, 2, 2>(p, stream);
-    return launch_cfg<128, 128, 2, 2>(p, stream);
+    static const int forced = [] {
+        const char* e = getenv("QA_GEMM_CFG");
+        return e ? atoi(e) : -1;
+    }();
+    static const int swz = [] {
+        const char* e = getenv("QA_GEMM_XCD");
+        return e ? atoi(e) : 1;
+    }();
+    ConvParams q = p;
+    q.xcd_swizzle = swz;
+    int cfg;
+    if (forced >= 0) cfg = forced;
+    else if (p.N <= 32) cfg = PROF_CFG_128x32;
+    else if (p.N <= 64) cfg = PROF_CFG_128x64;
+    else {
+        // few tiles: prefer the narrower tile so that more than one wave of workgroups exists
+        const long long big = ceil_div(p.M, 128) * ceil_div(p.N, 128);
+        cfg = big < 512 ? PROF_CFG_128x64 : PROF_CFG_128x128;
+    }
+    switch (cfg) {
+        case PROF_CFG_128x32: return launch_cfg<128, 32, 4, 1>(q, stream);
+        case PROF_CFG_128x64: return launch_cfg<128, 64, 2, 2>(q, stream);
+        default: return launch_cfg<128, 128, 2, 2>(q, stream);
+    }
 }
 
 int conv_params_from_args(const qa_conv_args& a, ConvParams* out) {

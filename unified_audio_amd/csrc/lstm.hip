@@ -28,6 +28,17 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const float* __restrict_
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // issue the epilogue's HBM reads (input projection, previous cell state) first: their latency hides under the matvec
+    const bool epi = tid < B * 4;
+    const int eb = tid >> 2, eu = tid & 3;
+    const int unit = blockIdx.x * 4 + eu;
+    float4 xg = make_float4(0.f, 0.f, 0.f, 0.f);
+    float c_prev = 0.f;
+    if (epi) {
+        xg = *reinterpret_cast<const float4*>(xw + ((long long)eb * T + t) * 4 * d + (long long)unit * 4);
+        if (t > 0) c_prev = c_state[(long long)eb * d + unit];
+    }
+
     if (t > 0) {
         const int kw = d / 8;
         const int k0 = wave * kw;
@@ -58,21 +69,18 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const float* __restrict_
         for (int r = 0; r < 4; ++r) part[wave][m][4 * kq + r][li] = acc[m][r];
     __syncthreads();
 
-    if (tid < B * 4) {
-        const int b = tid >> 2, u = tid & 3;
-        const int unit = blockIdx.x * 4 + u;
-        const float* xg = xw + ((long long)b * T + t) * 4 * d + (long long)unit * 4;
-        float g4[4];
+    if (epi) {
+        const int b = eb, u = eu;
+        float g4[4] = {xg.x, xg.y, xg.z, xg.w};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float s = xg[g];
+            float s = g4[g];
 #pragma unroll
             for (int w = 0; w < 8; ++w) s += part[w][b >> 4][b & 15][u * 4 + g];
             g4[g] = s;
         }
         const float ig = sigmoid_f(g4[0]), fg = sigmoid_f(g4[1]), gg = tanhf(g4[2]), og = sigmoid_f(g4[3]);
         const long long ci = (long long)b * d + unit;
-        const float c_prev = t > 0 ? c_state[ci] : 0.f;
         const float c_new = fg * c_prev + ig * gg;
         c_state[ci] = c_new;
         h_out[((long long)b * T + t) * d + unit] = og * tanhf(c_new);
