@@ -20,7 +20,7 @@ namespace qa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool PRO_ELU>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p) {
     constexpr int BK = 32;
     constexpr int LDS = BK + 4;
@@ -73,7 +73,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p) {
     }
 
     const bool reflect = p.pad_mode == PAD_REFLECT;
-    const bool pro_elu = p.prologue == ACT_ELU;
     const int ldx_i = (int)p.ldx;
     const int nk = p.K / BK;
 
@@ -86,7 +85,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // Staging registers of the NEXT K chunk.  No lambdas / conditionals around them: every iteration loads (the last one
-    // re-loads chunk nk-1, harmlessly) so that hipcc keeps them in VGPRs and issues the loads before the MFMAs.
+    // re-loads chunk nk-1, harmlessly) so that hipcc keeps them in VGPRs and issues the loads before the MFMAs.  (Keeping
+    // the row pointers incrementally under a wave-uniform "tap changed" branch was measured 13 % SLOWER: the branch splits
+    // the block and the address VALU no longer interleaves with the MFMAs.)
     float4 a_reg[A_IT], b_reg[B_IT];
     float a_keep[A_IT];  // 0 for frames that fall into zero padding (select on the data at LDS-store time, not on the load)
 
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p) {
         _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                                     \
             float4 v = a_reg[i];                                                                               \
             v.x *= a_keep[i]; v.y *= a_keep[i]; v.z *= a_keep[i]; v.w *= a_keep[i];                            \
-            float4 e;                                                                                          \
-            e.x = elu_f(v.x); e.y = elu_f(v.y); e.z = elu_f(v.z); e.w = elu_f(v.w);                            \
-            v.x = pro_elu ? e.x : v.x; v.y = pro_elu ? e.y : v.y; v.z = pro_elu ? e.z : v.z; v.w = pro_elu ? e.w : v.w; \
+            if (PRO_ELU) {                                                                                     \
+                v.x = elu_f(v.x); v.y = elu_f(v.y); v.z = elu_f(v.z); v.w = elu_f(v.w);                        \
+            }                                                                                                  \
             *reinterpret_cast<float4*>(a_ + (ld_row + 32 * i) * LDS + ld_c4) = v;                              \
         }                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < B_IT; ++i)                                                       \
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p) {
 
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const ConvParams& p, hipStream_t stream) {
+    QA_REQUIRE(p.prologue == ACT_NONE || p.prologue == ACT_ELU, "conv_gemm: prologue %d unsupported", p.prologue);
     const long long tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     const bool prof = profile_enabled();
     if (prof) {
@@ -190,7 +192,10 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
         const double n = p.algo_n ? p.algo_n : p.N, k = p.algo_k ? p.algo_k : p.K;
         profile_record_begin(cfg, 2.0 * (double)p.M * n * k, stream);
     }
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
+    if (p.prologue == ACT_ELU)
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
     if (prof) profile_record_end(stream);
     QA_LAUNCH_CHECK();
     return QA_OK;
