@@ -134,22 +134,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p) {
         QA_LOAD_GLOBAL(nxt)
         const float* a = sA + cur * BM * LDS + (wm * WTM + frag_row) * LDS + frag_k;
         const float* b = sB + cur * BN * LDS + (wn * WTN + frag_row) * LDS + frag_k;
+        {
+            // fragment double buffering: the ds_read_b128 of k-group kk+1 are issued before the MFMAs of group kk
+            float4 af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            float4 af[TM], bf[TN];
+            for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS + kk * 8);
+            for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS + kk * 8);
+            for (int kk = 0; kk < 4; ++kk) {
+                const int cb = kk & 1, nb = cb ^ 1;
+                if (kk < 3) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
+                        af[nb][i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS + (kk + 1) * 8);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        bf[nb][j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS + (kk + 1) * 8);
                 }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].x, bf[cb][j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].y, bf[cb][j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].z, bf[cb][j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].w, bf[cb][j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
         }
         QA_STORE_LDS(cur ^ 1)
         __syncthreads();
