@@ -73,6 +73,16 @@ typedef struct qa_hcodec_spec {
     int32_t n_fft;            /* 1280 */
     int32_t hop;              /* 320 */
     int32_t gn_groups;        /* 32 */
+    /* H-Codec 1.5 adaptive frame rate (QuarkAudio-HCodec/HCodec-1.5/conf/config_adaptive_v3.yaml:65-111); 0 = H-Codec 1.0 */
+    int32_t adaptive;
+    int32_t agg_layers;       /* 32  aggregators.*.num_layers (d_model = code_dim) */
+    int32_t agg_heads;        /* 8 */
+    int32_t agg_ff;           /* 2048 */
+    int32_t bt_layers;        /* 32  transformer_kwargs.num_layers (bottleneck, d_model = 2*code_dim) */
+    int32_t bt_heads;         /* 8 */
+    int32_t bt_ff;            /* 2048 */
+    int32_t max_tokens_per_group; /* 8 */
+    float threshold;          /* 0.6 manual_threshold */
 } qa_hcodec_spec;
 
 typedef struct qa_hcodec qa_hcodec;
@@ -99,6 +109,20 @@ int qa_hcodec_encode(qa_hcodec* h, const float* wav, int64_t B, int64_t T,
 /* Codec.decode.  codes: int64 [B, num_quantizers, N]; wav_out: fp32 [B, 2*N*hop]. */
 int qa_hcodec_decode(qa_hcodec* h, const int64_t* acoustic_codes, const int64_t* semantic_codes, int64_t B,
                      int64_t N, float* wav_out, void* stream);
+
+/* H-Codec 1.5 (spec.adaptive != 0): Codec.encode / Codec.decode of QuarkAudio-HCodec/HCodec-1.5/vq/codec_adaptive.py:150-199.
+ * The number of groups G is data dependent (the reference syncs the host too: modeling_flexicodec_new.py:910), so
+ *   - encode writes int64 [B, nq, G] length-injected codes (code' = (len-1)*codebook_size + code) compactly into buffers of
+ *     capacity B*nq*N25 elements and returns G through *n_groups (the call synchronises `stream` once);
+ *   - qa_hcodec_adaptive_frames returns max_b sum_g len[b,g] (= N25 of the clip) for a batch of codes, so the caller can size
+ *     wav_out = [B, frames * 2 * hop] before qa_hcodec_decode_adaptive. */
+int qa_hcodec_encode_adaptive(qa_hcodec* h, const float* wav, int64_t B, int64_t T,
+                              const float* feat, int64_t feat_stride_b, int64_t feat_stride_c, int64_t feat_stride_t,
+                              int64_t n_feat_frames, int64_t* acoustic_codes, int64_t* semantic_codes, int64_t* n_groups,
+                              void* stream);
+int qa_hcodec_adaptive_frames(qa_hcodec* h, const int64_t* semantic_codes, int64_t B, int64_t G, int64_t* frames, void* stream);
+int qa_hcodec_decode_adaptive(qa_hcodec* h, const int64_t* acoustic_codes, const int64_t* semantic_codes, int64_t B,
+                              int64_t G, int64_t frames, float* wav_out, void* stream);
 
 /* Test hook: when enabled, encode/decode snapshot their named intermediates (costs copies; off by default). */
 int qa_hcodec_enable_taps(qa_hcodec* h, int on);

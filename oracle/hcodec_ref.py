@@ -50,6 +50,16 @@ class HCodecSpec:
     n_fft: int = 1280  # codec_decoder.py:21
     hop: int = 320  # codec_decoder.py:22
     gn_groups: int = 32  # conv.py:259
+    # --- H-Codec 1.5 only (HCodec-1.5/conf/config_adaptive_v3.yaml:65-111); adaptive=False is H-Codec 1.0
+    adaptive: bool = False
+    agg_layers: int = 32  # aggregators.*.num_layers
+    agg_heads: int = 8
+    agg_ff: int = 2048
+    bt_layers: int = 32  # transformer_kwargs.num_layers (bottleneck, d_model = 2 * code_dim)
+    bt_heads: int = 8
+    bt_ff: int = 2048
+    threshold: float = 0.6  # manual_threshold
+    max_tokens_per_group: int = 8
 
     @property
     def enc_hop(self) -> int:
@@ -57,6 +67,9 @@ class HCodecSpec:
 
 
 SPEC_10 = HCodecSpec()
+# H-Codec 1.5 (config_adaptive_v3.yaml): SEANet stride order 8,5,4,2 (the config lists [2,4,5,8] and seanet.py:114 reverses
+# it), XLSR features (1024), decoder width 1024, plus the adaptive-frame-rate stacks.
+SPEC_15 = HCodecSpec(ratios=(8, 5, 4, 2), sem_in=1024, sem_ch=1024, dec_dim=1024, dec_inter=2304, adaptive=True)
 
 
 # ----------------------------------------------------------------------------- padding / convs

@@ -25,7 +25,21 @@ def reference_available() -> bool:
     return os.path.isdir(os.path.join(REFERENCE_ROOT, _VERSIONS["1.0"], "vq"))
 
 
-def load_reference_codec(version: str = "1.0"):
+def _config_15(spec):
+    import yaml
+
+    cfg = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, _VERSIONS["1.5"], "conf", "config_adaptive_v3.yaml")))
+    ad = cfg["adaptive_config"]
+    if spec is not None:  # the reference builds its stacks from this YAML, so smaller test variants are the reference's own code
+        for k in ("semantic_aggregator", "acoustic_aggregator"):
+            ad["aggregators"][k].update(num_layers=spec.agg_layers, num_heads=spec.agg_heads, dim_feedforward=spec.agg_ff)
+        ad["transformer_kwargs"].update(num_layers=spec.bt_layers, num_heads=spec.bt_heads, dim_feedforward=spec.bt_ff)
+        ad["manual_threshold"] = spec.threshold
+        ad["max_tokens_per_group"] = spec.max_tokens_per_group
+    return cfg
+
+
+def load_reference_codec(version: str = "1.0", spec=None):
     """Construct the reference `vq.Codec` (eval mode, random init) for the given H-Codec version."""
     if not reference_available():
         raise RuntimeError(f"reference tree not found under {REFERENCE_ROOT}")
@@ -38,9 +52,17 @@ def load_reference_codec(version: str = "1.0"):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             from vq import Codec  # type: ignore
-            if version != "1.0":
-                raise NotImplementedError("only H-Codec 1.0 is wired so far")
-            model = Codec(None, None, None)
+            if version == "1.0":
+                model = Codec(None, None, None)
+            elif version == "1.5":
+                import contextlib
+                import io
+
+                cfg = _config_15(spec)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    model = Codec(cfg["encoder_config"], cfg["decoder_config"], cfg["quantizer_config"], cfg["adaptive_config"])
+            else:
+                raise NotImplementedError("H-Codec 2.0 is not wired yet")
     finally:
         sys.path.remove(_STUBS)
         sys.path.remove(root)

@@ -73,6 +73,24 @@ class _Gen:
             self.norm(f"{lp}.post_attention_layernorm", d, bias=False)
 
 
+def _mimi(self, p, d, n_layers, ff):
+    for i in range(n_layers):
+        lp = f"{p}.layers.{i}"
+        self.linear(lp + ".self_attn.in_proj", 3 * d, d, bias=False, gain=1.5)
+        self.sd[lp + ".self_attn.in_proj_weight"] = self.sd.pop(lp + ".self_attn.in_proj.weight")
+        self.linear(lp + ".self_attn.out_proj", d, d, bias=False)
+        self.norm(lp + ".norm1", d)
+        self.norm(lp + ".norm2", d)
+        self.linear(lp + ".linear1", ff, d, bias=False)
+        self.linear(lp + ".linear2", d, ff, bias=False)
+        # LayerScale init is 0.01 in the reference; a trained model moves it, and a larger value makes the test discriminating
+        self.sd[lp + ".layer_scale_1.scale"] = _t(self.rng.uniform(0.05, 0.3, size=d))
+        self.sd[lp + ".layer_scale_2.scale"] = _t(self.rng.uniform(0.05, 0.3, size=d))
+
+
+_Gen.mimi = _mimi
+
+
 def hcodec10_state_dict(seed: int = 1234, spec: HCodecSpec = SPEC_10, head_logmag_bias: float = 1.5,
                         head_gain: float = 1.0) -> Dict[str, torch.Tensor]:
     g = _Gen(seed)
@@ -133,6 +151,11 @@ def hcodec10_state_dict(seed: int = 1234, spec: HCodecSpec = SPEC_10, head_logma
             g.conv(f"{bp}.res_units.{u}.conv2", sc, sc, 1, bias=False)
         g.conv(f"{bp}.conv.conv", sc, sc, 3 if s == 1 else 2 * s, bias=True)
     g.conv("semantic_encoder.conv2.conv", spec.code_dim, sc, 3, bias=False)
+    if spec.adaptive:  # H-Codec 1.5 stacks (codec_adaptive.py:49-64; mimi/transformer.py:436-594,701-739)
+        for name in ("semantic_aggregator", "acoustic_aggregator"):
+            g.sd[name + ".query_embedding"] = _t(g.rng.standard_normal((1, spec.code_dim, 1)))
+            g.mimi(name + ".transformer.transformer", spec.code_dim, spec.agg_layers, spec.agg_ff)
+        g.mimi("bottleneck_transformer.transformer", 2 * spec.code_dim, spec.bt_layers, spec.bt_ff)
     return g.sd
 
 

@@ -98,3 +98,68 @@ def test_decode_rejects_out_of_range_codes(qa_lib, gpu_device):
     bad = torch.full((1, 3, 4), 64, dtype=torch.int64)
     with pytest.raises(IndexError):
         codec.decode(bad, bad)
+
+
+# ------------------------------------------------------------------------------------------- H-Codec 1.5
+
+def _spec15(**kw):
+    import dataclasses
+
+    return dataclasses.replace(R.SPEC_15, **kw)
+
+
+def _run_parity_15(ospec, B, T, device, seed=31):
+    import unified_audio_amd as qa
+    from oracle import hcodec15_ref as R15
+
+    sd = synth.hcodec10_state_dict(seed, ospec)
+    kw = {f: getattr(ospec, f) for f in ospec.__dataclass_fields__}
+    codec = qa.Codec(None, None, None, spec=qa.HCodecSpec(**kw), device=device).load_state_dict(sd)
+    codec.enable_taps()
+    wav = synth.synth_wav(seed + 1, B, T)
+    feat = synth.synth_feat(seed + 2, B, T // 320, ospec.sem_in)
+    taps = {}
+    ref = R15.encode(sd, wav.unsqueeze(1), feat, ospec, taps)
+    got = codec.encode(wav.to(device).unsqueeze(1), feat.to(device))
+    torch.cuda.synchronize()
+    assert set(got) == {"acoustic_codes", "semantic_codes"}
+    assert got["acoustic_codes"].shape == ref["acoustic_codes"].shape, (got["acoustic_codes"].shape, ref["acoustic_codes"].shape)
+    K = ospec.codebook_size
+    # grouping (token lengths) is integer output of a threshold test on fp32 similarities: must match exactly here
+    len_g = torch.div(got["semantic_codes"][:, 0].cpu(), K, rounding_mode="floor") + 1
+    len_o = torch.div(ref["semantic_codes"][:, 0], K, rounding_mode="floor") + 1
+    assert torch.equal(len_g, len_o)
+    report = {
+        "enc.emb_agg": rel_err(codec.tap("enc.emb_agg"), taps["enc.emb_agg"].transpose(1, 2).contiguous().flatten()),
+        "enc.sem_agg": rel_err(codec.tap("enc.sem_agg"), taps["enc.sem_agg"].transpose(1, 2).contiguous().flatten()),
+    }
+    agree = min((got[k].cpu() == ref[k]).float().mean().item() for k in ref)
+    wav_o = R15.decode(sd, ref["acoustic_codes"], ref["semantic_codes"], ospec)
+    wav_g = codec.decode(ref["acoustic_codes"].to(device), ref["semantic_codes"].to(device))
+    torch.cuda.synchronize()
+    report["wav"] = rel_err(wav_g, wav_o)
+    # decode(plain codes, token_lengths) is the same computation (codec_adaptive.py:184-186)
+    plain_a, plain_s = ref["acoustic_codes"] % K, ref["semantic_codes"] % K
+    wav_g2 = codec.decode(plain_a.to(device), plain_s.to(device), token_lengths=len_o.to(device))
+    assert torch.equal(wav_g2, wav_g)
+    return report, agree, int(ref["acoustic_codes"].shape[-1]), (wav_g.cpu(), wav_o)
+
+
+@pytest.mark.parametrize("threshold", [0.6, 0.72])
+def test_hcodec15_reduced_depth_parity(qa_lib, gpu_device, threshold):
+    """H-Codec 1.5 at full width with 2-layer adaptive stacks (the layer count is a YAML knob of the reference)."""
+    ospec = _spec15(agg_layers=2, bt_layers=2, threshold=threshold)
+    report, agree, G, (wav_g, wav_o) = _run_parity_15(ospec, B=3, T=640 * 30, device=gpu_device)
+    print(report, agree, "groups", G)
+    assert all(v < STAGE_TOL for v in report.values()), report
+    assert agree > 0.98
+    assert wav_g.shape == wav_o.shape == (3, 640 * 30)
+
+
+def test_hcodec15_full_depth_parity(qa_lib, gpu_device):
+    """The shipped H-Codec 1.5 configuration: 32-layer aggregators and bottleneck (687 M parameters), 2 clips x 2.6 s."""
+    report, agree, G, (wav_g, wav_o) = _run_parity_15(R.SPEC_15, B=2, T=640 * 65, device=gpu_device, seed=41)
+    print(report, agree, "groups", G)
+    assert all(v < 4 * STAGE_TOL for v in report.values()), report
+    assert float((wav_g - wav_o).pow(2).mean().sqrt()) < 1e-3  # north_star waveform tolerance
+    assert agree > 0.97

@@ -30,6 +30,9 @@ class qa_hcodec_spec(C.Structure):
         ("codebook_size", C.c_int32), ("num_quantizers", C.c_int32), ("dec_dim", C.c_int32), ("dec_inter", C.c_int32),
         ("dec_heads", C.c_int32), ("dec_layers", C.c_int32), ("convnext_layers", C.c_int32), ("n_fft", C.c_int32),
         ("hop", C.c_int32), ("gn_groups", C.c_int32),
+        ("adaptive", C.c_int32), ("agg_layers", C.c_int32), ("agg_heads", C.c_int32), ("agg_ff", C.c_int32),
+        ("bt_layers", C.c_int32), ("bt_heads", C.c_int32), ("bt_ff", C.c_int32), ("max_tokens_per_group", C.c_int32),
+        ("threshold", C.c_float),
     ]
 
 
@@ -62,6 +65,11 @@ SYMBOLS = {
     "qa_hcodec_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                    C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qa_hcodec_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "qa_hcodec_encode_adaptive": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                            C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
+    "qa_hcodec_adaptive_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
+    "qa_hcodec_decode_adaptive": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                            C.c_void_p]),
     "qa_hcodec_enable_taps": (C.c_int, [C.c_void_p, C.c_int]),
     "qa_hcodec_tap": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "qa_rvq_search": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

@@ -305,7 +305,7 @@ int launch_groupnorm(const float* x, const float* w, const float* bias, float* y
 // Rotate-half RoPE applied in place to the q and k parts of a fused [rows, 3*d] QKV buffer
 // (transformer.py:182-215: q*cos + rotate_half(q)*sin, positions 0..N-1, tables as RotaryEmbedding.forward).
 __global__ __launch_bounds__(256) void rope_kernel(float* __restrict__ qkv, const float* __restrict__ cs, int B, int N,
-                                                   int H, int hd, long long ld, int pos0) {
+                                                   int H, int hd, long long ld, int pos0, int interleaved) {
     // one thread: one (row, head, pair i < hd/2) for q and for k
     const int half = hd >> 1;
     const long long total = (long long)B * N * H * half;
@@ -319,18 +319,21 @@ __global__ __launch_bounds__(256) void rope_kernel(float* __restrict__ qkv, cons
     const int d = H * hd;
     float* q = qkv + row * ld + h * hd;
     float* k = q + d;
-    const float q1 = q[i], q2 = q[i + half];
-    q[i] = q1 * c - q2 * s;
-    q[i + half] = q2 * c + q1 * s;
-    const float k1 = k[i], k2 = k[i + half];
-    k[i] = k1 * c - k2 * s;
-    k[i + half] = k2 * c + k1 * s;
+    // rotate-half pairs (i, i + hd/2) (HF Llama / codec transformers) or interleaved pairs (2i, 2i+1) (mimi, module/rope.py:13-69)
+    const int i0 = interleaved ? 2 * i : i, i1 = interleaved ? 2 * i + 1 : i + half;
+    const float q1 = q[i0], q2 = q[i1];
+    q[i0] = q1 * c - q2 * s;
+    q[i1] = q2 * c + q1 * s;
+    const float k1 = k[i0], k2 = k[i1];
+    k[i0] = k1 * c - k2 * s;
+    k[i1] = k2 * c + k1 * s;
 }
 
-int launch_rope(float* qkv, const float* cos_sin, int B, int N, int H, int hd, long long ld, int pos0, hipStream_t s) {
+int launch_rope(float* qkv, const float* cos_sin, int B, int N, int H, int hd, long long ld, int pos0, hipStream_t s,
+                int interleaved) {
     const long long total = (long long)B * N * H * (hd / 2);
     hipLaunchKernelGGL(rope_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, qkv, cos_sin, B, N, H, hd, ld,
-                       pos0);
+                       pos0, interleaved);
     QA_LAUNCH_CHECK();
     return QA_OK;
 }
@@ -458,6 +461,222 @@ int launch_istft_ola(const float* frames, const float* win, float* out, int B, i
     if (total == 0) return QA_OK;
     hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, frames, win, out, B, T,
                        n_fft, hop);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// H-Codec 1.5 adaptive frame rate (HCodec-1.5/adaptive/modeling_flexicodec_new.py:828-921): cosine similarity of
+// consecutive semantic frames, a new group wherever sim <= threshold, groups capped at max_tokens frames.
+// One workgroup per batch item; the scan over T (<= a few hundred frames) is sequential in thread 0.
+//   seg[b][t]   group index of frame t          start[b][g], len[b][g] (0 for g >= nseg[b])      nseg[b]
+//   gmax        max over b of nseg (atomicMax; zeroed by the launcher)
+__global__ __launch_bounds__(256) void align_kernel(const float* __restrict__ sem, int T, int D, float thr, int max_tokens,
+                                                    int* __restrict__ seg, int* __restrict__ start, int* __restrict__ len,
+                                                    int* __restrict__ nseg, int* __restrict__ gmax) {
+    extern __shared__ float sh[];  // [T] 1/max(norm, eps), then [T] sim
+    float* inv = sh;
+    float* sim = sh + T;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = sem + (long long)b * T * D;
+    for (int t = wave; t < T; t += 4) {
+        float s = 0.f;
+        for (int c = lane * 4; c < D; c += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (long long)t * D + c);
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        s = wave_sum(s);
+        if (lane == 0) inv[t] = 1.f / fmaxf(sqrtf(s), 1e-8f);  // F.cosine_similarity: x / clamp_min(||x||, eps)
+    }
+    __syncthreads();
+    for (int t = wave; t < T - 1; t += 4) {
+        const float ia = inv[t], ib = inv[t + 1];
+        float s = 0.f;
+        for (int c = lane * 4; c < D; c += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(x + (long long)t * D + c);
+            const float4 bb = *reinterpret_cast<const float4*>(x + (long long)(t + 1) * D + c);
+            s += (a.x * ia) * (bb.x * ib) + (a.y * ia) * (bb.y * ib) + (a.z * ia) * (bb.z * ib) + (a.w * ia) * (bb.w * ib);
+        }
+        s = wave_sum(s);
+        if (lane == 0) sim[t] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int g = -1, in_seg = 0;
+        for (int t = 0; t < T; ++t) {
+            const bool new_group = (t == 0) || (sim[t - 1] <= thr);
+            in_seg = new_group ? 0 : in_seg + 1;
+            if (in_seg % max_tokens == 0) {
+                ++g;
+                start[(long long)b * T + g] = t;
+                len[(long long)b * T + g] = 0;
+            }
+            seg[(long long)b * T + t] = g;
+            len[(long long)b * T + g] += 1;
+        }
+        for (int k = g + 1; k < T; ++k) {
+            start[(long long)b * T + k] = T;
+            len[(long long)b * T + k] = 0;
+        }
+        nseg[b] = g + 1;
+        atomicMax(gmax, g + 1);
+    }
+}
+
+int launch_align(const float* sem, int B, int T, int D, float thr, int max_tokens, int* seg, int* start, int* len,
+                 int* nseg, int* gmax, hipStream_t s) {
+    QA_REQUIRE(D % 4 == 0 && T >= 1 && max_tokens >= 1, "align: bad shape");
+    QA_HIP(hipMemsetAsync(gmax, 0, sizeof(int), s));
+    hipLaunchKernelGGL(align_kernel, dim3(B), dim3(256), 2 * T * sizeof(float), s, sem, T, D, thr, max_tokens, seg, start, len,
+                       nseg, gmax);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+// QueryTokenAggregator input (mimi/transformer.py:766-806): frames interleaved with one query token after each group;
+// query = mean of the group's frames + query_embedding; padded groups (g >= nseg[b]) sit at the end and carry the bare
+// query embedding.  out [B, T + G, D].
+__global__ __launch_bounds__(256) void agg_build_kernel(const float* __restrict__ feats, const int* __restrict__ seg,
+                                                        const int* __restrict__ start, const int* __restrict__ len,
+                                                        const int* __restrict__ nseg, const float* __restrict__ qemb,
+                                                        float* __restrict__ out, int T, int G, int D) {
+    const int b = blockIdx.y, p = blockIdx.x;  // p: source element, frames 0..T-1 then queries T..T+G-1
+    const int S = T + G;
+    float* ob = out + (long long)b * S * D;
+    if (p < T) {
+        const int dst = p + seg[(long long)b * T + p];
+        for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4)
+            *reinterpret_cast<float4*>(ob + (long long)dst * D + c) =
+                *reinterpret_cast<const float4*>(feats + ((long long)b * T + p) * D + c);
+        return;
+    }
+    const int g = p - T;
+    if (g >= nseg[b]) {
+        for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4)
+            *reinterpret_cast<float4*>(ob + (long long)(T + g) * D + c) = *reinterpret_cast<const float4*>(qemb + c);
+        return;
+    }
+    const int st = start[(long long)b * T + g], n = len[(long long)b * T + g];
+    const int dst = st + n + g;
+    const float inv = 1.f / (float)n;
+    for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = st; t < st + n; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(feats + ((long long)b * T + t) * D + c);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        const float4 q = *reinterpret_cast<const float4*>(qemb + c);
+        acc.x = acc.x * inv + q.x; acc.y = acc.y * inv + q.y; acc.z = acc.z * inv + q.z; acc.w = acc.w * inv + q.w;
+        *reinterpret_cast<float4*>(ob + (long long)dst * D + c) = acc;
+    }
+}
+int launch_agg_build(const float* feats, const int* seg, const int* start, const int* len, const int* nseg, const float* qemb,
+                     float* out, int B, int T, int G, int D, hipStream_t s) {
+    hipLaunchKernelGGL(agg_build_kernel, dim3(T + G, B), dim3(128), 0, s, feats, seg, start, len, nseg, qemb, out, T, G, D);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+// transformer output at the query positions -> [B, G, D], zero for padded groups (mimi/transformer.py:812-824)
+__global__ __launch_bounds__(128) void agg_gather_kernel(const float* __restrict__ x, const int* __restrict__ start,
+                                                         const int* __restrict__ len, const int* __restrict__ nseg,
+                                                         float* __restrict__ out, int T, int G, int D) {
+    const int b = blockIdx.y, g = blockIdx.x;
+    const bool valid = g < nseg[b];
+    const int src = valid ? start[(long long)b * T + g] + len[(long long)b * T + g] + g : 0;
+    for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) v = *reinterpret_cast<const float4*>(x + ((long long)b * (T + G) + src) * D + c);
+        *reinterpret_cast<float4*>(out + ((long long)b * G + g) * D + c) = v;
+    }
+}
+int launch_agg_gather(const float* x, const int* start, const int* len, const int* nseg, float* out, int B, int T, int G,
+                      int D, hipStream_t s) {
+    hipLaunchKernelGGL(agg_gather_kernel, dim3(G, B), dim3(128), 0, s, x, start, len, nseg, out, T, G, D);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+// library indices [B*G, Q] -> reference layout [B, Q, G] with the group length injected:
+// code' = (len - 1) * K + code (codec_adaptive.py:68-73; len = 0 for padded groups gives code - K, as in the reference)
+__global__ void codes_inject_kernel(const long long* __restrict__ idx, const int* __restrict__ len, long long* __restrict__ dst,
+                                    int B, int T, int G, int Q, int K) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)B * Q * G) return;
+    const int g = (int)(gid % G);
+    const int q = (int)((gid / G) % Q);
+    const int b = (int)(gid / ((long long)G * Q));
+    dst[gid] = (long long)(len[(long long)b * T + g] - 1) * K + idx[((long long)b * G + g) * Q + q];
+}
+int launch_codes_inject(const long long* idx, const int* len, long long* dst, int B, int T, int G, int Q, int K,
+                        hipStream_t s) {
+    const long long total = (long long)B * Q * G;
+    hipLaunchKernelGGL(codes_inject_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, idx, len, dst, B, T, G, Q, K);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+__device__ __forceinline__ long long floordiv_ll(long long a, long long b) {
+    long long q = a / b;
+    if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
+    return q;
+}
+
+// total frames per item from length-injected codes: len = floor(code / K) + 1 of quantizer 0 (codec_adaptive.py:75-80)
+__global__ void adaptive_frames_kernel(const long long* __restrict__ codes, int B, int Q, int G, int K, int* __restrict__ totals,
+                                       int* __restrict__ tmax) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int tot = 0;
+    for (int g = 0; g < G; ++g) {
+        const long long l = floordiv_ll(codes[((long long)b * Q) * G + g], K) + 1;
+        tot += l > 0 ? (int)l : 0;
+    }
+    totals[b] = tot;
+    atomicMax(tmax, tot);
+}
+int launch_adaptive_frames(const long long* codes, int B, int Q, int G, int K, int* totals, int* tmax, hipStream_t s) {
+    QA_HIP(hipMemsetAsync(tmax, 0, sizeof(int), s));
+    hipLaunchKernelGGL(adaptive_frames_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, s, codes, B, Q, G, K, totals, tmax);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+// _deaggregate_features_from_token_lengths on index tensors (modeling_flexicodec_new.py:1007-1041, codec_adaptive.py:184-189):
+// codes [B, Q, G] (length-injected) -> plain indices [B*T, Q], each group repeated len times, rows past an item's total = 0.
+// Lengths come from `len_codes` (the reference ends up using the semantic stream's lengths for both streams).
+__global__ __launch_bounds__(64) void deaggregate_kernel(const long long* __restrict__ codes, const long long* __restrict__ len_codes,
+                                                          long long* __restrict__ out, int Q, int G, int T, int K) {
+    const int b = blockIdx.x;
+    __shared__ int s_start[1024];
+    __shared__ int s_n;
+    if (threadIdx.x == 0) {
+        int pos = 0;
+        for (int g = 0; g < G && g < 1024; ++g) {
+            s_start[g] = pos;
+            const long long l = floordiv_ll(len_codes[((long long)b * Q) * G + g], K) + 1;
+            pos += l > 0 ? (int)l : 0;
+        }
+        s_n = pos;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T * Q; i += blockDim.x) out[((long long)b * T) * Q + i] = 0;
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        const int st = s_start[g];
+        const int en = (g + 1 < G) ? s_start[g + 1] : s_n;
+        for (int q = 0; q < Q; ++q) {
+            const long long c = codes[((long long)b * Q + q) * G + g];
+            long long plain = c % K;
+            if (plain < 0) plain += K;  // python modulo
+            for (int t = st; t < en && t < T; ++t) out[((long long)b * T + t) * Q + q] = plain;
+        }
+    }
+}
+int launch_deaggregate(const long long* codes, const long long* len_codes, long long* out, int B, int Q, int G, int T, int K,
+                       hipStream_t s) {
+    QA_REQUIRE(G <= 1024, "deaggregate: %d groups per item exceed 1024", G);
+    hipLaunchKernelGGL(deaggregate_kernel, dim3(B), dim3(64), 0, s, codes, len_codes, out, Q, G, T, K);
     QA_LAUNCH_CHECK();
     return QA_OK;
 }

@@ -37,6 +37,16 @@ struct ConvNeXtW {
     ConvW pw1, pw2;
 };
 
+struct MimiLayerW {  // StreamingTransformerLayer (mimi/transformer.py:436-594)
+    const float *n1w, *n1b, *n2w, *n2b, *ls1, *ls2;
+    ConvW in_proj, out_proj, lin1, lin2;
+};
+struct MimiW {
+    std::vector<MimiLayerW> layers;
+    int d = 0, heads = 0, ff = 0;
+    const float* rope = nullptr;  // interleaved-pair table [MAX_POS][hd/2][2]
+};
+
 constexpr int MAX_POS = 8192;
 
 }  // namespace
@@ -77,6 +87,10 @@ struct qa_hcodec {
     ConvW head, basis;
     const float* window = nullptr;
     int spec_ld = 0;
+    // H-Codec 1.5
+    MimiW agg_sem, agg_ac, bottleneck;
+    const float *qemb_sem = nullptr, *qemb_ac = nullptr;
+    int* host_sync = nullptr;  // pinned host scalar for the data-dependent group / frame counts
     // workspace
     char* ws = nullptr;
     size_t ws_cap = 0;
@@ -241,6 +255,44 @@ void build_transformer(Builder& b, TransformerW* tw, const std::string& p, int d
     b.raw(&tw->rope, cs);
 }
 
+void build_mimi(Builder& b, MimiW* mw, const std::string& p, int d, int n_layers, int heads, int ff) {
+    mw->d = d;
+    mw->heads = heads;
+    mw->ff = ff;
+    mw->layers.resize(n_layers);
+    for (int l = 0; l < n_layers; ++l) {
+        MimiLayerW& L = mw->layers[l];
+        const std::string lp = p + ".layers." + std::to_string(l);
+        b.vec(&L.n1w, lp + ".norm1.weight", d);
+        b.vec(&L.n1b, lp + ".norm1.bias", d);
+        b.vec(&L.n2w, lp + ".norm2.weight", d);
+        b.vec(&L.n2b, lp + ".norm2.bias", d);
+        b.vec(&L.ls1, lp + ".layer_scale_1.scale", d);
+        b.vec(&L.ls2, lp + ".layer_scale_2.scale", d);
+        L.in_proj.N = 3 * d; L.in_proj.C_in = d;
+        b.vec(&L.in_proj.w, lp + ".self_attn.in_proj_weight", (int64_t)3 * d * d);
+        L.out_proj.N = d; L.out_proj.C_in = d;
+        b.vec(&L.out_proj.w, lp + ".self_attn.out_proj.weight", (int64_t)d * d);
+        L.lin1.N = ff; L.lin1.C_in = d;
+        b.vec(&L.lin1.w, lp + ".linear1.weight", (int64_t)ff * d);
+        L.lin2.N = d; L.lin2.C_in = ff;
+        b.vec(&L.lin2.w, lp + ".linear2.weight", (int64_t)ff * d);
+    }
+    // apply_rope (mimi/module/rope.py:38-56): freqs = exp(i * (-ln(P) * 2 / D)), angle = freqs * t, all in fp32
+    const int hd = d / heads, half = hd / 2;
+    std::vector<float> cs((size_t)MAX_POS * half * 2);
+    const float coef = (float)(-std::log(10000.0) * 2.0 / hd);
+    for (int i = 0; i < half; ++i) {
+        const float fr = std::exp((float)i * coef);
+        for (int t = 0; t < MAX_POS; ++t) {
+            const float ang = fr * (float)t;
+            cs[((size_t)t * half + i) * 2] = (float)std::cos((double)ang);
+            cs[((size_t)t * half + i) * 2 + 1] = (float)std::sin((double)ang);
+        }
+    }
+    b.raw(&mw->rope, cs);
+}
+
 // ---------------------------------------------------------------- graph helpers
 
 int conv_op(Ctx& c, const float* x, int64_t ldx, int B, int T_in, const ConvW& w, float* y, int64_t ldy, int T_out,
@@ -320,6 +372,33 @@ int transformer_op(Ctx& c, const TransformerW& tw, float* x, int B, int N, const
     return QA_OK;
 }
 
+// StreamingTransformer.forward, non-causal / non-streaming (mimi/transformer.py:377-425,553-594,674-698), in place on x
+int mimi_op(Ctx& c, const MimiW& mw, float* x, int B, int N) {
+    const int d = mw.d, H = mw.heads, hd = d / H;
+    const int64_t rows = (int64_t)B * N;
+    QA_REQUIRE(N <= MAX_POS, "mimi transformer: sequence of %d tokens exceeds %d", N, MAX_POS);
+    const size_t mark = c.arena.mark();
+    float* hn = c.arena.alloc<float>(rows * d);
+    float* qkv = c.arena.alloc<float>(rows * 3 * d);
+    float* att = c.arena.alloc<float>(rows * d);
+    float* u = c.arena.alloc<float>(rows * mw.ff);
+    if (!c.dry) {
+        for (const MimiLayerW& L : mw.layers) {
+            QA_TRY(launch_layernorm(x, L.n1w, L.n1b, hn, rows, d, 1e-5f, c.stream));
+            QA_TRY(linear_op(c, hn, rows, L.in_proj, qkv));
+            QA_TRY(launch_rope(qkv, mw.rope, B, N, H, hd, 3 * d, 0, c.stream, 1));
+            QA_TRY(launch_attention(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, B, N, N, (long long)N * 3 * d, H, hd,
+                                    1.0f / std::sqrt((float)hd), 0, c.stream));
+            QA_TRY(linear_op(c, att, rows, L.out_proj, x, ACT_NONE, x, nullptr, L.ls1));
+            QA_TRY(launch_layernorm(x, L.n2w, L.n2b, hn, rows, d, 1e-5f, c.stream));
+            QA_TRY(linear_op(c, hn, rows, L.lin1, u, ACT_GELU));
+            QA_TRY(linear_op(c, u, rows, L.lin2, x, ACT_NONE, x, nullptr, L.ls2));
+        }
+    }
+    c.arena.release(mark);
+    return QA_OK;
+}
+
 int groupnorm_op(Ctx& c, const float* x, const float* w, const float* b, float* y, int B, int T, int C, int G,
                  int swish) {
     const size_t mark = c.arena.mark();
@@ -344,8 +423,9 @@ int dec_resblock_op(Ctx& c, const DecResW& w, float* x, int B, int T, int C, int
 
 // ---------------------------------------------------------------- encode / decode graphs
 
-int encode_graph(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const float* feat, int64_t fsb, int64_t fsc,
-                 int64_t fst, int n_feat, long long* ac_out, long long* sc_out) {
+// SEANet encoder + semantic encoder: wav, feat -> emb, sem  [B, N25, code_dim] each (codec.py:169-170)
+int encode_front(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const float* feat, int64_t fsb, int64_t fsc,
+                 int64_t fst, int n_feat, float** emb_out, float** sem_out, int* n25_out) {
     const qa_hcodec_spec& sp = h->spec;
     // ---- SEANet encoder
     int C = sp.n_filters, L = T;
@@ -422,7 +502,18 @@ int encode_graph(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const flo
     float* sem = c.arena.alloc<float>((size_t)B * Ls * sp.code_dim);
     QA_TRY(conv_same(c, s, B, Ls, h->sem_out, sem));
     c.tap("enc.sem", sem, (int64_t)B * Ls * sp.code_dim);
+    *emb_out = emb;
+    *sem_out = sem;
+    *n25_out = N25;
+    return QA_OK;
+}
 
+int encode_graph(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const float* feat, int64_t fsb, int64_t fsc,
+                 int64_t fst, int n_feat, long long* ac_out, long long* sc_out) {
+    const qa_hcodec_spec& sp = h->spec;
+    float *emb = nullptr, *sem = nullptr;
+    int N25 = 0;
+    QA_TRY(encode_front(h, c, wav, B, T, feat, fsb, fsc, fst, n_feat, &emb, &sem, &N25));
     // ---- RVQ (both streams)
     const int Q = sp.num_quantizers;
     long long* ia = c.arena.alloc<long long>((size_t)B * N25 * Q);
@@ -438,6 +529,8 @@ int encode_graph(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const flo
     return QA_OK;
 }
 
+int decode_tail(qa_hcodec* h, Ctx& c, const float* cat, int B, int N, float* wav_out);
+
 int decode_graph(qa_hcodec* h, Ctx& c, const long long* ac, const long long* scodes, int B, int N, float* wav_out) {
     const qa_hcodec_spec& sp = h->spec;
     const int Q = sp.num_quantizers, D = sp.code_dim, d = sp.dec_dim;
@@ -451,6 +544,14 @@ int decode_graph(qa_hcodec* h, Ctx& c, const long long* ac, const long long* sco
         QA_TRY(launch_rvq_lookup(ia, rows25, h->cb_a, Q, sp.codebook_size, D, cat, 2 * D, c.stream));
         QA_TRY(launch_rvq_lookup(is, rows25, h->cb_s, Q, sp.codebook_size, D, cat + D, 2 * D, c.stream));
     }
+    return decode_tail(h, c, cat, B, N, wav_out);
+}
+
+// CodecDecoder.forward (codec_decoder.py:58-67) from the concatenated [acoustic | semantic] embeddings [B, N, 2*code_dim]
+int decode_tail(qa_hcodec* h, Ctx& c, const float* cat, int B, int N, float* wav_out) {
+    const qa_hcodec_spec& sp = h->spec;
+    const int d = sp.dec_dim;
+    const int64_t rows25 = (int64_t)B * N;
     // sub-pixel upsampler: 1x1 conv to 2*d channels; in channel-last layout the pixel shuffle (vq/conv.py:86-88) is a
     // pure reinterpretation [B, N, 2, d] -> [B, 2N, d]
     float* up = c.arena.alloc<float>(rows25 * 2 * d);
@@ -491,6 +592,80 @@ int decode_graph(qa_hcodec* h, Ctx& c, const long long* ac, const long long* sco
     QA_TRY(linear_op(c, S, rows, h->basis, frames));
     if (!c.dry) QA_TRY(launch_istft_ola(frames, h->window, wav_out, B, N50, sp.n_fft, sp.hop, c.stream));
     return QA_OK;
+}
+
+// ---- H-Codec 1.5 (codec_adaptive.py:150-199)
+
+int read_scalar(Ctx& c, qa_hcodec* h, const int* dev, int* out) {
+    QA_HIP(hipMemcpyAsync(h->host_sync, dev, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    QA_HIP(hipStreamSynchronize(c.stream));  // data-dependent shape: the reference syncs here too (modeling_flexicodec_new.py:910)
+    *out = *h->host_sync;
+    return QA_OK;
+}
+
+int encode_adaptive_graph(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const float* feat, int64_t fsb, int64_t fsc,
+                          int64_t fst, int n_feat, long long* ac_out, long long* sc_out, int* G_out) {
+    const qa_hcodec_spec& sp = h->spec;
+    const int D = sp.code_dim, Q = sp.num_quantizers;
+    float *emb = nullptr, *sem = nullptr;
+    int N = 0;
+    QA_TRY(encode_front(h, c, wav, B, T, feat, fsb, fsc, fst, n_feat, &emb, &sem, &N));
+    int* seg = c.arena.alloc<int>((size_t)B * N);
+    int* start = c.arena.alloc<int>((size_t)B * N);
+    int* len = c.arena.alloc<int>((size_t)B * N);
+    int* nseg = c.arena.alloc<int>(B);
+    int* gmax = c.arena.alloc<int>(1);
+    int G = N;  // planning pass: worst case, every frame its own group
+    if (!c.dry) {
+        QA_TRY(launch_align(sem, B, N, D, sp.threshold, sp.max_tokens_per_group, seg, start, len, nseg, gmax, c.stream));
+        QA_TRY(read_scalar(c, h, gmax, &G));
+        QA_REQUIRE(G >= 1 && G <= N, "encode: alignment produced %d groups for %d frames", G, N);
+    }
+    *G_out = G;
+    const int S = N + G;
+    float* inter = c.arena.alloc<float>((size_t)B * S * D);
+    float* agg_a = c.arena.alloc<float>((size_t)B * G * D);
+    float* agg_s = c.arena.alloc<float>((size_t)B * G * D);
+    // semantic_aggregator(sem), acoustic_aggregator(emb): both use the alignment of the semantic stream
+    if (!c.dry) QA_TRY(launch_agg_build(sem, seg, start, len, nseg, h->qemb_sem, inter, B, N, G, D, c.stream));
+    QA_TRY(mimi_op(c, h->agg_sem, inter, B, S));
+    if (!c.dry) {
+        QA_TRY(launch_agg_gather(inter, start, len, nseg, agg_s, B, N, G, D, c.stream));
+        QA_TRY(launch_agg_build(emb, seg, start, len, nseg, h->qemb_ac, inter, B, N, G, D, c.stream));
+    }
+    QA_TRY(mimi_op(c, h->agg_ac, inter, B, S));
+    if (!c.dry) QA_TRY(launch_agg_gather(inter, start, len, nseg, agg_a, B, N, G, D, c.stream));
+    c.tap("enc.emb_agg", agg_a, (int64_t)B * G * D);
+    c.tap("enc.sem_agg", agg_s, (int64_t)B * G * D);
+    long long* ia = c.arena.alloc<long long>((size_t)B * G * Q);
+    long long* is = c.arena.alloc<long long>((size_t)B * G * Q);
+    if (!c.dry) {
+        QA_TRY(launch_rvq_search(agg_a, (long long)B * G, h->cb_a, h->e2_a, Q, sp.codebook_size, D, ia, nullptr, 0, c.stream));
+        QA_TRY(launch_rvq_search(agg_s, (long long)B * G, h->cb_s, h->e2_s, Q, sp.codebook_size, D, is, nullptr, 0, c.stream));
+        QA_TRY(launch_codes_inject(ia, len, ac_out, B, N, G, Q, sp.codebook_size, c.stream));
+        QA_TRY(launch_codes_inject(is, len, sc_out, B, N, G, Q, sp.codebook_size, c.stream));
+    }
+    return QA_OK;
+}
+
+int decode_adaptive_graph(qa_hcodec* h, Ctx& c, const long long* ac, const long long* scodes, int B, int G, int N,
+                          float* wav_out) {
+    const qa_hcodec_spec& sp = h->spec;
+    const int Q = sp.num_quantizers, D = sp.code_dim;
+    const int64_t rows = (int64_t)B * N;
+    long long* ia = c.arena.alloc<long long>(rows * Q);
+    long long* is = c.arena.alloc<long long>(rows * Q);
+    float* cat = c.arena.alloc<float>(rows * 2 * D);
+    if (!c.dry) {
+        // token lengths: the reference keeps the ones extracted from the SEMANTIC codes for both streams (codec_adaptive.py:185-186)
+        QA_TRY(launch_deaggregate(ac, scodes, ia, B, Q, G, N, sp.codebook_size, c.stream));
+        QA_TRY(launch_deaggregate(scodes, scodes, is, B, Q, G, N, sp.codebook_size, c.stream));
+        QA_TRY(launch_rvq_lookup(ia, rows, h->cb_a, Q, sp.codebook_size, D, cat, 2 * D, c.stream));
+        QA_TRY(launch_rvq_lookup(is, rows, h->cb_s, Q, sp.codebook_size, D, cat + D, 2 * D, c.stream));
+    }
+    QA_TRY(mimi_op(c, h->bottleneck, cat, B, N));
+    c.tap("dec.bottleneck", cat, rows * 2 * D);
+    return decode_tail(h, c, cat, B, N, wav_out);
 }
 
 int ensure_workspace(qa_hcodec* h, size_t bytes) {
@@ -651,7 +826,19 @@ int build(qa_hcodec* h, const HostTable& tab) {
         b.raw(&h->basis.w, basis);
         b.raw(&h->window, win);
     }
+    if (sp.adaptive) {
+        QA_REQUIRE(sp.agg_heads > 0 && sp.bt_heads > 0 && sp.code_dim % sp.agg_heads == 0 && (2 * sp.code_dim) % sp.bt_heads == 0,
+                   "spec: bad head counts for the adaptive stacks");
+        QA_REQUIRE(sp.agg_ff % 32 == 0 && sp.bt_ff % 32 == 0 && sp.max_tokens_per_group >= 1, "spec: bad adaptive widths");
+        build_mimi(b, &h->agg_sem, "semantic_aggregator.transformer.transformer", sp.code_dim, sp.agg_layers, sp.agg_heads, sp.agg_ff);
+        build_mimi(b, &h->agg_ac, "acoustic_aggregator.transformer.transformer", sp.code_dim, sp.agg_layers, sp.agg_heads, sp.agg_ff);
+        build_mimi(b, &h->bottleneck, "bottleneck_transformer.transformer", 2 * sp.code_dim, sp.bt_layers, sp.bt_heads, sp.bt_ff);
+        b.vec(&h->qemb_sem, "semantic_aggregator.query_embedding", sp.code_dim);
+        b.vec(&h->qemb_ac, "acoustic_aggregator.query_embedding", sp.code_dim);
+        QA_REQUIRE(2 * sp.code_dim == sp.dec_dim || true, "unused");
+    }
     if (!b.f.ok) return b.f.status;
+    QA_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->host_sync), sizeof(int) * 4));
     QA_TRY(h->store.upload());
     b.resolve();
     // |e|^2 tables
@@ -698,6 +885,7 @@ void qa_hcodec_destroy(qa_hcodec* h) {
     h->store.release();
     if (h->e2_dev) (void)hipFree(h->e2_dev);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->host_sync) (void)hipHostFree(h->host_sync);
     delete h;
 }
 
@@ -712,6 +900,7 @@ int qa_hcodec_encode(qa_hcodec* h, const float* wav, int64_t B, int64_t T, const
     QA_REQUIRE(B > 0 && T > 0 && T % hop == 0, "qa_hcodec_encode: wav is [%lld, %lld]; T must be a positive multiple of %d "
                "(HCodecTokenizer.pad_wav)", (long long)B, (long long)T, hop);
     QA_REQUIRE(B * T < (1LL << 31), "qa_hcodec_encode: batch of %lld x %lld samples is too large", (long long)B, (long long)T);
+    QA_REQUIRE(!h->spec.adaptive, "qa_hcodec_encode: this handle is an H-Codec 1.5 model, use qa_hcodec_encode_adaptive");
     QA_HIP(hipSetDevice(h->device));
     Ctx& c = h->ctx;
     c.stream = static_cast<hipStream_t>(stream);
@@ -732,6 +921,7 @@ int qa_hcodec_decode(qa_hcodec* h, const int64_t* ac, const int64_t* sc, int64_t
     }
     QA_REQUIRE(B > 0 && N > 0, "qa_hcodec_decode: codes are [%lld, Q, %lld]", (long long)B, (long long)N);
     QA_REQUIRE(B * N * 2 * (int64_t)h->spec.hop < (1LL << 31), "qa_hcodec_decode: output too large");
+    QA_REQUIRE(!h->spec.adaptive, "qa_hcodec_decode: this handle is an H-Codec 1.5 model, use qa_hcodec_decode_adaptive");
     QA_HIP(hipSetDevice(h->device));
     Ctx& c = h->ctx;
     c.stream = static_cast<hipStream_t>(stream);
@@ -743,6 +933,75 @@ int qa_hcodec_decode(qa_hcodec* h, const int64_t* ac, const int64_t* sc, int64_t
     c.taps.clear();
     c.arena.begin(h->ws, h->ws_cap);
     return decode_graph(h, c, (const long long*)ac, (const long long*)sc, (int)B, (int)N, wav_out);
+}
+
+int qa_hcodec_encode_adaptive(qa_hcodec* h, const float* wav, int64_t B, int64_t T, const float* feat, int64_t fsb, int64_t fsc,
+                              int64_t fst, int64_t n_feat, int64_t* ac, int64_t* sc, int64_t* n_groups, void* stream) {
+    if (!h || !wav || !feat || !ac || !sc || !n_groups) {
+        set_error("qa_hcodec_encode_adaptive: null argument");
+        return QA_ERR_INVALID;
+    }
+    QA_REQUIRE(h->spec.adaptive, "qa_hcodec_encode_adaptive: this handle is not an H-Codec 1.5 model");
+    int hop = 2;
+    for (int i = 0; i < h->spec.n_ratios; ++i) hop *= h->spec.ratios[i];
+    QA_REQUIRE(B > 0 && T > 0 && T % hop == 0, "qa_hcodec_encode_adaptive: wav is [%lld, %lld]; T must be a positive multiple of %d",
+               (long long)B, (long long)T, hop);
+    QA_REQUIRE(B * T < (1LL << 31), "qa_hcodec_encode_adaptive: batch too large");
+    QA_HIP(hipSetDevice(h->device));
+    Ctx& c = h->ctx;
+    c.stream = static_cast<hipStream_t>(stream);
+    c.dry = true;
+    c.arena.begin(nullptr, 0);
+    int G = 0;
+    QA_TRY(encode_adaptive_graph(h, c, wav, (int)B, (int)T, feat, fsb, fsc, fst, (int)n_feat, (long long*)ac, (long long*)sc, &G));
+    QA_TRY(ensure_workspace(h, c.arena.peak()));
+    c.dry = false;
+    c.taps.clear();
+    c.arena.begin(h->ws, h->ws_cap);
+    QA_TRY(encode_adaptive_graph(h, c, wav, (int)B, (int)T, feat, fsb, fsc, fst, (int)n_feat, (long long*)ac, (long long*)sc, &G));
+    *n_groups = G;
+    return QA_OK;
+}
+
+int qa_hcodec_adaptive_frames(qa_hcodec* h, const int64_t* semantic_codes, int64_t B, int64_t G, int64_t* frames, void* stream) {
+    if (!h || !semantic_codes || !frames) {
+        set_error("qa_hcodec_adaptive_frames: null argument");
+        return QA_ERR_INVALID;
+    }
+    QA_REQUIRE(h->spec.adaptive && B > 0 && G > 0, "qa_hcodec_adaptive_frames: bad argument");
+    QA_HIP(hipSetDevice(h->device));
+    QA_TRY(ensure_workspace(h, (size_t)(B + 64) * sizeof(int)));
+    Ctx& c = h->ctx;
+    c.stream = static_cast<hipStream_t>(stream);
+    int* totals = reinterpret_cast<int*>(h->ws);
+    int* tmax = totals + B;
+    QA_TRY(launch_adaptive_frames((const long long*)semantic_codes, (int)B, h->spec.num_quantizers, (int)G, h->spec.codebook_size,
+                                  totals, tmax, c.stream));
+    int n = 0;
+    QA_TRY(read_scalar(c, h, tmax, &n));
+    *frames = n;
+    return QA_OK;
+}
+
+int qa_hcodec_decode_adaptive(qa_hcodec* h, const int64_t* ac, const int64_t* sc, int64_t B, int64_t G, int64_t frames,
+                              float* wav_out, void* stream) {
+    if (!h || !ac || !sc || !wav_out) {
+        set_error("qa_hcodec_decode_adaptive: null argument");
+        return QA_ERR_INVALID;
+    }
+    QA_REQUIRE(h->spec.adaptive, "qa_hcodec_decode_adaptive: this handle is not an H-Codec 1.5 model");
+    QA_REQUIRE(B > 0 && G > 0 && frames > 0 && B * frames * 2 * (int64_t)h->spec.hop < (1LL << 31), "qa_hcodec_decode_adaptive: bad shape");
+    QA_HIP(hipSetDevice(h->device));
+    Ctx& c = h->ctx;
+    c.stream = static_cast<hipStream_t>(stream);
+    c.dry = true;
+    c.arena.begin(nullptr, 0);
+    QA_TRY(decode_adaptive_graph(h, c, (const long long*)ac, (const long long*)sc, (int)B, (int)G, (int)frames, wav_out));
+    QA_TRY(ensure_workspace(h, c.arena.peak()));
+    c.dry = false;
+    c.taps.clear();
+    c.arena.begin(h->ws, h->ws_cap);
+    return decode_adaptive_graph(h, c, (const long long*)ac, (const long long*)sc, (int)B, (int)G, (int)frames, wav_out);
 }
 
 int qa_hcodec_enable_taps(qa_hcodec* h, int on) {

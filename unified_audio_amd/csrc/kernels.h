@@ -17,7 +17,19 @@ int launch_dwconv(const float* x, const float* w_kc, const float* bias, const fl
 size_t groupnorm_scratch_bytes(int B, int T, int G);
 int launch_groupnorm(const float* x, const float* w, const float* bias, float* y, double* scratch, int B, int T, int C,
                      int G, float eps, int swish, hipStream_t s);
-int launch_rope(float* qkv, const float* cos_sin, int B, int N, int H, int hd, long long ld, int pos0, hipStream_t s);
+int launch_rope(float* qkv, const float* cos_sin, int B, int N, int H, int hd, long long ld, int pos0, hipStream_t s,
+                int interleaved = 0);
+int launch_align(const float* sem, int B, int T, int D, float thr, int max_tokens, int* seg, int* start, int* len,
+                 int* nseg, int* gmax, hipStream_t s);
+int launch_agg_build(const float* feats, const int* seg, const int* start, const int* len, const int* nseg, const float* qemb,
+                     float* out, int B, int T, int G, int D, hipStream_t s);
+int launch_agg_gather(const float* x, const int* start, const int* len, const int* nseg, float* out, int B, int T, int G,
+                      int D, hipStream_t s);
+int launch_codes_inject(const long long* idx, const int* len, long long* dst, int B, int T, int G, int Q, int K,
+                        hipStream_t s);
+int launch_adaptive_frames(const long long* codes, int B, int Q, int G, int K, int* totals, int* tmax, hipStream_t s);
+int launch_deaggregate(const long long* codes, const long long* len_codes, long long* out, int B, int Q, int G, int T, int K,
+                       hipStream_t s);
 int launch_to_channel_last(const float* x, long long sb, long long sc, long long st, float* y, int B, int C, int T,
                            hipStream_t s);
 int launch_codes_to_bqn(const long long* src, long long* dst, int B, int N, int Q, hipStream_t s);

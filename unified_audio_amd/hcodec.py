@@ -40,6 +40,16 @@ class HCodecSpec:
     n_fft: int = 1280
     hop: int = 320
     gn_groups: int = 32
+    # H-Codec 1.5 (QuarkAudio-HCodec/HCodec-1.5/conf/config_adaptive_v3.yaml:65-111); adaptive=False is H-Codec 1.0
+    adaptive: bool = False
+    agg_layers: int = 32
+    agg_heads: int = 8
+    agg_ff: int = 2048
+    bt_layers: int = 32
+    bt_heads: int = 8
+    bt_ff: int = 2048
+    threshold: float = 0.6
+    max_tokens_per_group: int = 8
 
     @property
     def enc_hop(self) -> int:
@@ -57,10 +67,15 @@ class HCodecSpec:
         s.code_dim, s.codebook_size, s.num_quantizers = self.code_dim, self.codebook_size, self.num_quantizers
         s.dec_dim, s.dec_inter, s.dec_heads, s.dec_layers = self.dec_dim, self.dec_inter, self.dec_heads, self.dec_layers
         s.convnext_layers, s.n_fft, s.hop, s.gn_groups = self.convnext_layers, self.n_fft, self.hop, self.gn_groups
+        s.adaptive, s.agg_layers, s.agg_heads, s.agg_ff = int(self.adaptive), self.agg_layers, self.agg_heads, self.agg_ff
+        s.bt_layers, s.bt_heads, s.bt_ff = self.bt_layers, self.bt_heads, self.bt_ff
+        s.max_tokens_per_group, s.threshold = self.max_tokens_per_group, self.threshold
         return s
 
 
 SPEC_10 = HCodecSpec()
+# H-Codec 1.5: SEANet stride order 8,5,4,2 (config lists [2,4,5,8], seanet.py:114 reverses it), XLSR features, decoder 1024
+SPEC_15 = HCodecSpec(ratios=(8, 5, 4, 2), sem_in=1024, sem_ch=1024, dec_dim=1024, dec_inter=2304, adaptive=True)
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -120,7 +135,7 @@ class Codec:
 
     # -- hot path ------------------------------------------------------------------------------------
     @torch.no_grad()
-    def encode(self, x: torch.Tensor, feat: torch.Tensor):
+    def encode(self, x: torch.Tensor, feat: torch.Tensor, use_mask=False, domain_split=None, threshold: float = 0.0):
         """codec.py:166-175.  x [B,1,T] fp32, feat [B, sem_in, N50] fp32 (any strides) -> two int64 [B, nq, N25]."""
         self._require_loaded()
         if x.dim() != 3 or x.shape[1] != 1:
@@ -135,14 +150,28 @@ class Codec:
         ac = torch.empty((B, q, n25), dtype=torch.int64, device=self.device)
         sc = torch.empty((B, q, n25), dtype=torch.int64, device=self.device)
         sb, sch, st = feat.stride()
+        if self.spec.adaptive:
+            # codec_adaptive.py:150-178: dict of length-injected codes [B, nq, G]; G is data dependent (host sync, as in the
+            # reference: modeling_flexicodec_new.py:910)
+            if threshold != 0.0:
+                raise _lib.QuarkAudioError(-4, "per-call threshold is fixed at load time: set HCodecSpec.threshold")
+            g = C.c_int64(0)
+            _lib.check(self._lib.qa_hcodec_encode_adaptive(self._handle, x.data_ptr(), B, T, feat.data_ptr(), sb, sch, st,
+                                                           feat.shape[2], ac.data_ptr(), sc.data_ptr(), C.byref(g),
+                                                           _stream_ptr(self.device)))
+            G = int(g.value)
+            return {"acoustic_codes": ac.view(-1)[: B * q * G].view(B, q, G), "semantic_codes": sc.view(-1)[: B * q * G].view(B, q, G)}
         _lib.check(self._lib.qa_hcodec_encode(self._handle, x.data_ptr(), B, T, feat.data_ptr(), sb, sch, st,
                                               feat.shape[2], ac.data_ptr(), sc.data_ptr(), _stream_ptr(self.device)))
         return ac, sc
 
     @torch.no_grad()
-    def decode(self, acoustic_codes: torch.Tensor, semantic_codes: torch.Tensor):
-        """codec.py:178-187.  int64 [B, nq, N25] x2 -> wav [B, N25 * 2 * hop]."""
+    def decode(self, acoustic_codes: torch.Tensor, semantic_codes: torch.Tensor, token_lengths: Optional[torch.Tensor] = None):
+        """codec.py:178-187.  int64 [B, nq, N25] x2 -> wav [B, N25 * 2 * hop].  H-Codec 1.5 (codec_adaptive.py:181-199):
+        length-injected codes [B, nq, G] (or plain codes + token_lengths [B, G])."""
         self._require_loaded()
+        if self.spec.adaptive:
+            return self._decode_adaptive(acoustic_codes, semantic_codes, token_lengths)
         q = self.spec.num_quantizers
         if acoustic_codes.shape != semantic_codes.shape or acoustic_codes.dim() != 3 or acoustic_codes.shape[1] != q:
             raise _lib.QuarkAudioError(-1, f"decode expects two [B,{q},N] code tensors, got "
@@ -163,6 +192,24 @@ class Codec:
         self._require_loaded()
         _lib.check(self._lib.qa_hcodec_enable_taps(self._handle, int(on)))
         return self
+
+    def _decode_adaptive(self, acoustic_codes, semantic_codes, token_lengths):
+        q, K = self.spec.num_quantizers, self.spec.codebook_size
+        if acoustic_codes.shape != semantic_codes.shape or acoustic_codes.dim() != 3 or acoustic_codes.shape[1] != q:
+            raise _lib.QuarkAudioError(-1, f"decode expects two [B,{q},G] code tensors")
+        ac = acoustic_codes.to(device=self.device, dtype=torch.int64).contiguous()
+        sc = semantic_codes.to(device=self.device, dtype=torch.int64).contiguous()
+        if token_lengths is not None:  # plain codes + explicit lengths: inject, exactly what encode emits (codec_adaptive.py:68-73)
+            tl = token_lengths.to(device=self.device, dtype=torch.int64).unsqueeze(1)
+            ac, sc = (tl - 1) * K + ac, (tl - 1) * K + sc
+        B, _, G = ac.shape
+        frames = C.c_int64(0)
+        _lib.check(self._lib.qa_hcodec_adaptive_frames(self._handle, sc.data_ptr(), B, G, C.byref(frames), _stream_ptr(self.device)))
+        n = int(frames.value)
+        wav = torch.empty((B, n * 2 * self.spec.hop), dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.qa_hcodec_decode_adaptive(self._handle, ac.data_ptr(), sc.data_ptr(), B, G, n, wav.data_ptr(),
+                                                       _stream_ptr(self.device)))
+        return wav
 
     def tap(self, name: str) -> torch.Tensor:
         """Test hook: flat fp32 copy of a named intermediate of the last encode/decode (channel-last layout)."""
@@ -218,5 +265,8 @@ class HCodecTokenizer:
         return self.model.encode(wav.unsqueeze(1), feats)
 
     @torch.no_grad()
-    def detokenize(self, acoustic_codes: torch.Tensor, semantic_codes: torch.Tensor):
+    def detokenize(self, acoustic_codes: torch.Tensor, semantic_codes: torch.Tensor, token_lengths=None):
+        """1.0: audio_tokenizer.py:64-66; 1.5: HCodec-1.5/audio_tokenizer.py:83-86 (call as detokenize(**codes))."""
+        if self.model.spec.adaptive:
+            return self.model.decode(acoustic_codes, semantic_codes, token_lengths)
         return self.model.decode(acoustic_codes, semantic_codes)
