@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU (BASELINE metric: b=32)")
     ap.add_argument("--seconds", type=float, default=10.0, help="clip length (BASELINE configs[1]: 10 s)")
+    ap.add_argument("--model", choices=["1.5", "1.0"], default="1.5", help="H-Codec version (BASELINE configs[1] is 1.5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=2, help="clips in the bounded CPU-baseline sample")
     ap.add_argument("--no-lm", action="store_true", help="skip the secondary UniSE AR-LM tokens/sec measurement")
@@ -42,7 +43,7 @@ def parse():
     return ap.parse_args()
 
 
-def _cpu_baseline_worker(clips, seconds, reps, threads):
+def _cpu_baseline_worker(clips, seconds, reps, threads, model="1.5"):
     """Runs in a child process (so a stuck host BLAS thread pool can never hang the bench): prints one JSON line."""
     import faulthandler
 
@@ -51,27 +52,33 @@ def _cpu_baseline_worker(clips, seconds, reps, threads):
     from oracle import hcodec_ref as R
     from oracle import synth
 
-    spec = R.SPEC_10
+    from oracle import hcodec15_ref as R15
+
+    spec = R.SPEC_15 if model == "1.5" else R.SPEC_10
     sd = synth.hcodec10_state_dict(1234, spec)
     T = int(round(seconds * SR / spec.enc_hop)) * spec.enc_hop
     wav = synth.synth_wav(101, clips, T)
-    feat = synth.synth_feat(102, clips, T // 320)
+    feat = synth.synth_feat(102, clips, T // 320, spec.sem_in)
     best = float("inf")
     with torch.no_grad():
         for i in range(reps + 1):  # first pass = warm-up
             t0 = time.perf_counter()
-            ac, sc = R.encode(sd, wav.unsqueeze(1), feat, spec)
-            R.decode(sd, ac, sc, spec)
+            if spec.adaptive:
+                codes = R15.encode(sd, wav.unsqueeze(1), feat, spec)
+                R15.decode(sd, codes["acoustic_codes"], codes["semantic_codes"], spec)
+            else:
+                ac, sc = R.encode(sd, wav.unsqueeze(1), feat, spec)
+                R.decode(sd, ac, sc, spec)
             dt = time.perf_counter() - t0
             if i:
                 best = min(best, dt)
     print(json.dumps({"value": clips * T / SR / best, "unit": "audio-seconds/sec", "cores": torch.get_num_threads(),
                       "kind": "port",
-                      "sample": f"oracle/hcodec_ref.py (PyTorch-CPU restatement of the reference op sequence) encode+decode of "
+                      "sample": f"oracle/hcodec{'15' if spec.adaptive else ''}_ref.py (PyTorch-CPU restatement of the reference op sequence, H-Codec {model}) encode+decode of "
                                 f"{clips} x {T / SR:.1f} s clips, best of {reps} after 1 warm-up"}))
 
 
-def cpu_baseline(clips, seconds, reps=2):
+def cpu_baseline(clips, seconds, reps=2, model="1.5"):
     """The oracle timed on this host's cores: kind = "port".  Bounded sample, hard timeout."""
     import subprocess
 
@@ -79,7 +86,7 @@ def cpu_baseline(clips, seconds, reps=2):
     threads = max(1, min(cores, 32))  # the op sizes of a 2-clip sample stop scaling well before 32 threads
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", f"{clips},{seconds},{reps},{threads}"],
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", f"{clips},{seconds},{reps},{threads},{model}"],
                            capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
         return json.loads(r.stdout.strip().splitlines()[-1])
     except Exception as e:  # noqa: BLE001 - a failed baseline must not lose the GPU measurement
@@ -125,8 +132,8 @@ def log(msg):
 def main():
     args = parse()
     if args.cpu_baseline_worker:
-        c, sec, reps, thr = args.cpu_baseline_worker.split(",")
-        return _cpu_baseline_worker(int(c), float(sec), int(reps), int(thr))
+        c, sec, reps, thr, mdl = args.cpu_baseline_worker.split(",")
+        return _cpu_baseline_worker(int(c), float(sec), int(reps), int(thr), mdl)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,17 +159,25 @@ def main():
     from oracle import synth
 
     lib = qa.load_library()
-    spec = R.SPEC_10
+    spec = R.SPEC_15 if args.model == "1.5" else R.SPEC_10
+    log(f"generating seeded H-Codec {args.model} weights ...")
     sd = synth.hcodec10_state_dict(1234, spec)
-    codec = qa.Codec(None, None, None, device=dev).load_state_dict(sd)
+    kw = {f: getattr(spec, f) for f in spec.__dataclass_fields__}
+    codec = qa.Codec(None, None, None, spec=qa.HCodecSpec(**kw), device=dev).load_state_dict(sd)
+    n_params = sum(v.numel() for v in sd.values())
 
     B = args.batch
     T = int(round(args.seconds * SR / spec.enc_hop)) * spec.enc_hop
     # each rank draws its own shard of clips (weak scaling: B clips per GPU, no data-path collective)
     wav = synth.synth_wav(7 + rank, B, T).to(dev)
-    feats = synth.synth_feat(9 + rank, B, T // 320).transpose(1, 2).contiguous().to(dev)  # [B, N50, 768] as the SSL model emits
+    feats = synth.synth_feat(9 + rank, B, T // 320, spec.sem_in).transpose(1, 2).contiguous().to(dev)  # [B, N50, C] as the SSL model emits
+    groups = [0]
 
     def step():
+        if spec.adaptive:
+            codes = codec.encode(wav.unsqueeze(1), feats.transpose(1, 2))
+            groups[0] = codes["acoustic_codes"].shape[-1]
+            return codec.decode(**codes)
         ac, sc = codec.encode(wav.unsqueeze(1), feats.transpose(1, 2))
         return codec.decode(ac, sc)
 
@@ -220,9 +235,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (seeded band-limited noise + tones; seeded random weights of the H-Codec 1.0 architecture)",
-            "config": {"workload": f"H-Codec 1.0 Codec.encode+Codec.decode, {B} clips x {T / SR:.0f} s @16 kHz per GPU, "
-                                   "SSL features precomputed, inputs resident in HBM",
+            "data": f"synthetic (seeded band-limited noise + tones; seeded random weights of the H-Codec {args.model} architecture)",
+            "config": {"workload": f"H-Codec {args.model} Codec.encode+Codec.decode ({n_params / 1e6:.0f} M parameters"
+                                   + (f", 32-layer aggregators + bottleneck, threshold {spec.threshold}, {groups[0]} groups per clip" if spec.adaptive else "")
+                                   + f"), {B} clips x {T / SR:.0f} s @16 kHz per GPU, SSL features precomputed, inputs resident in HBM",
                        "clips_per_gpu": B, "clip_seconds": T / SR, "parallelism": f"dp{world} (independent clips, no collective)"},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": None,
@@ -233,7 +249,7 @@ def main():
             line["unise_lm"] = lm_line
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline ...")
-            line["cpu_baseline"] = cpu_baseline(args.cpu_clips, args.seconds)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_clips, args.seconds, model=args.model)
             if line["cpu_baseline"]["value"]:
                 line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line))

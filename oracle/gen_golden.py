@@ -47,10 +47,40 @@ def run_case(name, seed, head_bias, batch, samples):
     print(name, tuple(ac.shape), tuple(rec.shape), "wav rms %.4f max %.3f" % (rec.pow(2).mean().sqrt(), rec.abs().max()))
 
 
+CASES_15 = [
+    # name, seed, batch, samples, threshold  (full-width H-Codec 1.5 with 2-layer adaptive stacks: the layer count is a YAML knob
+    # of the reference - config_adaptive_v3.yaml:86,95,103 - so this is the reference's own code path)
+    ("hcodec15_b2_thr060", 1500, 2, 640 * 24 + 50, 0.6),
+    ("hcodec15_b2_thr072", 1501, 2, 640 * 24, 0.72),
+]
+
+
+def run_case_15(name, seed, batch, samples, threshold):
+    import dataclasses
+
+    from . import hcodec15_ref  # noqa: F401  (same spec object the tests use)
+
+    spec = dataclasses.replace(R.SPEC_15, agg_layers=2, bt_layers=2, threshold=threshold)
+    sd = synth.hcodec10_state_dict(seed, spec)
+    model = ref_shim.load_state(ref_shim.load_reference_codec("1.5", spec), sd)
+    wav = R.pad_wav(synth.synth_wav(seed + 1, batch, samples))
+    feat = synth.synth_feat(seed + 2, batch, wav.shape[-1] // 320, spec.sem_in)
+    with torch.no_grad():
+        codes = model.encode(wav.unsqueeze(1), feat)
+        rec = model.decode(codes["acoustic_codes"], codes["semantic_codes"])
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), seed=seed, batch=batch, samples=samples, threshold=threshold,
+        acoustic_codes=codes["acoustic_codes"].numpy().astype(np.int32), semantic_codes=codes["semantic_codes"].numpy().astype(np.int32),
+        wav_rec=rec.numpy().astype(np.float32))
+    print(name, tuple(codes["acoustic_codes"].shape), tuple(rec.shape), "lens", (codes["semantic_codes"][0, 0] // 1024 + 1).tolist())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     for c in CASES:
         run_case(*c)
+    for c in CASES_15:
+        run_case_15(*c)
 
 
 if __name__ == "__main__":

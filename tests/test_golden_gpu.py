@@ -34,3 +34,34 @@ def test_hip_path_reproduces_reference_golden(qa_lib, gpu_device, path):
     rms = float(np.sqrt(np.mean((rec - g["wav_rec"]) ** 2)))
     assert rms < 1e-3 * max(1.0, float(np.sqrt(np.mean(g["wav_rec"] ** 2)))), rms  # north_star: <= 1e-3 RMS
     assert rms / float(np.sqrt(np.mean(g["wav_rec"] ** 2))) < 1e-4
+
+
+GOLDEN_15 = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hcodec15_*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN_15, ids=[os.path.basename(p)[:-4] for p in GOLDEN_15])
+def test_hip_path_reproduces_reference_golden_15(qa_lib, gpu_device, path):
+    """H-Codec 1.5 (full width, 2-layer adaptive stacks) against vectors produced by the reference's vq.Codec."""
+    import dataclasses
+
+    import unified_audio_amd as qa
+
+    g = np.load(path)
+    seed = int(g["seed"])
+    ospec = dataclasses.replace(R.SPEC_15, agg_layers=2, bt_layers=2, threshold=float(g["threshold"]))
+    sd = synth.hcodec10_state_dict(seed, ospec)
+    kw = {f: getattr(ospec, f) for f in ospec.__dataclass_fields__}
+    tok = qa.HCodecTokenizer(state_dict=sd, device=gpu_device, spec=qa.HCodecSpec(**kw))
+    wav = synth.synth_wav(seed + 1, int(g["batch"]), int(g["samples"]))
+    feat = synth.synth_feat(seed + 2, int(g["batch"]), R.pad_wav(wav).shape[-1] // 320, ospec.sem_in)
+    codes = tok.tokenize(wav.to(gpu_device), feats=feat.transpose(1, 2).contiguous().to(gpu_device))
+    ref_ac = torch.from_numpy(g["acoustic_codes"].astype(np.int64))
+    ref_sc = torch.from_numpy(g["semantic_codes"].astype(np.int64))
+    assert codes["acoustic_codes"].shape == ref_ac.shape  # same number of groups
+    assert torch.equal(codes["semantic_codes"].cpu() // 1024, ref_sc // 1024)  # identical token lengths
+    assert (codes["acoustic_codes"].cpu() == ref_ac).float().mean() > 0.95
+    assert (codes["semantic_codes"].cpu() == ref_sc).float().mean() > 0.95
+    rec = tok.detokenize(acoustic_codes=ref_ac.to(gpu_device), semantic_codes=ref_sc.to(gpu_device)).cpu().numpy()
+    assert rec.shape == g["wav_rec"].shape
+    rms = float(np.sqrt(np.mean((rec - g["wav_rec"]) ** 2)))
+    assert rms < 1e-3 and rms / float(np.sqrt(np.mean(g["wav_rec"] ** 2))) < 1e-4, rms

@@ -84,3 +84,72 @@ def test_rvq_first_maximum_wins_on_exact_ties():
 def test_pad_wav_rule():
     assert R.pad_wav(torch.zeros(1, 78480)).shape[-1] == 78720  # H15/sample.flac -> wav_rec.wav
     assert R.pad_wav(torch.zeros(1, 64000)).shape[-1] == 64000
+
+
+# ------------------------------------------------------------------------------------------- H-Codec 1.5
+GOLDEN_15 = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hcodec15_*.npz")))
+
+
+def _spec15(threshold):
+    import dataclasses
+
+    return dataclasses.replace(R.SPEC_15, agg_layers=2, bt_layers=2, threshold=threshold)
+
+
+@pytest.mark.parametrize("path", GOLDEN_15, ids=[os.path.basename(p)[:-4] for p in GOLDEN_15])
+def test_oracle15_reproduces_reference_golden(path):
+    from oracle import hcodec15_ref as R15
+
+    g = np.load(path)
+    seed, spec = int(g["seed"]), _spec15(float(g["threshold"]))
+    sd = synth.hcodec10_state_dict(seed, spec)
+    wav = R.pad_wav(synth.synth_wav(seed + 1, int(g["batch"]), int(g["samples"])))
+    feat = synth.synth_feat(seed + 2, int(g["batch"]), wav.shape[-1] // 320, spec.sem_in)
+    with torch.no_grad():
+        codes = R15.encode(sd, wav.unsqueeze(1), feat, spec)
+        rec = R15.decode(sd, codes["acoustic_codes"], codes["semantic_codes"], spec)
+    assert np.array_equal(codes["acoustic_codes"].numpy(), g["acoustic_codes"].astype(np.int64))
+    assert np.array_equal(codes["semantic_codes"].numpy(), g["semantic_codes"].astype(np.int64))
+    err = float(np.sqrt(np.mean((rec.numpy() - g["wav_rec"]) ** 2)) / np.sqrt(np.mean(g["wav_rec"] ** 2)))
+    assert err < 1e-5, err
+    # code range of the length-injected format: < max_tokens * codebook_size
+    assert int(codes["acoustic_codes"].max()) < spec.max_tokens_per_group * spec.codebook_size
+
+
+def test_golden15_present():
+    assert len(GOLDEN_15) >= 2
+
+
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference is only mounted in the build container")
+def test_restatement15_matches_reference_modules():
+    from oracle import hcodec15_ref as R15
+
+    spec = _spec15(0.7)
+    sd = synth.hcodec10_state_dict(777, spec)
+    model = ref_shim.load_state(ref_shim.load_reference_codec("1.5", spec), sd)
+    ref_sd = model.state_dict()
+    assert not [k for k in ref_sd if k not in sd and not k.startswith("semantic_decoder.")]
+    assert not [k for k in sd if k not in ref_sd]
+    wav = R.pad_wav(synth.synth_wav(8, 2, 640 * 17 + 5))
+    feat = synth.synth_feat(9, 2, wav.shape[-1] // 320, spec.sem_in)
+    with torch.no_grad():
+        ref = model.encode(wav.unsqueeze(1), feat)
+        mine = R15.encode(sd, wav.unsqueeze(1), feat, spec)
+        assert torch.equal(ref["acoustic_codes"], mine["acoustic_codes"]) and torch.equal(ref["semantic_codes"], mine["semantic_codes"])
+        w_r = model.decode(**ref)
+        w = R15.decode(sd, ref["acoustic_codes"], ref["semantic_codes"], spec)
+    assert float((w - w_r).abs().max()) < 1e-5 * float(w_r.abs().max())
+
+
+def test_alignment_scan_rules():
+    """Grouping rules of modeling_flexicodec_new.py:862-895 on a hand-made similarity pattern."""
+    from oracle import hcodec15_ref as R15
+
+    t = 20
+    h = torch.zeros(1, t, 4)
+    h[0, :, 0] = 1.0  # all frames identical -> one similarity run, split every 8 frames by max_tokens
+    seg, nseg, _ = R15.similarity_alignment(h, 0.6, 8)
+    assert seg[0].tolist() == [0] * 8 + [1] * 8 + [2] * 4 and int(nseg) == 3
+    h[0, 5:, 0], h[0, 5:, 1] = 0.0, 1.0  # orthogonal from frame 5 on -> boundary at 5
+    seg, nseg, _ = R15.similarity_alignment(h, 0.6, 8)
+    assert seg[0].tolist() == [0] * 5 + [1] * 8 + [2] * 7 and int(nseg) == 3
