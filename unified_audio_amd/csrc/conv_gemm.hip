@@ -236,9 +236,13 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
     else if (p.N <= 32) cfg = PROF_CFG_128x32;
     else if (p.N <= 64) cfg = PROF_CFG_128x64;
     else {
-        // few tiles: prefer the narrower tile so that more than one wave of workgroups exists
-        const long long big = ceil_div(p.M, 128) * ceil_div(p.N, 128);
-        cfg = big < 512 ? PROF_CFG_128x64 : PROF_CFG_128x128;
+        // Tiles of one launch are dealt round-robin over 256 CUs (two co-resident workgroups share a CU's matrix pipes), so
+        // the makespan is (tiles on the busiest CU) x (work per tile) / (sustained efficiency of the configuration:
+        // measured ~92 TFLOP/s for 128x128 vs ~75 for 128x64 on long-K shapes).
+        const long long t128 = ceil_div(p.M, 128) * ceil_div(p.N, 128), t64 = ceil_div(p.M, 128) * ceil_div(p.N, 64);
+        const double c128 = (double)ceil_div(t128, 256) * 128 * 128 / 1.0;
+        const double c64 = (double)ceil_div(t64, 256) * 128 * 64 / 0.82;
+        cfg = c64 < c128 ? PROF_CFG_128x64 : PROF_CFG_128x128;
     }
     switch (cfg) {
         case PROF_CFG_128x32: return launch_cfg<128, 32, 4, 1>(q, stream);
