@@ -83,6 +83,13 @@ typedef struct qa_hcodec_spec {
     int32_t bt_ff;            /* 2048 */
     int32_t max_tokens_per_group; /* 8 */
     float threshold;          /* 0.6 manual_threshold */
+    /* H-Codec 2.0 (QuarkAudio-HCodec/HCodec-2.0/conf/large_12.5hz_config.yaml); version 0 / 10 = SEANet family (1.0, 1.5) */
+    int32_t version;          /* 20 = STFT-domain ConvNeXt encoder, repeat-interleave decoder embed */
+    int32_t enc_dim;          /* 1536 */
+    int32_t enc_inter;        /* 4608 */
+    int32_t enc_convnext_layers; /* 24 */
+    int32_t frame_stride;     /* 4 = int(50 / target_frame_rate) */
+    int32_t tr_inter_cap;     /* 4096: transformer MLP width = min(4*d, cap); 0 = 4*d */
 } qa_hcodec_spec;
 
 typedef struct qa_hcodec qa_hcodec;
@@ -161,6 +168,7 @@ typedef struct qa_conv_args {
     int32_t prologue;      /* 0 none, 1 ELU applied to x on load */
     int32_t act;           /* 0 none, 1 ELU, 2 GELU(erf), 3 SiLU */
     int32_t post_act;      /* applied after the residual add: 0 none, 1 ELU */
+    int32_t in_rep;        /* 0/1 none; r > 1: x is read as x.repeat_interleave(r) along frames (zero padding only) */
 } qa_conv_args;
 int qa_conv1d_cl(const qa_conv_args* args, void* stream);
 

@@ -39,6 +39,27 @@ def _config_15(spec):
     return cfg
 
 
+def _config_20(spec):
+    import yaml
+
+    cfg = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, _VERSIONS["2.0"], "conf", "large_12.5hz_config.yaml")))
+    if spec is not None:  # the reference builds H-Codec 2.0 from this YAML: reduced sizes are its own code path
+        rate = 50.0 / spec.stride
+        cfg["encoder_config"].update(dim=spec.enc_dim, intermediate_dim=spec.enc_inter, dimension=spec.dimension, n_fft=spec.n_fft,
+                                     hop_length=spec.hop, convnext_layers=spec.enc_convnext_layers,
+                                     transformer_layers=spec.enc_transformer_layers, target_frame_rate=rate)
+        cfg["decoder_config"].update(input_channels=2 * spec.dimension, dim=spec.dec_dim, intermediate_dim=spec.dec_inter,
+                                     convnext_layers=spec.dec_convnext_layers, transformer_layers=spec.dec_transformer_layers,
+                                     n_fft=spec.n_fft, hop_length=spec.hop, target_frame_rate=rate)
+        cfg["quantizer_config"].update(dim=spec.dimension, codebook_size=spec.codebook_size, num_quantizers=spec.num_quantizers)
+        for k, a, b in (("semantic_encoder_config", "input_channels", "encode_channels"),):
+            cfg[k].update({a: spec.sem_in, b: spec.sem_ch, "out_channels": spec.dimension, "strides": list(spec.sem_strides),
+                           "channel_ratios": [1] * len(spec.sem_strides)})
+        cfg["semantic_decoder_config"].update(code_dim=spec.dimension, output_channels=spec.sem_in, decode_channels=spec.sem_ch,
+                                              strides=list(spec.sem_strides), channel_ratios=[1] * len(spec.sem_strides))
+    return cfg
+
+
 def load_reference_codec(version: str = "1.0", spec=None):
     """Construct the reference `vq.Codec` (eval mode, random init) for the given H-Codec version."""
     if not reference_available():
@@ -62,7 +83,9 @@ def load_reference_codec(version: str = "1.0", spec=None):
                 with contextlib.redirect_stdout(io.StringIO()):
                     model = Codec(cfg["encoder_config"], cfg["decoder_config"], cfg["quantizer_config"], cfg["adaptive_config"])
             else:
-                raise NotImplementedError("H-Codec 2.0 is not wired yet")
+                cfg = _config_20(spec)
+                model = Codec(cfg["encoder_config"], cfg["decoder_config"], cfg["quantizer_config"],
+                              cfg["semantic_encoder_config"], cfg["semantic_decoder_config"])
     finally:
         sys.path.remove(_STUBS)
         sys.path.remove(root)

@@ -56,7 +56,8 @@ class _Gen:
         if bias:
             self.sd[name + ".bias"] = _t(0.05 * self.rng.standard_normal(c))
 
-    def transformer(self, p, d, n_layers):
+    def transformer(self, p, d, n_layers, inter=None):
+        inter = inter or 4 * d
         for i in range(n_layers):
             lp = f"{p}.layers.{i}"
             b = 1.0 / math.sqrt(d)
@@ -66,9 +67,9 @@ class _Gen:
             for nm in ("q_proj", "k_proj", "v_proj"):
                 self.linear(f"{lp}.self_attn.{nm}", d, d, bias=True, gain=2.0)
             self.linear(f"{lp}.self_attn.o_proj", d, d, bias=False)
-            self.linear(f"{lp}.mlp.w1", 4 * d, d, bias=False)
-            self.linear(f"{lp}.mlp.w2", d, 4 * d, bias=False)
-            self.linear(f"{lp}.mlp.w3", 4 * d, d, bias=False)
+            self.linear(f"{lp}.mlp.w1", inter, d, bias=False)
+            self.linear(f"{lp}.mlp.w2", d, inter, bias=False)
+            self.linear(f"{lp}.mlp.w3", inter, d, bias=False)
             self.norm(f"{lp}.input_layernorm", d, bias=False)
             self.norm(f"{lp}.post_attention_layernorm", d, bias=False)
 
@@ -185,3 +186,68 @@ def synth_feat(seed: int, batch: int, frames: int, dim: int = 768) -> torch.Tens
     x = (c[:, :, 15:] - c[:, :, :-15]) / 15.0 * math.sqrt(15.0)
     x = np.sign(x) * np.abs(x) ** 0.3
     return _t(x)
+
+
+def hcodec20_state_dict(seed: int, spec, head_logmag_bias: float = 1.5) -> Dict[str, torch.Tensor]:
+    """H-Codec 2.0 keys (HCodec-2.0/vq/codec.py:17-56 with codec_encoder.py / codec_decoder.py), minus semantic_decoder.*"""
+    g = _Gen(seed)
+    nb = spec.n_fft // 2 + 1
+
+    def convnext(p, d, inter, n):
+        g.sd[p + ".gamma"] = _t(g.rng.uniform(0.5, 1.5, size=d) / n)
+        g.conv(p + ".dwconv.conv", d, 1, 7)
+        g.norm(p + ".norm", d)
+        g.linear(p + ".pwconv1.linear", inter, d)
+        g.linear(p + ".pwconv2.linear", d, inter)
+
+    d = spec.enc_dim
+    g.conv("encoder.embed.conv", d, 2 * nb, 3, gain=2.0)
+    g.norm("encoder.norm", d)
+    for i in range(spec.enc_convnext_layers):
+        convnext(f"encoder.prior_net.{i}", d, spec.enc_inter, spec.enc_convnext_layers)
+    g.transformer("encoder.post_net.1", d, spec.enc_transformer_layers, spec.tr_inter(d))
+    g.norm("encoder.final_layer_norm", d)
+    g.conv("encoder.out.conv", spec.dimension, d, 2 * spec.stride + 1, gain=1.5)
+    d = spec.dec_dim
+    g.conv("decoder.embed.conv", d, 2 * spec.dimension, spec.stride + 1, gain=1.5)
+    g.norm("decoder.norm", d)
+    for i in range(spec.dec_convnext_layers):
+        convnext(f"decoder.post_net.{i}", d, spec.dec_inter, spec.dec_convnext_layers)
+    g.norm("decoder.final_layer_norm", d)
+    for i in (0, 1, 5, 6):
+        rp = f"decoder.prior_net.{i}"
+        g.norm(rp + ".norm1", d)
+        g.conv(rp + ".conv1.conv", d, d, 3)
+        g.norm(rp + ".norm2", d)
+        g.conv(rp + ".conv2.conv", d, d, 3)
+    g.transformer("decoder.prior_net.3", d, spec.dec_transformer_layers, spec.tr_inter(d))
+    g.norm("decoder.prior_net.7", d)
+    g.linear("decoder.head.out", spec.n_fft + 2, d)
+    g.sd["decoder.head.out.bias"][:nb] += head_logmag_bias
+    g.sd["decoder.head.istft.window"] = torch.hann_window(spec.n_fft)
+    for name in ("quantizer", "semantic_quantizer"):
+        for q in range(spec.num_quantizers):
+            e = g.rng.standard_normal((1, spec.codebook_size, spec.dimension)) * (0.6 * 0.7 ** q)
+            g.sd[f"{name}.layers.{q}._codebook.embed"] = _t(e)
+    sc = spec.sem_ch
+    g.conv("semantic_encoder.conv.conv", sc, spec.sem_in, 3, bias=False)
+    for i, s in enumerate(spec.sem_strides):
+        bp = f"semantic_encoder.conv_blocks.{i}"
+        for u in range(2):
+            g.conv(f"{bp}.res_units.{u}.conv1.conv", sc, sc, 3, bias=False)
+            g.conv(f"{bp}.res_units.{u}.conv2", sc, sc, 1, bias=False)
+        g.conv(f"{bp}.conv.conv", sc, sc, 3 if s == 1 else 2 * s, bias=True)
+    g.conv("semantic_encoder.conv2.conv", spec.dimension, sc, 3, bias=False)
+    return g.sd
+
+
+def synth_wav_fullband(seed: int, batch: int, samples: int) -> torch.Tensor:
+    """White noise + tones, peak 0.5: every STFT bin carries energy, so log-magnitude / phase are well conditioned
+    (the phase of a near-empty bin is numerically arbitrary in ANY implementation, the reference's included)."""
+    rng = np.random.default_rng(seed)
+    x = 0.2 * rng.standard_normal((batch, samples))
+    t = np.arange(samples) / 48000.0
+    for b in range(batch):
+        for f, a in zip(rng.uniform(100, 8000, size=3), (0.3, 0.2, 0.1)):
+            x[b] += a * np.sin(2 * np.pi * f * t + rng.uniform(0, 2 * np.pi))
+    return _t(0.5 * x / np.abs(x).max(axis=1, keepdims=True))

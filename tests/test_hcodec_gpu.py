@@ -163,3 +163,62 @@ def test_hcodec15_full_depth_parity(qa_lib, gpu_device):
     assert all(v < 4 * STAGE_TOL for v in report.values()), report
     assert float((wav_g - wav_o).pow(2).mean().sqrt()) < 1e-3  # north_star waveform tolerance
     assert agree > 0.97
+
+
+# ------------------------------------------------------------------------------------------- H-Codec 2.0
+
+def _run_parity_20(ospec, B, T, device, seed=51, tol=STAGE_TOL):
+    import unified_audio_amd as qa
+    from oracle import hcodec20_ref as R20
+
+    sd = synth.hcodec20_state_dict(seed, ospec)
+    pspec = qa.HCodecSpec(version=20, enc_dim=ospec.enc_dim, enc_inter=ospec.enc_inter, enc_convnext_layers=ospec.enc_convnext_layers,
+                          enc_layers=ospec.enc_transformer_layers, frame_stride=ospec.stride, tr_inter_cap=ospec.tr_inter_cap,
+                          dimension=ospec.dimension, code_dim=ospec.dimension, sem_in=ospec.sem_in, sem_ch=ospec.sem_ch,
+                          sem_strides=ospec.sem_strides, codebook_size=ospec.codebook_size, num_quantizers=ospec.num_quantizers,
+                          dec_dim=ospec.dec_dim, dec_inter=ospec.dec_inter, dec_heads=ospec.dec_dim // 64,
+                          dec_layers=ospec.dec_transformer_layers, convnext_layers=ospec.dec_convnext_layers, n_fft=ospec.n_fft,
+                          hop=ospec.hop, gn_groups=ospec.gn_groups)
+    codec = qa.Codec(None, None, None, spec=pspec, device=device).load_state_dict(sd)
+    codec.enable_taps()
+    wav = synth.synth_wav_fullband(seed + 1, B, T)
+    feat = synth.synth_feat(seed + 2, B, T // ospec.hop, ospec.sem_in)
+    taps = {}
+    ac_o, sc_o = R20.encode(sd, wav, feat, ospec, taps)
+    ac, sc = codec.encode(wav.to(device), feat.to(device))  # [B, T] without channel dim, like the reference
+    torch.cuda.synchronize()
+    nb2 = ospec.n_fft + 2
+    stft = codec.tap("enc.stft").view(B, T // ospec.hop, -1)[..., :nb2].cpu()
+    report = {"enc.stft": rel_err(stft, taps["enc.stft"].transpose(1, 2)),
+              "enc.emb": rel_err(codec.tap("enc.emb"), _cl(taps["enc.emb"])), "enc.sem": rel_err(codec.tap("enc.sem"), _cl(taps["enc.sem"]))}
+    agree = ((ac.cpu() == ac_o).float().mean().item(), (sc.cpu() == sc_o).float().mean().item())
+    wav_o = R20.decode(sd, ac_o, sc_o, ospec)
+    wav_g = codec.decode(ac_o.to(device), sc_o.to(device))
+    torch.cuda.synchronize()
+    report["wav"] = rel_err(wav_g, wav_o)
+    assert wav_g.shape == wav_o.shape == (B, T)
+    return report, agree
+
+
+def test_hcodec20_reduced_parity(qa_lib, gpu_device):
+    from oracle import hcodec20_ref as R20
+
+    ospec = R20.HCodec20Spec(enc_dim=256, enc_inter=512, enc_convnext_layers=2, enc_transformer_layers=1, dimension=128, sem_in=64,
+                             sem_ch=128, codebook_size=64, num_quantizers=5, dec_dim=256, dec_inter=512, dec_convnext_layers=2,
+                             dec_transformer_layers=1)
+    report, agree = _run_parity_20(ospec, B=2, T=3840 * 6, device=gpu_device)
+    print(report, agree)
+    assert all(v < STAGE_TOL for v in report.values()), report
+    assert min(agree) > 0.95
+
+
+def test_hcodec20_full_width_parity(qa_lib, gpu_device):
+    """Full H-Codec 2.0 widths (1536 / 4608, 24 heads, 16 codebooks, n_fft 1920) with 2 ConvNeXt blocks per stack."""
+    from oracle import hcodec20_ref as R20
+    import dataclasses
+
+    ospec = dataclasses.replace(R20.SPEC_20, enc_convnext_layers=2, dec_convnext_layers=2)
+    report, agree = _run_parity_20(ospec, B=2, T=3840 * 8, device=gpu_device, seed=61)
+    print(report, agree)
+    assert all(v < 2 * STAGE_TOL for v in report.values()), report
+    assert min(agree) > 0.95

@@ -6,7 +6,7 @@ reference's own interface (`Codec.encode/decode`, `HCodecTokenizer.tokenize/deto
 There is no CPU / PyTorch fallback: if libquarkaudio_hip.so is missing or no gfx950 device is visible, calls raise.
 """
 from ._lib import QuarkAudioError, lib_path, load_library  # noqa: F401
-from .hcodec import Codec, HCodecSpec, HCodecTokenizer, SPEC_10, SPEC_15  # noqa: F401
+from .hcodec import Codec, HCodecSpec, HCodecTokenizer, SPEC_10, SPEC_15, SPEC_20  # noqa: F401
 from .llm import LLM_SFT  # noqa: F401
 
-__all__ = ["LLM_SFT", "Codec", "HCodecSpec", "HCodecTokenizer", "SPEC_10", "SPEC_15", "QuarkAudioError", "load_library", "lib_path"]
+__all__ = ["LLM_SFT", "Codec", "HCodecSpec", "HCodecTokenizer", "SPEC_10", "SPEC_15", "SPEC_20", "QuarkAudioError", "load_library", "lib_path"]

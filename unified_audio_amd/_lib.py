@@ -33,6 +33,8 @@ class qa_hcodec_spec(C.Structure):
         ("adaptive", C.c_int32), ("agg_layers", C.c_int32), ("agg_heads", C.c_int32), ("agg_ff", C.c_int32),
         ("bt_layers", C.c_int32), ("bt_heads", C.c_int32), ("bt_ff", C.c_int32), ("max_tokens_per_group", C.c_int32),
         ("threshold", C.c_float),
+        ("version", C.c_int32), ("enc_dim", C.c_int32), ("enc_inter", C.c_int32), ("enc_convnext_layers", C.c_int32),
+        ("frame_stride", C.c_int32), ("tr_inter_cap", C.c_int32),
     ]
 
 
@@ -44,6 +46,7 @@ class qa_conv_args(C.Structure):
         ("ldx", C.c_int64), ("ldy", C.c_int64), ("ldr", C.c_int64), ("ldg", C.c_int64),
         ("ksize", C.c_int32), ("stride", C.c_int32), ("pad_left", C.c_int32), ("pad_right", C.c_int32),
         ("pad_mode", C.c_int32), ("prologue", C.c_int32), ("act", C.c_int32), ("post_act", C.c_int32),
+        ("in_rep", C.c_int32),
     ]
 
 

@@ -101,6 +101,7 @@ struct ConvParams {
     int prologue, act, post_act;
     int algo_n, algo_k;  // un-padded N / K for the algorithmic FLOP count (0 = use N / K)
     int xcd_swizzle;
+    int in_rep;  // >1: the input is read as if every frame were repeated in_rep times (x.repeat_interleave, H-Codec 2.0 decoder)
 };
 
 // Live measurement hook (bench.py): when enabled every conv_gemm launch is bracketed by HIP events on its own stream.

@@ -75,6 +75,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p) {
     const bool reflect = p.pad_mode == PAD_REFLECT;
     const int ldx_i = (int)p.ldx;
     const int nk = p.K / BK;
+    const int in_rep = p.in_rep;
+    const int t_virtual = p.T_in * (in_rep > 1 ? in_rep : 1);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -100,8 +102,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p) {
             int r_ = a_t0[i] + j_;                                                                             \
             const int rr_ = r_ < 0 ? -r_ : (r_ >= p.Lp ? 2 * (p.Lp - 1) - r_ : r_); /* = resolve_frame() */    \
             r_ = reflect ? rr_ : r_;                                                                           \
-            const bool ok_ = r_ >= 0 && r_ < p.T_in;                                                           \
+            const bool ok_ = r_ >= 0 && r_ < t_virtual;                                                        \
             a_keep[i] = ok_ ? 1.f : 0.f;                                                                       \
+            r_ = in_rep > 1 ? r_ / in_rep : r_;                                                                \
             a_reg[i] = *reinterpret_cast<const float4*>(p.x + a_base[i] + (unsigned)((ok_ ? r_ : 0) * ldx_i + c_)); \
         }                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < B_IT; ++i) b_reg[i] = *reinterpret_cast<const float4*>(b_ptr[i] + k0_); \
@@ -231,6 +234,7 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
     }();
     ConvParams q = p;
     q.xcd_swizzle = swz;
+    QA_REQUIRE(p.in_rep <= 1 || p.pad_mode == PAD_ZERO, "conv_gemm: in_rep needs zero padding");
     int cfg;
     if (forced >= 0) cfg = forced;
     else if (p.N <= 32) cfg = PROF_CFG_128x32;
@@ -269,7 +273,8 @@ int conv_params_from_args(const qa_conv_args& a, ConvParams* out) {
     const int max_pad = a.pad_left > a.pad_right ? a.pad_left : a.pad_right;
     p.Lp = (p.T_in <= max_pad) ? max_pad + 1 : p.T_in;
     // every window must stay inside the padded signal
-    QA_REQUIRE(a.T_out == 0 || (a.T_out - 1) * (int64_t)a.stride + a.ksize <= a.pad_left + a.T_in + a.pad_right,
+    p.in_rep = a.in_rep > 1 ? a.in_rep : 1;
+    QA_REQUIRE(a.T_out == 0 || (a.T_out - 1) * (int64_t)a.stride + a.ksize <= a.pad_left + a.T_in * (int64_t)p.in_rep + a.pad_right,
                "conv1d_cl: T_out=%lld windows do not fit pad_left=%d + T_in=%lld + pad_right=%d", (long long)a.T_out,
                a.pad_left, (long long)a.T_in, a.pad_right);
     p.prologue = a.prologue; p.act = a.act; p.post_act = a.post_act;

@@ -431,6 +431,31 @@ int launch_istft_spec(const float* y, float* S, long long rows, int nb, int ldy,
     return QA_OK;
 }
 
+// H-Codec 2.0 encoder front (HCodec-2.0/vq/codec_encoder.py:66-71): STFT rows (re | im) [rows, 2*nb] ->
+// (log(max(|X|, 1e-5)) | angle(X) / pi | 0 pad) [rows, ldo]
+__global__ __launch_bounds__(256) void stft_post_kernel(const float* __restrict__ ri, float* __restrict__ out, long long rows,
+                                                        int nb, int ldi, int ldo) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = ldo - nb;
+    if (gid >= rows * (long long)w) return;
+    const int k = (int)(gid % w);
+    const long long r = gid / w;
+    float ph = 0.f;
+    if (k < nb) {
+        const float re = ri[r * ldi + k], im = ri[r * ldi + nb + k];
+        out[r * ldo + k] = logf(fmaxf(hypotf(re, im), 1e-5f));
+        ph = atan2f(im, re) / 3.14159265358979323846f;
+    }
+    out[r * ldo + nb + k] = ph;
+}
+int launch_stft_post(const float* ri, float* out, long long rows, int nb, int ldi, int ldo, hipStream_t s) {
+    QA_REQUIRE(ldo >= 2 * nb, "stft_post: ldo=%d < 2*nb", ldo);
+    const long long total = rows * (long long)(ldo - nb);
+    hipLaunchKernelGGL(stft_post_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, ri, out, rows, nb, ldi, ldo);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
 // ISTFT step 3 (vq/spectral_ops.py:58-73): overlap-add of the windowed frames, trim (win-hop)/2 each side,
 // divide by the folded hann^2 envelope.  frames [B, T, n_fft] (already multiplied by the window inside the
 // inverse-DFT basis), out [B, T*hop].

@@ -21,7 +21,7 @@ struct TransformerLayerW {
 
 struct TransformerW {
     std::vector<TransformerLayerW> layers;
-    int d = 0, heads = 0;
+    int d = 0, heads = 0, inter = 0;
     const float* rope = nullptr;  // [MAX_POS][hd/2][2]
 };
 
@@ -87,6 +87,11 @@ struct qa_hcodec {
     ConvW head, basis;
     const float* window = nullptr;
     int spec_ld = 0;
+    // H-Codec 2.0 encoder
+    ConvW stft_basis, enc_embed, enc_out20, dec_embed20;
+    const float *enc_norm_w = nullptr, *enc_norm_b = nullptr, *enc_fnorm_w = nullptr, *enc_fnorm_b = nullptr;
+    std::vector<ConvNeXtW> enc_cnx;
+    int stft_ld = 0;
     // H-Codec 1.5
     MimiW agg_sem, agg_ac, bottleneck;
     const float *qemb_sem = nullptr, *qemb_ac = nullptr;
@@ -191,9 +196,11 @@ struct Builder {
 };
 
 // rows of an LSTM matrix / bias go from PyTorch's gate-major order (i,f,g,o blocks of d) to (unit, gate)
-void build_transformer(Builder& b, TransformerW* tw, const std::string& p, int d, int n_layers, int heads) {
+void build_transformer(Builder& b, TransformerW* tw, const std::string& p, int d, int n_layers, int heads, int inter = 0) {
+    if (inter <= 0) inter = 4 * d;
     tw->d = d;
     tw->heads = heads;
+    tw->inter = inter;
     tw->layers.resize(n_layers);
     for (int l = 0; l < n_layers; ++l) {
         TransformerLayerW& L = tw->layers[l];
@@ -233,12 +240,12 @@ void build_transformer(Builder& b, TransformerW* tw, const std::string& p, int d
         b.raw(&L.qkv.b, bq);
         L.o.N = d; L.o.C_in = d; L.o.ksize = 1;
         b.vec(&L.o.w, ap + ".o_proj.weight", (int64_t)d * d);
-        L.w1.N = 4 * d; L.w1.C_in = d; L.w1.ksize = 1;
-        b.vec(&L.w1.w, lp + ".mlp.w1.weight", (int64_t)4 * d * d);
-        L.w3.N = 4 * d; L.w3.C_in = d; L.w3.ksize = 1;
-        b.vec(&L.w3.w, lp + ".mlp.w3.weight", (int64_t)4 * d * d);
-        L.w2.N = d; L.w2.C_in = 4 * d; L.w2.ksize = 1;
-        b.vec(&L.w2.w, lp + ".mlp.w2.weight", (int64_t)4 * d * d);
+        L.w1.N = inter; L.w1.C_in = d; L.w1.ksize = 1;
+        b.vec(&L.w1.w, lp + ".mlp.w1.weight", (int64_t)inter * d);
+        L.w3.N = inter; L.w3.C_in = d; L.w3.ksize = 1;
+        b.vec(&L.w3.w, lp + ".mlp.w3.weight", (int64_t)inter * d);
+        L.w2.N = d; L.w2.C_in = inter; L.w2.ksize = 1;
+        b.vec(&L.w2.w, lp + ".mlp.w2.weight", (int64_t)inter * d);
     }
     // RoPE table, RotaryEmbedding of transformer.py:8-74 evaluated in fp32 like the reference
     const int hd = d / heads, half = hd / 2;
@@ -297,7 +304,7 @@ void build_mimi(Builder& b, MimiW* mw, const std::string& p, int d, int n_layers
 
 int conv_op(Ctx& c, const float* x, int64_t ldx, int B, int T_in, const ConvW& w, float* y, int64_t ldy, int T_out,
             int stride, int pad_left, int pad_right, int pad_mode, int prologue, int act, const float* gamma,
-            const float* res, int64_t ldr, const float* gate, int post_act) {
+            const float* res, int64_t ldr, const float* gate, int post_act, int in_rep = 1) {
     if (c.dry) return QA_OK;
     qa_conv_args a{};
     a.x = x; a.w = w.w; a.bias = w.b; a.gamma = gamma; a.residual = res; a.gate = gate; a.y = y;
@@ -305,6 +312,7 @@ int conv_op(Ctx& c, const float* x, int64_t ldx, int B, int T_in, const ConvW& w
     a.ldx = ldx; a.ldy = ldy; a.ldr = ldr; a.ldg = w.N;
     a.ksize = w.ksize; a.stride = stride; a.pad_left = pad_left; a.pad_right = pad_right; a.pad_mode = pad_mode;
     a.prologue = prologue; a.act = act; a.post_act = post_act;
+    a.in_rep = in_rep;
     ConvParams p;
     QA_TRY(conv_params_from_args(a, &p));
     p.algo_n = w.algo_n;
@@ -344,8 +352,9 @@ int transformer_op(Ctx& c, const TransformerW& tw, float* x, int B, int N, const
     QA_REQUIRE(N <= MAX_POS, "transformer: sequence of %d frames exceeds %d", N, MAX_POS);
     const size_t mark = c.arena.mark();
     float* hn = c.arena.alloc<float>(rows * d);
-    float* big = c.arena.alloc<float>(rows * 4 * d);   // xw / gate buffer
-    float* big2 = c.arena.alloc<float>(rows * 4 * d);  // swiglu product
+    const int wide = std::max(4 * d, tw.inter);
+    float* big = c.arena.alloc<float>(rows * wide);   // xw (4d) / gate buffer
+    float* big2 = c.arena.alloc<float>(rows * wide);  // swiglu product
     float* hl = c.arena.alloc<float>(rows * d);
     float* qkv = c.arena.alloc<float>(rows * 3 * d);
     float* att = c.arena.alloc<float>(rows * d);
@@ -423,10 +432,58 @@ int dec_resblock_op(Ctx& c, const DecResW& w, float* x, int B, int T, int C, int
 
 // ---------------------------------------------------------------- encode / decode graphs
 
+int convnext_op(Ctx& c, const ConvNeXtW& w, float* x, float* t1, float* u, int B, int T, int d) {
+    const int64_t rows = (int64_t)B * T;
+    if (c.dry) return QA_OK;
+    QA_TRY(launch_dwconv(x, w.dw, w.dwb, w.lnw, w.lnb, t1, B, T, d, 7, 1e-6f, c.stream));
+    QA_TRY(linear_op(c, t1, rows, w.pw1, u, ACT_GELU));
+    return linear_op(c, u, rows, w.pw2, x, ACT_NONE, x, nullptr, w.gamma);
+}
+
+// H-Codec 2.0 CodecEncoder.forward (HCodec-2.0/vq/codec_encoder.py:62-79): wav [B, T] -> emb [B, T / (hop*stride), code_dim]
+int encoder20(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, float** emb_out, int* n50_out, int* nf_out) {
+    const qa_hcodec_spec& sp = h->spec;
+    const int blk = (sp.n_fft - sp.hop) / 2;  // 480: pad = (n_fft - hop) / 2 and hop = 2 * blk, n_fft = 4 * blk
+    const int N50 = T / sp.hop, d = sp.enc_dim, nb = sp.n_fft / 2 + 1;
+    const int64_t rows = (int64_t)B * N50;
+    // STFT as an implicit GEMM: the signal is a [B, T / blk, blk] "channel-last" tensor, a frame is 4 consecutive blocks
+    // starting one block before 2 t (zero padded), the filter bank is the windowed DFT basis (re | im)
+    float* ri = c.arena.alloc<float>(rows * 2 * nb);
+    QA_TRY(conv_op(c, wav, blk, B, T / blk, h->stft_basis, ri, 2 * nb, N50, 2, 1, 1, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, nullptr,
+                   0, nullptr, ACT_NONE));
+    float* feat = c.arena.alloc<float>(rows * h->stft_ld);
+    if (!c.dry) QA_TRY(launch_stft_post(ri, feat, rows, nb, 2 * nb, h->stft_ld, c.stream));
+    c.tap("enc.stft", feat, rows * h->stft_ld);
+    float* x = c.arena.alloc<float>(rows * d);
+    float* t1 = c.arena.alloc<float>(rows * d);
+    float* u = c.arena.alloc<float>(rows * sp.enc_inter);
+    QA_TRY(conv_op(c, feat, h->stft_ld, B, N50, h->enc_embed, t1, d, N50, 1, 1, 1, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, nullptr, 0,
+                   nullptr, ACT_NONE));
+    if (!c.dry) QA_TRY(launch_layernorm(t1, h->enc_norm_w, h->enc_norm_b, x, rows, d, 1e-6f, c.stream));
+    for (const ConvNeXtW& w : h->enc_cnx) QA_TRY(convnext_op(c, w, x, t1, u, B, N50, d));
+    c.tap("enc.prior", x, rows * d);
+    QA_TRY(transformer_op(c, h->enc_tr, x, B, N50, "encoder.post_net.1"));
+    if (!c.dry) QA_TRY(launch_layernorm(x, h->enc_fnorm_w, h->enc_fnorm_b, t1, rows, d, 1e-6f, c.stream));
+    const int k = h->enc_out20.ksize, pad = k / 2, st = sp.frame_stride;
+    const int Nf = (N50 + 2 * pad - k) / st + 1;
+    float* emb = c.arena.alloc<float>((size_t)B * Nf * sp.code_dim);
+    QA_TRY(conv_op(c, t1, d, B, N50, h->enc_out20, emb, sp.code_dim, Nf, st, pad, pad, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, nullptr,
+                   0, nullptr, ACT_NONE));
+    *emb_out = emb;
+    *n50_out = N50;
+    *nf_out = Nf;
+    return QA_OK;
+}
+
 // SEANet encoder + semantic encoder: wav, feat -> emb, sem  [B, N25, code_dim] each (codec.py:169-170)
 int encode_front(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const float* feat, int64_t fsb, int64_t fsc,
                  int64_t fst, int n_feat, float** emb_out, float** sem_out, int* n25_out) {
     const qa_hcodec_spec& sp = h->spec;
+    float* emb = nullptr;
+    int N50 = 0, N25 = 0;
+    if (sp.version == 20) {
+        QA_TRY(encoder20(h, c, wav, B, T, &emb, &N50, &N25));
+    } else {
     // ---- SEANet encoder
     int C = sp.n_filters, L = T;
     float* x = c.arena.alloc<float>((size_t)B * L * C);
@@ -460,14 +517,15 @@ int encode_front(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const flo
         c.tap("enc.stage" + std::to_string(i), x, (int64_t)B * L * C);
     }
     QA_REQUIRE(C == sp.dimension, "encoder: channel ladder ends at %d, spec.dimension is %d", C, sp.dimension);
-    const int N50 = L;
+    N50 = L;
     QA_TRY(transformer_op(c, h->enc_tr, x, B, N50, "encoder.model." + std::to_string(3 * sp.n_ratios + 2)));
     c.tap("enc.transformer", x, (int64_t)B * N50 * C);
     const SGeom g = sconv_geom(N50, 4, 2);
-    const int N25 = g.T_out;
-    float* emb = c.arena.alloc<float>((size_t)B * N25 * sp.code_dim);
+    N25 = g.T_out;
+    emb = c.arena.alloc<float>((size_t)B * N25 * sp.code_dim);
     QA_TRY(conv_op(c, x, C, B, N50, h->enc_out, emb, sp.code_dim, N25, 2, g.left, g.right, PAD_REFLECT, ACT_ELU, ACT_NONE,
                    nullptr, nullptr, 0, nullptr, ACT_NONE));
+    }
     c.tap("enc.emb", emb, (int64_t)B * N25 * sp.code_dim);
 
     // ---- semantic encoder
@@ -554,12 +612,21 @@ int decode_tail(qa_hcodec* h, Ctx& c, const float* cat, int B, int N, float* wav
     const int64_t rows25 = (int64_t)B * N;
     // sub-pixel upsampler: 1x1 conv to 2*d channels; in channel-last layout the pixel shuffle (vq/conv.py:86-88) is a
     // pure reinterpretation [B, N, 2, d] -> [B, 2N, d]
-    float* up = c.arena.alloc<float>(rows25 * 2 * d);
-    QA_TRY(linear_op(c, cat, rows25, h->up, up));
-    const int N50 = 2 * N;
+    const bool v20 = sp.version == 20;
+    const int N50 = (v20 ? sp.frame_stride : 2) * N;
     const int64_t rows = (int64_t)B * N50;
     float* x = c.arena.alloc<float>(rows * d);
-    if (!c.dry) QA_TRY(launch_dwconv(up, h->up_dw, h->up_dwb, nullptr, nullptr, x, B, N50, d, 5, 0.f, c.stream));
+    if (v20) {
+        // H-Codec 2.0 (codec_decoder.py:30-31,64-65): x.repeat_interleave(s) -> Conv1d k = s + 1, "same" zero padding.  The
+        // repetition is folded into the implicit-GEMM gather (frame r reads row r / s), nothing is materialised.
+        const int k = h->dec_embed20.ksize;
+        QA_TRY(conv_op(c, cat, 2 * sp.code_dim, B, N, h->dec_embed20, x, d, N50, 1, k / 2, k / 2, PAD_ZERO, ACT_NONE, ACT_NONE,
+                       nullptr, nullptr, 0, nullptr, ACT_NONE, sp.frame_stride));
+    } else {
+        float* up = c.arena.alloc<float>(rows25 * 2 * d);
+        QA_TRY(linear_op(c, cat, rows25, h->up, up));
+        if (!c.dry) QA_TRY(launch_dwconv(up, h->up_dw, h->up_dwb, nullptr, nullptr, x, B, N50, d, 5, 0.f, c.stream));
+    }
     c.tap("dec.embed", x, rows * d);
     QA_TRY(dec_resblock_op(c, h->dres[0], x, B, N50, d, sp.gn_groups));
     QA_TRY(dec_resblock_op(c, h->dres[1], x, B, N50, d, sp.gn_groups));
@@ -573,12 +640,7 @@ int decode_tail(qa_hcodec* h, Ctx& c, const float* cat, int B, int N, float* wav
     QA_TRY(groupnorm_op(c, x, h->gn_w, h->gn_b, t1, B, N50, d, sp.gn_groups, 0));
     if (!c.dry) QA_TRY(launch_layernorm(t1, h->norm_w, h->norm_b, x, rows, d, 1e-6f, c.stream));
     c.tap("dec.prior", x, rows * d);
-    for (const ConvNeXtW& w : h->cnx) {
-        if (c.dry) break;
-        QA_TRY(launch_dwconv(x, w.dw, w.dwb, w.lnw, w.lnb, t1, B, N50, d, 7, 1e-6f, c.stream));
-        QA_TRY(linear_op(c, t1, rows, w.pw1, u, ACT_GELU));
-        QA_TRY(linear_op(c, u, rows, w.pw2, x, ACT_NONE, x, nullptr, w.gamma));
-    }
+    for (const ConvNeXtW& w : h->cnx) QA_TRY(convnext_op(c, w, x, t1, u, B, N50, d));
     if (!c.dry) QA_TRY(launch_layernorm(x, h->fnorm_w, h->fnorm_b, t1, rows, d, 1e-6f, c.stream));
     c.tap("dec.backbone", t1, rows * d);
     // ISTFT head
@@ -681,14 +743,67 @@ int ensure_workspace(qa_hcodec* h, size_t bytes) {
 
 int build(qa_hcodec* h, const HostTable& tab) {
     const qa_hcodec_spec& sp = h->spec;
-    QA_REQUIRE(sp.n_ratios >= 1 && sp.n_ratios <= 8 && sp.n_sem_strides >= 1 && sp.n_sem_strides <= 4, "spec: bad counts");
-    QA_REQUIRE(sp.n_filters % 32 == 0, "spec: n_filters=%d must be a multiple of 32", sp.n_filters);
-    QA_REQUIRE(sp.dimension % 128 == 0 && sp.dec_dim % 128 == 0, "spec: transformer widths must be multiples of 128");
+    const bool v20 = sp.version == 20;
+    QA_REQUIRE(sp.version == 0 || sp.version == 10 || sp.version == 15 || v20, "spec: unknown version %d", sp.version);
+    QA_REQUIRE(!(v20 && sp.adaptive), "spec: H-Codec 2.0 has no adaptive frame rate");
+    QA_REQUIRE(sp.n_sem_strides >= 1 && sp.n_sem_strides <= 4, "spec: bad counts");
+    QA_REQUIRE(v20 || (sp.n_ratios >= 1 && sp.n_ratios <= 8 && sp.n_filters % 32 == 0), "spec: bad SEANet ladder");
+    QA_REQUIRE((v20 ? sp.enc_dim : sp.dimension) % 128 == 0 && sp.dec_dim % 128 == 0, "spec: transformer widths must be multiples of 128");
+    auto tr_inter = [&](int d) { return sp.tr_inter_cap > 0 ? std::min(4 * d, sp.tr_inter_cap) : 4 * d; };
     QA_REQUIRE(sp.sem_in % 32 == 0 && sp.sem_ch % 32 == 0 && sp.code_dim % 32 == 0 && sp.dec_inter % 32 == 0,
                "spec: channel counts must be multiples of 32");
     QA_REQUIRE(sp.n_fft % 2 == 0 && sp.hop > 0 && sp.n_fft > sp.hop && (sp.n_fft - sp.hop) % 2 == 0, "spec: bad STFT geometry");
     QA_REQUIRE(sp.dec_dim % sp.gn_groups == 0, "spec: dec_dim %% gn_groups != 0");
     Builder b{Folder{tab, h->store}};
+    auto dw_fold_c = [&](const float** dst, const std::string& name, int k, int ch) {
+        std::vector<float> w((size_t)k * ch, 0.f);
+        const float* p = b.f.need(name, (int64_t)ch * k);
+        if (p)
+            for (int c = 0; c < ch; ++c)
+                for (int j = 0; j < k; ++j) w[(size_t)j * ch + c] = p[c * k + j];
+        b.raw(dst, w);
+    };
+    auto fold_convnext = [&](ConvNeXtW& w, const std::string& cp, int ch, int inter) {
+        dw_fold_c(&w.dw, cp + ".dwconv.conv.weight", 7, ch);
+        b.vec(&w.dwb, cp + ".dwconv.conv.bias", ch);
+        b.vec(&w.lnw, cp + ".norm.weight", ch);
+        b.vec(&w.lnb, cp + ".norm.bias", ch);
+        b.vec(&w.gamma, cp + ".gamma", ch);
+        w.pw1.N = inter; w.pw1.C_in = ch; w.pw1.ksize = 1;
+        b.vec(&w.pw1.w, cp + ".pwconv1.linear.weight", (int64_t)inter * ch);
+        b.vec(&w.pw1.b, cp + ".pwconv1.linear.bias", inter);
+        w.pw2.N = ch; w.pw2.C_in = inter; w.pw2.ksize = 1;
+        b.vec(&w.pw2.w, cp + ".pwconv2.linear.weight", (int64_t)inter * ch);
+        b.vec(&w.pw2.b, cp + ".pwconv2.linear.bias", ch);
+    };
+    if (v20) {
+        // --- H-Codec 2.0 encoder (HCodec-2.0/vq/codec_encoder.py:12-79)
+        const int Nf = sp.n_fft, nbins = Nf / 2 + 1, blk = (Nf - sp.hop) / 2, de = sp.enc_dim;
+        QA_REQUIRE(sp.hop == 2 * blk && Nf == 4 * blk && blk % 32 == 0, "spec: H-Codec 2.0 needs n_fft = 2 * hop and hop %% 64 == 0");
+        QA_REQUIRE(de % 64 == 0 && sp.enc_inter % 32 == 0 && sp.frame_stride >= 1, "spec: bad H-Codec 2.0 encoder widths");
+        {   // torchaudio Spectrogram(n_fft, hop, center=False, power=None): X[k] = sum_n hann[n] x[n] e^{-2 pi i k n / N}
+            std::vector<float> basis((size_t)2 * nbins * Nf);
+            for (int k = 0; k < nbins; ++k)
+                for (int n = 0; n < Nf; ++n) {
+                    const double wn = 0.5 - 0.5 * std::cos(2.0 * M_PI * n / Nf);
+                    const double ang = 2.0 * M_PI * (double)(((int64_t)k * n) % Nf) / Nf;
+                    basis[(size_t)k * Nf + n] = (float)(wn * std::cos(ang));
+                    basis[(size_t)(nbins + k) * Nf + n] = (float)(-wn * std::sin(ang));
+                }
+            h->stft_basis.N = 2 * nbins; h->stft_basis.C_in = blk; h->stft_basis.ksize = 4;
+            b.raw(&h->stft_basis.w, basis);  // [2*nb][4][blk] == [2*nb][n_fft]
+        }
+        h->stft_ld = pad32(2 * nbins);
+        b.conv(&h->enc_embed, "encoder.embed.conv", de, 2 * nbins, 3, false, true, de, h->stft_ld);
+        b.vec(&h->enc_norm_w, "encoder.norm.weight", de);
+        b.vec(&h->enc_norm_b, "encoder.norm.bias", de);
+        h->enc_cnx.resize(sp.enc_convnext_layers);
+        for (int i = 0; i < sp.enc_convnext_layers; ++i) fold_convnext(h->enc_cnx[i], "encoder.prior_net." + std::to_string(i), de, sp.enc_inter);
+        build_transformer(b, &h->enc_tr, "encoder.post_net.1", de, sp.enc_layers, de / 64, tr_inter(de));
+        b.vec(&h->enc_fnorm_w, "encoder.final_layer_norm.weight", de);
+        b.vec(&h->enc_fnorm_b, "encoder.final_layer_norm.bias", de);
+        b.conv(&h->enc_out20, "encoder.out.conv", sp.code_dim, de, 2 * sp.frame_stride + 1, false, true);
+    } else {
     // --- SEANet encoder (seanet.py:121-187)
     const std::string em = "encoder.model.";
     {
@@ -724,6 +839,7 @@ int build(qa_hcodec* h, const HostTable& tab) {
     build_transformer(b, &h->enc_tr, em + std::to_string(3 * sp.n_ratios + 2), sp.dimension, sp.enc_layers, sp.enc_heads);
     b.conv(&h->enc_out, em + std::to_string(3 * sp.n_ratios + 5) + ".conv.conv", sp.dimension, sp.dimension, 4, true, true);
     QA_REQUIRE(sp.code_dim == sp.dimension, "spec: code_dim must equal dimension");
+    }
     // --- semantic encoder (semantic_module.py:157-201)
     const std::string se = "semantic_encoder.";
     b.conv(&h->sem_in, se + "conv.conv", sp.sem_ch, sp.sem_in, 3, false, false);
@@ -754,17 +870,13 @@ int build(qa_hcodec* h, const HostTable& tab) {
     }
     // --- decoder (codec_decoder.py:14-67)
     const int d = sp.dec_dim;
-    b.conv(&h->up, "decoder.embed.up", 2 * d, 2 * sp.code_dim, 1, false, true);
-    auto dw_fold = [&](const float** dst, const std::string& name, int k) {
-        std::vector<float> w((size_t)k * d, 0.f);
-        const float* p = b.f.need(name, (int64_t)d * k);
-        if (p)
-            for (int c = 0; c < d; ++c)
-                for (int j = 0; j < k; ++j) w[(size_t)j * d + c] = p[c * k + j];
-        b.raw(dst, w);
-    };
-    dw_fold(&h->up_dw, "decoder.embed.dw.weight", 5);
-    b.vec(&h->up_dwb, "decoder.embed.dw.bias", d);
+    if (v20) {
+        b.conv(&h->dec_embed20, "decoder.embed.conv", d, 2 * sp.code_dim, sp.frame_stride + 1, false, true);
+    } else {
+        b.conv(&h->up, "decoder.embed.up", 2 * d, 2 * sp.code_dim, 1, false, true);
+        dw_fold_c(&h->up_dw, "decoder.embed.dw.weight", 5, d);
+        b.vec(&h->up_dwb, "decoder.embed.dw.bias", d);
+    }
     const int ridx[4] = {0, 1, 5, 6};
     for (int i = 0; i < 4; ++i) {
         const std::string rp = "decoder.prior_net." + std::to_string(ridx[i]);
@@ -775,7 +887,7 @@ int build(qa_hcodec* h, const HostTable& tab) {
         b.conv(&h->dres[i].c1, rp + ".conv1.conv", d, d, 3, false, true);
         b.conv(&h->dres[i].c2, rp + ".conv2.conv", d, d, 3, false, true);
     }
-    build_transformer(b, &h->dec_tr, "decoder.prior_net.3", d, sp.dec_layers, sp.dec_heads);
+    build_transformer(b, &h->dec_tr, "decoder.prior_net.3", d, sp.dec_layers, sp.dec_heads, tr_inter(d));
     b.vec(&h->gn_w, "decoder.prior_net.7.weight", d);
     b.vec(&h->gn_b, "decoder.prior_net.7.bias", d);
     b.vec(&h->norm_w, "decoder.norm.weight", d);
@@ -783,21 +895,7 @@ int build(qa_hcodec* h, const HostTable& tab) {
     b.vec(&h->fnorm_w, "decoder.final_layer_norm.weight", d);
     b.vec(&h->fnorm_b, "decoder.final_layer_norm.bias", d);
     h->cnx.resize(sp.convnext_layers);
-    for (int i = 0; i < sp.convnext_layers; ++i) {
-        ConvNeXtW& w = h->cnx[i];
-        const std::string cp = "decoder.post_net." + std::to_string(i);
-        dw_fold(&w.dw, cp + ".dwconv.conv.weight", 7);
-        b.vec(&w.dwb, cp + ".dwconv.conv.bias", d);
-        b.vec(&w.lnw, cp + ".norm.weight", d);
-        b.vec(&w.lnb, cp + ".norm.bias", d);
-        b.vec(&w.gamma, cp + ".gamma", d);
-        w.pw1.N = sp.dec_inter; w.pw1.C_in = d; w.pw1.ksize = 1;
-        b.vec(&w.pw1.w, cp + ".pwconv1.linear.weight", (int64_t)sp.dec_inter * d);
-        b.vec(&w.pw1.b, cp + ".pwconv1.linear.bias", sp.dec_inter);
-        w.pw2.N = d; w.pw2.C_in = sp.dec_inter; w.pw2.ksize = 1;
-        b.vec(&w.pw2.w, cp + ".pwconv2.linear.weight", (int64_t)sp.dec_inter * d);
-        b.vec(&w.pw2.b, cp + ".pwconv2.linear.bias", d);
-    }
+    for (int i = 0; i < sp.convnext_layers; ++i) fold_convnext(h->cnx[i], "decoder.post_net." + std::to_string(i), d, sp.dec_inter);
     const int nb = sp.n_fft / 2 + 1;
     h->head.N = 2 * nb; h->head.C_in = d; h->head.ksize = 1;
     b.vec(&h->head.w, "decoder.head.out.weight", (int64_t)2 * nb * d);
@@ -897,6 +995,7 @@ int qa_hcodec_encode(qa_hcodec* h, const float* wav, int64_t B, int64_t T, const
     }
     int hop = 2;
     for (int i = 0; i < h->spec.n_ratios; ++i) hop *= h->spec.ratios[i];
+    if (h->spec.version == 20) hop = h->spec.hop * h->spec.frame_stride;
     QA_REQUIRE(B > 0 && T > 0 && T % hop == 0, "qa_hcodec_encode: wav is [%lld, %lld]; T must be a positive multiple of %d "
                "(HCodecTokenizer.pad_wav)", (long long)B, (long long)T, hop);
     QA_REQUIRE(B * T < (1LL << 31), "qa_hcodec_encode: batch of %lld x %lld samples is too large", (long long)B, (long long)T);
@@ -920,7 +1019,7 @@ int qa_hcodec_decode(qa_hcodec* h, const int64_t* ac, const int64_t* sc, int64_t
         return QA_ERR_INVALID;
     }
     QA_REQUIRE(B > 0 && N > 0, "qa_hcodec_decode: codes are [%lld, Q, %lld]", (long long)B, (long long)N);
-    QA_REQUIRE(B * N * 2 * (int64_t)h->spec.hop < (1LL << 31), "qa_hcodec_decode: output too large");
+    QA_REQUIRE(B * N * (h->spec.version == 20 ? h->spec.frame_stride : 2) * (int64_t)h->spec.hop < (1LL << 31), "qa_hcodec_decode: output too large");
     QA_REQUIRE(!h->spec.adaptive, "qa_hcodec_decode: this handle is an H-Codec 1.5 model, use qa_hcodec_decode_adaptive");
     QA_HIP(hipSetDevice(h->device));
     Ctx& c = h->ctx;

@@ -34,6 +34,7 @@ int launch_to_channel_last(const float* x, long long sb, long long sc, long long
                            hipStream_t s);
 int launch_codes_to_bqn(const long long* src, long long* dst, int B, int N, int Q, hipStream_t s);
 int launch_codes_from_bqn(const long long* src, long long* dst, int B, int N, int Q, hipStream_t s);
+int launch_stft_post(const float* ri, float* out, long long rows, int nb, int ldi, int ldo, hipStream_t s);
 int launch_istft_spec(const float* y, float* S, long long rows, int nb, int ldy, int ldS, hipStream_t s);
 int launch_istft_ola(const float* frames, const float* win, float* out, int B, int T, int n_fft, int hop, hipStream_t s);
 

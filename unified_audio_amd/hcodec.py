@@ -50,10 +50,24 @@ class HCodecSpec:
     bt_ff: int = 2048
     threshold: float = 0.6
     max_tokens_per_group: int = 8
+    # H-Codec 2.0 (QuarkAudio-HCodec/HCodec-2.0/conf/large_12.5hz_config.yaml); version 10 = SEANet family (1.0 / 1.5)
+    version: int = 10
+    enc_dim: int = 1536
+    enc_inter: int = 4608
+    enc_convnext_layers: int = 24
+    frame_stride: int = 4
+    tr_inter_cap: int = 0  # transformer MLP width = min(4 d, cap); 0 = 4 d
 
     @property
     def enc_hop(self) -> int:
+        """samples per code frame"""
+        if self.version == 20:
+            return self.hop * self.frame_stride
         return int(math.prod(self.ratios)) * 2
+
+    @property
+    def dec_upsample(self) -> int:
+        return self.frame_stride if self.version == 20 else 2
 
     def to_c(self) -> "_lib.qa_hcodec_spec":
         s = _lib.qa_hcodec_spec()
@@ -70,12 +84,18 @@ class HCodecSpec:
         s.adaptive, s.agg_layers, s.agg_heads, s.agg_ff = int(self.adaptive), self.agg_layers, self.agg_heads, self.agg_ff
         s.bt_layers, s.bt_heads, s.bt_ff = self.bt_layers, self.bt_heads, self.bt_ff
         s.max_tokens_per_group, s.threshold = self.max_tokens_per_group, self.threshold
+        s.version, s.enc_dim, s.enc_inter = self.version, self.enc_dim, self.enc_inter
+        s.enc_convnext_layers, s.frame_stride, s.tr_inter_cap = self.enc_convnext_layers, self.frame_stride, self.tr_inter_cap
         return s
 
 
 SPEC_10 = HCodecSpec()
 # H-Codec 1.5: SEANet stride order 8,5,4,2 (config lists [2,4,5,8], seanet.py:114 reverses it), XLSR features, decoder 1024
 SPEC_15 = HCodecSpec(ratios=(8, 5, 4, 2), sem_in=1024, sem_ch=1024, dec_dim=1024, dec_inter=2304, adaptive=True)
+# H-Codec 2.0: 48 kHz, 12.5 Hz frames, STFT/ConvNeXt encoder, 16 + 16 codebooks
+SPEC_20 = HCodecSpec(version=20, enc_dim=1536, enc_inter=4608, enc_convnext_layers=24, enc_layers=2, frame_stride=4,
+                     tr_inter_cap=4096, dimension=512, sem_in=768, sem_ch=1536, sem_strides=(2, 1, 2), num_quantizers=16,
+                     dec_dim=1536, dec_inter=4608, dec_heads=24, dec_layers=2, convnext_layers=32, n_fft=1920, hop=960)
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -138,6 +158,8 @@ class Codec:
     def encode(self, x: torch.Tensor, feat: torch.Tensor, use_mask=False, domain_split=None, threshold: float = 0.0):
         """codec.py:166-175.  x [B,1,T] fp32, feat [B, sem_in, N50] fp32 (any strides) -> two int64 [B, nq, N25]."""
         self._require_loaded()
+        if self.spec.version == 20 and x.dim() == 2:  # H-Codec 2.0 passes wav without the channel dim (audio_tokenizer.py:73)
+            x = x.unsqueeze(1)
         if x.dim() != 3 or x.shape[1] != 1:
             raise _lib.QuarkAudioError(-1, f"encode expects x of shape [B,1,T], got {tuple(x.shape)}")
         if feat.dim() != 3 or feat.shape[0] != x.shape[0] or feat.shape[1] != self.spec.sem_in:
@@ -182,7 +204,7 @@ class Codec:
             if c.numel() and (int(c.min()) < 0 or int(c.max()) >= self.spec.codebook_size):
                 raise IndexError(f"{name} out of range [0, {self.spec.codebook_size})")  # reference: F.embedding raises
         B, _, N = ac.shape
-        wav = torch.empty((B, N * 2 * self.spec.hop), dtype=torch.float32, device=self.device)
+        wav = torch.empty((B, N * self.spec.dec_upsample * self.spec.hop), dtype=torch.float32, device=self.device)
         _lib.check(self._lib.qa_hcodec_decode(self._handle, ac.data_ptr(), sc.data_ptr(), B, N, wav.data_ptr(),
                                               _stream_ptr(self.device)))
         return wav
