@@ -75,8 +75,31 @@ def run_case_15(name, seed, batch, samples, threshold):
     print(name, tuple(codes["acoustic_codes"].shape), tuple(rec.shape), "lens", (codes["semantic_codes"][0, 0] // 1024 + 1).tolist())
 
 
+SPEC20_SMALL = dict(enc_dim=256, enc_inter=512, enc_convnext_layers=2, enc_transformer_layers=1, dimension=128, sem_in=64, sem_ch=128,
+                    codebook_size=64, num_quantizers=5, dec_dim=256, dec_inter=512, dec_convnext_layers=2, dec_transformer_layers=1)
+
+
+def run_case_20(name, seed, batch, samples):
+    """H-Codec 2.0 built by the reference from a reduced YAML (same code path as the 1.28 B-parameter configuration)."""
+    from . import hcodec20_ref as R20
+
+    spec = R20.HCodec20Spec(**SPEC20_SMALL)
+    sd = synth.hcodec20_state_dict(seed, spec)
+    model = ref_shim.load_state(ref_shim.load_reference_codec("2.0", spec), sd)
+    wav = R.pad_wav(synth.synth_wav_fullband(seed + 1, batch, samples), spec.frame_hop)
+    feat = synth.synth_feat(seed + 2, batch, wav.shape[-1] // spec.hop, spec.sem_in)
+    with torch.no_grad():
+        ac, sc = model.encode(wav, feat)
+        rec = model.decode(ac, sc)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, batch=batch, samples=samples,
+                        acoustic_codes=ac.numpy().astype(np.int16), semantic_codes=sc.numpy().astype(np.int16),
+                        wav_rec=rec.numpy().astype(np.float32))
+    print(name, tuple(ac.shape), tuple(rec.shape))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    run_case_20("hcodec20_small_b2", 2000, 2, 3840 * 5 + 1000)
     for c in CASES:
         run_case(*c)
     for c in CASES_15:

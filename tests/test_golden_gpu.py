@@ -65,3 +65,29 @@ def test_hip_path_reproduces_reference_golden_15(qa_lib, gpu_device, path):
     assert rec.shape == g["wav_rec"].shape
     rms = float(np.sqrt(np.mean((rec - g["wav_rec"]) ** 2)))
     assert rms < 1e-3 and rms / float(np.sqrt(np.mean(g["wav_rec"] ** 2))) < 1e-4, rms
+
+
+def test_hip_path_reproduces_reference_golden_20(qa_lib, gpu_device):
+    """H-Codec 2.0 against vectors produced by the reference's vq.Codec built from a reduced YAML."""
+    import unified_audio_amd as qa
+    from oracle import hcodec20_ref as R20
+    from oracle.gen_golden import SPEC20_SMALL
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hcodec20_small_b2.npz"))
+    seed, o = int(g["seed"]), R20.HCodec20Spec(**SPEC20_SMALL)
+    sd = synth.hcodec20_state_dict(seed, o)
+    pspec = qa.HCodecSpec(version=20, enc_dim=o.enc_dim, enc_inter=o.enc_inter, enc_convnext_layers=o.enc_convnext_layers,
+                          enc_layers=o.enc_transformer_layers, frame_stride=o.stride, tr_inter_cap=o.tr_inter_cap, dimension=o.dimension,
+                          code_dim=o.dimension, sem_in=o.sem_in, sem_ch=o.sem_ch, sem_strides=o.sem_strides, codebook_size=o.codebook_size,
+                          num_quantizers=o.num_quantizers, dec_dim=o.dec_dim, dec_inter=o.dec_inter, dec_heads=o.dec_dim // 64,
+                          dec_layers=o.dec_transformer_layers, convnext_layers=o.dec_convnext_layers, n_fft=o.n_fft, hop=o.hop)
+    tok = qa.HCodecTokenizer(state_dict=sd, device=gpu_device, spec=pspec)
+    assert tok.hop_length == 3840  # int(sampling_rate / target_frame_rate), HCodec-2.0/audio_tokenizer.py:41
+    wav = synth.synth_wav_fullband(seed + 1, int(g["batch"]), int(g["samples"]))
+    feat = synth.synth_feat(seed + 2, int(g["batch"]), R.pad_wav(wav, 3840).shape[-1] // o.hop, o.sem_in)
+    ac, sc = tok.tokenize(wav.to(gpu_device), feats=feat.transpose(1, 2).contiguous().to(gpu_device))
+    ref_ac, ref_sc = torch.from_numpy(g["acoustic_codes"].astype(np.int64)), torch.from_numpy(g["semantic_codes"].astype(np.int64))
+    assert ac.shape == ref_ac.shape and (ac.cpu() == ref_ac).float().mean() > 0.95 and (sc.cpu() == ref_sc).float().mean() > 0.95
+    rec = tok.detokenize(ref_ac.to(gpu_device), ref_sc.to(gpu_device)).cpu().numpy()
+    assert rec.shape == g["wav_rec"].shape
+    assert float(np.sqrt(np.mean((rec - g["wav_rec"]) ** 2)) / np.sqrt(np.mean(g["wav_rec"] ** 2))) < 1e-4

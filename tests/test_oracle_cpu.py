@@ -153,3 +153,45 @@ def test_alignment_scan_rules():
     h[0, 5:, 0], h[0, 5:, 1] = 0.0, 1.0  # orthogonal from frame 5 on -> boundary at 5
     seg, nseg, _ = R15.similarity_alignment(h, 0.6, 8)
     assert seg[0].tolist() == [0] * 5 + [1] * 8 + [2] * 7 and int(nseg) == 3
+
+
+# ------------------------------------------------------------------------------------------- H-Codec 2.0
+def _spec20_small():
+    from oracle import hcodec20_ref as R20
+    from oracle.gen_golden import SPEC20_SMALL
+
+    return R20.HCodec20Spec(**SPEC20_SMALL)
+
+
+def test_oracle20_reproduces_reference_golden():
+    from oracle import hcodec20_ref as R20
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hcodec20_small_b2.npz"))
+    seed, spec = int(g["seed"]), _spec20_small()
+    sd = synth.hcodec20_state_dict(seed, spec)
+    wav = R.pad_wav(synth.synth_wav_fullband(seed + 1, int(g["batch"]), int(g["samples"])), spec.frame_hop)
+    feat = synth.synth_feat(seed + 2, int(g["batch"]), wav.shape[-1] // spec.hop, spec.sem_in)
+    with torch.no_grad():
+        ac, sc = R20.encode(sd, wav, feat, spec)
+        rec = R20.decode(sd, ac, sc, spec)
+    assert np.array_equal(ac.numpy(), g["acoustic_codes"].astype(np.int64)) and np.array_equal(sc.numpy(), g["semantic_codes"].astype(np.int64))
+    assert float(np.sqrt(np.mean((rec.numpy() - g["wav_rec"]) ** 2)) / np.sqrt(np.mean(g["wav_rec"] ** 2))) < 1e-5
+    assert rec.shape[-1] == wav.shape[-1] and wav.shape[-1] % 3840 == 0  # H20/test.wav -> wav_rec.wav length rule
+
+
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference is only mounted in the build container")
+def test_restatement20_matches_reference_modules():
+    from oracle import hcodec20_ref as R20
+
+    spec = _spec20_small()
+    sd = synth.hcodec20_state_dict(31, spec)
+    model = ref_shim.load_state(ref_shim.load_reference_codec("2.0", spec), sd)
+    ref_sd = model.state_dict()
+    assert not [k for k in ref_sd if k not in sd and not k.startswith("semantic_decoder.")] and not [k for k in sd if k not in ref_sd]
+    wav = synth.synth_wav_fullband(32, 2, 3840 * 4)
+    feat = synth.synth_feat(33, 2, wav.shape[-1] // spec.hop, spec.sem_in)
+    with torch.no_grad():
+        ac_r, sc_r = model.encode(wav, feat)
+        ac, sc = R20.encode(sd, wav, feat, spec)
+        assert torch.equal(ac, ac_r) and torch.equal(sc, sc_r)
+        assert float((R20.decode(sd, ac_r, sc_r, spec) - model.decode(ac_r, sc_r)).abs().max()) < 1e-5

@@ -788,7 +788,9 @@ int build(qa_hcodec* h, const HostTable& tab) {
                     const double wn = 0.5 - 0.5 * std::cos(2.0 * M_PI * n / Nf);
                     const double ang = 2.0 * M_PI * (double)(((int64_t)k * n) % Nf) / Nf;
                     basis[(size_t)k * Nf + n] = (float)(wn * std::cos(ang));
-                    basis[(size_t)(nbins + k) * Nf + n] = (float)(-wn * std::sin(ang));
+                    // DC and Nyquist bins are purely real: keep their imaginary rows at exactly +0 so that angle() of a negative
+                    // real value is +pi, as torch.stft's rfft returns it (a -0 / 1e-17 there flips the phase to -pi)
+                    basis[(size_t)(nbins + k) * Nf + n] = (k == 0 || 2 * k == Nf) ? 0.f : (float)(-wn * std::sin(ang));
                 }
             h->stft_basis.N = 2 * nbins; h->stft_basis.C_in = blk; h->stft_basis.ksize = 4;
             b.raw(&h->stft_basis.w, basis);  // [2*nb][4][blk] == [2*nb][n_fft]
