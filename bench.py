@@ -34,7 +34,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU (BASELINE metric: b=32)")
     ap.add_argument("--seconds", type=float, default=10.0, help="clip length (BASELINE configs[1]: 10 s)")
-    ap.add_argument("--model", choices=["1.5", "1.0"], default="1.5", help="H-Codec version (BASELINE configs[1] is 1.5)")
+    ap.add_argument("--model", choices=["1.5", "1.0", "2.0"], default="1.5",
+                    help="H-Codec version (BASELINE configs[1] is 1.5; 2.0 = configs[4]'s per-GPU share: use --batch 16 --seconds 30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=2, help="clips in the bounded CPU-baseline sample")
     ap.add_argument("--no-lm", action="store_true", help="skip the secondary UniSE AR-LM tokens/sec measurement")
@@ -159,22 +160,34 @@ def main():
     from oracle import synth
 
     lib = qa.load_library()
-    spec = R.SPEC_15 if args.model == "1.5" else R.SPEC_10
+    global SR
     log(f"generating seeded H-Codec {args.model} weights ...")
-    sd = synth.hcodec10_state_dict(1234, spec)
-    kw = {f: getattr(spec, f) for f in spec.__dataclass_fields__}
-    codec = qa.Codec(None, None, None, spec=qa.HCodecSpec(**kw), device=dev).load_state_dict(sd)
+    if args.model == "2.0":
+        from oracle import hcodec20_ref as R20
+
+        SR = 48000
+        spec = R20.SPEC_20
+        sd = synth.hcodec20_state_dict(1234, spec)
+        codec = qa.Codec(None, None, None, spec=qa.SPEC_20, device=dev).load_state_dict(sd)
+        hop_in, frame_hop = spec.hop, spec.frame_hop
+    else:
+        spec = R.SPEC_15 if args.model == "1.5" else R.SPEC_10
+        sd = synth.hcodec10_state_dict(1234, spec)
+        kw = {f: getattr(spec, f) for f in spec.__dataclass_fields__}
+        codec = qa.Codec(None, None, None, spec=qa.HCodecSpec(**kw), device=dev).load_state_dict(sd)
+        hop_in, frame_hop = 320, spec.enc_hop
+    adaptive = getattr(spec, "adaptive", False)
     n_params = sum(v.numel() for v in sd.values())
 
     B = args.batch
-    T = int(round(args.seconds * SR / spec.enc_hop)) * spec.enc_hop
+    T = int(round(args.seconds * SR / frame_hop)) * frame_hop
     # each rank draws its own shard of clips (weak scaling: B clips per GPU, no data-path collective)
-    wav = synth.synth_wav(7 + rank, B, T).to(dev)
-    feats = synth.synth_feat(9 + rank, B, T // 320, spec.sem_in).transpose(1, 2).contiguous().to(dev)  # [B, N50, C] as the SSL model emits
+    wav = (synth.synth_wav_fullband(7 + rank, B, T) if args.model == "2.0" else synth.synth_wav(7 + rank, B, T)).to(dev)
+    feats = synth.synth_feat(9 + rank, B, T // hop_in, spec.sem_in).transpose(1, 2).contiguous().to(dev)  # [B, N50, C] as the SSL model emits
     groups = [0]
 
     def step():
-        if spec.adaptive:
+        if adaptive:
             codes = codec.encode(wav.unsqueeze(1), feats.transpose(1, 2))
             groups[0] = codes["acoustic_codes"].shape[-1]
             return codec.decode(**codes)
@@ -237,8 +250,8 @@ def main():
             "dtype": "f32",
             "data": f"synthetic (seeded band-limited noise + tones; seeded random weights of the H-Codec {args.model} architecture)",
             "config": {"workload": f"H-Codec {args.model} Codec.encode+Codec.decode ({n_params / 1e6:.0f} M parameters"
-                                   + (f", 32-layer aggregators + bottleneck, threshold {spec.threshold}, {groups[0]} groups per clip" if spec.adaptive else "")
-                                   + f"), {B} clips x {T / SR:.0f} s @16 kHz per GPU, SSL features precomputed, inputs resident in HBM",
+                                   + (f", 32-layer aggregators + bottleneck, threshold {spec.threshold}, {groups[0]} groups per clip" if adaptive else "")
+                                   + f"), {B} clips x {T / SR:.0f} s @{SR // 1000} kHz per GPU, SSL features precomputed, inputs resident in HBM",
                        "clips_per_gpu": B, "clip_seconds": T / SR, "parallelism": f"dp{world} (independent clips, no collective)"},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": None,
@@ -247,7 +260,9 @@ def main():
         }
         if lm_line is not None:
             line["unise_lm"] = lm_line
-        if world == 1 and not args.no_cpu_baseline:
+        if args.model == "2.0":
+            line["metric"] = "audio-seconds/sec H-Codec 2.0 encode+decode @48kHz (BASELINE configs[4], per-GPU share)"
+        if world == 1 and not args.no_cpu_baseline and args.model != "2.0":
             log("cpu baseline ...")
             line["cpu_baseline"] = cpu_baseline(args.cpu_clips, args.seconds, model=args.model)
             if line["cpu_baseline"]["value"]:
