@@ -235,6 +235,16 @@ def main():
                 cfgs.append({"kernel": name, "launches_per_step": n / args.steps, "avg_us": 1e3 * ms / n,
                              "tflops": fl / (ms * 1e-3) / 1e12, "share_of_step_time": ms * 1e-3 / elapsed})
         dom = max(cfgs, key=lambda c: c["share_of_step_time"])
+        # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950
+        # correction, + WRITE_SIZE) over this same command, summarised under profiles/ (PMC cannot be sampled from inside the run)
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic_hcodec15.json")
+        if args.model == "1.5" and B == 32 and abs(args.seconds - 10.0) < 1e-6 and os.path.exists(pmc_file):
+            want = dom["kernel"].replace("conv_gemm_kernel<", "").rstrip(">").replace(",", ", ")
+            for k, v in json.load(open(pmc_file)).items():
+                if f"conv_gemm_kernel<{want}, false>" in k:
+                    traffic, traffic_src = v["hbm_bytes_per_launch"], "profiles/r01_d_hcodec15_pmc_hbm_mfma.md (2*FETCH_SIZE + WRITE_SIZE, per launch)"
+                    mfma_busy = v["mfma_busy_frac"]
         gemm_ms = sum(prof[3 * i + 1] for i in range(3))
         line = {
             "metric": "audio-seconds/sec H-Codec encode+decode @16kHz b=32",
@@ -254,7 +264,8 @@ def main():
                                    + f"), {B} clips x {T / SR:.0f} s @{SR // 1000} kHz per GPU, SSL features precomputed, inputs resident in HBM",
                        "clips_per_gpu": B, "clip_seconds": T / SR, "parallelism": f"dp{world} (independent clips, no collective)"},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
                          "gemm_share_of_step_time": gemm_ms * 1e-3 / elapsed, "all_gemm_configs": cfgs},
         }
