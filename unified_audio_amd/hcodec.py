@@ -109,7 +109,8 @@ class Codec:
     through `load_state_dict` in the reference's own key layout (weight_g / weight_v, `layers.{q}._codebook.embed`).
     """
 
-    def __init__(self, encoder_kwargs=None, decoder_kwargs=None, quantizer_kwargs=None, *, spec: HCodecSpec = SPEC_10,
+    def __init__(self, encoder_kwargs=None, decoder_kwargs=None, quantizer_kwargs=None, adaptive_kwargs=None,
+                 semantic_decoder_kwargs=None, *, spec: HCodecSpec = SPEC_10,
                  device: str | torch.device = "cuda:0"):
         self.spec = spec
         self.device = torch.device(device)
