@@ -220,6 +220,22 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(out).all()
 
+    # secondary: the same step with host (pageable) tensors in and out, as HCodecTokenizer's __main__ moves them
+    # (audio_tokenizer.py:79,84: wav.to(device) ... wav_rec.cpu()); never `value`
+    wav_h, feats_h = wav.cpu(), feats.cpu()
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for _ in range(2):
+        w_d, f_d = wav_h.to(dev), feats_h.to(dev)
+        if adaptive:
+            codes = codec.encode(w_d.unsqueeze(1), f_d.transpose(1, 2))
+            rec_h = codec.decode(**{k: v.cpu().to(dev) for k, v in codes.items()}).cpu()
+        else:
+            a_, s_ = codec.encode(w_d.unsqueeze(1), f_d.transpose(1, 2))
+            rec_h = codec.decode(a_.cpu().to(dev), s_.cpu().to(dev)).cpu()
+    pcie_elapsed = (time.perf_counter() - t1) / 2
+    del rec_h
+
     lm_line = None
     if not args.no_lm:
         del out
@@ -269,6 +285,8 @@ def main():
                          "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
                          "gemm_share_of_step_time": gemm_ms * 1e-3 / elapsed, "all_gemm_configs": cfgs},
         }
+        line["pcie_inclusive"] = {"value": B * T / SR / pcie_elapsed, "unit": "audio-seconds/sec", "ms_per_step": 1e3 * pcie_elapsed,
+                                  "note": "rank-0 only: wav+features H2D from pageable memory, codes D2H+H2D, waveform D2H included"}
         if lm_line is not None:
             line["unise_lm"] = lm_line
         if args.model == "2.0":
