@@ -1,0 +1,24 @@
+#!/usr/bin/env python
+"""UniSE LM generate micro-benchmark (B segments, SE prompt 252, 33 + 250 greedy steps)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import unified_audio_amd as qa  # noqa: E402
+from oracle import llm_ref as L  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+dev = torch.device("cuda:0")
+lm = qa.LLM_SFT(device=dev).load_state_dict(L.lm_state_dict(4321))
+mix = L.synth_feats(50, B, 250).to(dev)
+mel = torch.zeros(B, 250, 80)
+for i in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g, s = lm.generate("se", None, None, mel, mix, do_sample=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"B={B} generate {dt * 1e3:.1f} ms  {B * 283 / dt:.0f} tok/s", flush=True)

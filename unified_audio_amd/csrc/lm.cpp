@@ -22,7 +22,9 @@ int launch_argmax(const float* logits, int B, int width, long long ld, int lo, l
                   long long ids_ld, int col, hipStream_t s);
 int launch_skinny_gemm(const float* x, long long ldx, const float* w, const float* bias, const float* gate,
                        long long ldg, const float* res, long long ldr, float* y, long long ldy, int M, int N, int K,
-                       int act, hipStream_t s);
+                       int act, hipStream_t s, float rms_eps, int dual);
+int launch_rope_kv(float* qkv, const float* cs, float* kc, float* vc, int B, int n, int H, int hd, int pos0, int max_len,
+                   hipStream_t s);
 int launch_attention_decode(const float* q, long long ldq, const float* kc, const float* vc, long long kv_bstride,
                             long long ldkv, float* out, long long ldo, int B, int H, int hd, int n_keys, float scale,
                             hipStream_t s);
@@ -32,8 +34,9 @@ using namespace qa;
 
 namespace {
 struct LMLayer {
-    const float *ln1 = nullptr, *ln2 = nullptr;
+    // RMSNorm weights are folded into the consuming projections (W' = W diag(w)): qkv <- input_layernorm, gate/up <- post_attention_layernorm
     ConvW qkv, o, gate, up, down;
+    const float* gate_up = nullptr;  // decode layout: per 16-column group 16 gate rows then 16 up rows (both norm-folded)
 };
 constexpr int LM_MAX_POS = 4096;  // max_position_embeddings (conf/config.yaml:146)
 }  // namespace
@@ -42,8 +45,8 @@ struct qa_lm {
     qa_lm_spec spec{};
     int device = 0;
     WeightStore store;
-    const float *task_emb = nullptr, *enroll_sos = nullptr, *mix_sos = nullptr, *codec_emb = nullptr, *norm = nullptr,
-                *rope = nullptr;
+    const float *task_emb = nullptr, *enroll_sos = nullptr, *mix_sos = nullptr, *codec_emb = nullptr, *ones = nullptr,
+                *rope = nullptr;  // `ones`: unit RMSNorm weight (the learned ones are folded into the projections)
     ConvW adapter, head;
     std::vector<LMLayer> layers;
     char* ws = nullptr;
@@ -56,13 +59,16 @@ namespace {
 int vocab_of(const qa_lm_spec& s) { return 3 + s.global_size + s.semantic_size; }
 
 // y[rows, N] = epi(x[rows, K] W^T): skinny kernel for decode-sized M, implicit GEMM otherwise
+bool skinny_ok(int64_t rows, const ConvW& w) { return rows <= 32 && w.C_in % 256 == 0; }
+
 int lm_linear(Ctx& c, const float* x, int64_t rows, const ConvW& w, float* y, const float* res = nullptr,
-              const float* gate = nullptr, int n_rows_w = -1, const float* w_ptr = nullptr) {
+              const float* gate = nullptr, int n_rows_w = -1, const float* w_ptr = nullptr, float rms_eps = 0.f) {
     if (c.dry) return QA_OK;
     const int N = n_rows_w >= 0 ? n_rows_w : w.N;
     const float* wp = w_ptr ? w_ptr : w.w;
-    if (rows <= 32 && w.C_in % 256 == 0)
-        return launch_skinny_gemm(x, w.C_in, wp, w.b, gate, N, res, N, y, N, (int)rows, N, w.C_in, ACT_NONE, c.stream);
+    if (skinny_ok(rows, w))
+        return launch_skinny_gemm(x, w.C_in, wp, w.b, gate, N, res, N, y, N, (int)rows, N, w.C_in, ACT_NONE, c.stream, rms_eps, 0);
+    QA_REQUIRE(rms_eps == 0.f, "lm_linear: fused RMSNorm is only available on the skinny path");
     qa_conv_args a{};
     a.x = x; a.w = wp; a.bias = w.b; a.residual = res; a.gate = gate; a.y = y;
     a.B = 1; a.T_in = rows; a.C_in = w.C_in; a.T_out = rows; a.N = N;
@@ -95,33 +101,65 @@ int build_lm(qa_lm* lm, const HostTable& tab) {
     vec(&lm->enroll_sos, "enroll_sos_embedding.weight", d);
     vec(&lm->mix_sos, "mix_sos_embedding.weight", d);
     vec(&lm->codec_emb, "codec_embedding.weight", (int64_t)V * d);
-    vec(&lm->norm, "norm.weight", d);
+    {
+        std::vector<float> ones(d, 1.0f);
+        pend.push_back({&lm->ones, st.add(ones)});
+    }
+    // fold W' = W diag(w_norm): rows of W scaled column-wise by the RMSNorm weight that precedes the projection
+    auto folded = [&](const std::string& wname, int64_t rows, const float* nw, std::vector<float>* out) -> bool {
+        const float* w = tab.get(wname, rows * d);
+        if (!w || !nw) return false;
+        out->resize((size_t)rows * d);
+        for (int64_t r = 0; r < rows; ++r)
+            for (int k = 0; k < d; ++k) (*out)[(size_t)r * d + k] = w[r * d + k] * nw[k];
+        return true;
+    };
     lm->adapter.N = d; lm->adapter.C_in = sp.feats_dim;
     vec(&lm->adapter.w, "adapter.weight", (int64_t)d * sp.feats_dim);
     vec(&lm->adapter.b, "adapter.bias", d);
     lm->head.N = V; lm->head.C_in = d;
-    vec(&lm->head.w, "output_head.weight", (int64_t)V * d);
+    {
+        std::vector<float> hw;
+        if (folded("output_head.weight", V, tab.get("norm.weight", d), &hw)) pend.push_back({&lm->head.w, st.add(hw)});
+        else ok = false;
+    }
     lm->layers.resize(sp.n_layers);
     for (int i = 0; i < sp.n_layers; ++i) {
         LMLayer& L = lm->layers[i];
         const std::string p = "layers." + std::to_string(i);
-        vec(&L.ln1, p + ".input_layernorm.weight", d);
-        vec(&L.ln2, p + ".post_attention_layernorm.weight", d);
+        const float* ln1 = tab.get(p + ".input_layernorm.weight", d);
+        const float* ln2 = tab.get(p + ".post_attention_layernorm.weight", d);
+        if (!ln1 || !ln2) ok = false;
         std::vector<float> wq((size_t)3 * d * d, 0.f);
         const char* nm[3] = {".self_attn.q_proj.weight", ".self_attn.k_proj.weight", ".self_attn.v_proj.weight"};
         for (int j = 0; j < 3; ++j) {
-            const float* w = tab.get(p + nm[j], (int64_t)d * d);
-            if (!w) ok = false;
-            else std::memcpy(&wq[(size_t)j * d * d], w, sizeof(float) * d * d);
+            std::vector<float> f;
+            if (!folded(p + nm[j], d, ln1, &f)) ok = false;
+            else std::memcpy(&wq[(size_t)j * d * d], f.data(), sizeof(float) * d * d);
         }
         L.qkv.N = 3 * d; L.qkv.C_in = d;
         pend.push_back({&L.qkv.w, st.add(wq)});
         L.o.N = d; L.o.C_in = d;
         vec(&L.o.w, p + ".self_attn.o_proj.weight", (int64_t)d * d);
         L.gate.N = I; L.gate.C_in = d;
-        vec(&L.gate.w, p + ".mlp.gate_proj.weight", (int64_t)I * d);
         L.up.N = I; L.up.C_in = d;
-        vec(&L.up.w, p + ".mlp.up_proj.weight", (int64_t)I * d);
+        {
+            std::vector<float> g, u;
+            if (folded(p + ".mlp.gate_proj.weight", I, ln2, &g) && folded(p + ".mlp.up_proj.weight", I, ln2, &u)) {
+                pend.push_back({&L.gate.w, st.add(g)});
+                pend.push_back({&L.up.w, st.add(u)});
+                if (I % 16 == 0) {  // decode layout for the dual-accumulator skinny kernel
+                    std::vector<float> gu((size_t)2 * I * d);
+                    for (int blk = 0; blk < I / 16; ++blk) {
+                        std::memcpy(&gu[(size_t)(blk * 32) * d], &g[(size_t)(blk * 16) * d], sizeof(float) * 16 * d);
+                        std::memcpy(&gu[(size_t)(blk * 32 + 16) * d], &u[(size_t)(blk * 16) * d], sizeof(float) * 16 * d);
+                    }
+                    pend.push_back({&L.gate_up, st.add(gu)});
+                }
+            } else {
+                ok = false;
+            }
+        }
         L.down.N = d; L.down.C_in = I;
         vec(&L.down.w, p + ".mlp.down_proj.weight", (int64_t)I * d);
     }
@@ -161,11 +199,16 @@ int lm_body(qa_lm* lm, Ctx& c, LMBuffers& b, int B, int n, int pos0, int max_len
         float* kc = b.kc + i * cache_stride;
         float* vc = b.vc + i * cache_stride;
         if (!c.dry) {
-            QA_TRY(launch_rmsnorm(b.x, L.ln1, b.hn, rows, d, sp.rms_eps, c.stream));
-            QA_TRY(lm_linear(c, b.hn, rows, L.qkv, b.qkv));
-            QA_TRY(launch_rope(b.qkv, lm->rope, B, n, H, hd, 3 * d, pos0, c.stream));
-            QA_TRY(launch_kv_store(b.qkv, kc, vc, B, n, pos0, max_len, d, c.stream));
-            if (skip_last_mlp && i == sp.n_layers - 1) break;  // prefill: only the KV cache of the last layer is consumed
+            const bool last = skip_last_mlp && i == sp.n_layers - 1;  // prefill: only the KV cache of the last layer is consumed
+            const bool dec = skinny_ok(rows, L.qkv);                   // decode step: norms fused into the weight-streaming GEMMs
+            if (dec) {
+                QA_TRY(lm_linear(c, b.x, rows, L.qkv, b.qkv, nullptr, nullptr, -1, nullptr, sp.rms_eps));
+            } else {
+                QA_TRY(launch_rmsnorm(b.x, lm->ones, b.hn, rows, d, sp.rms_eps, c.stream));
+                QA_TRY(lm_linear(c, b.hn, rows, L.qkv, b.qkv));
+            }
+            QA_TRY(launch_rope_kv(b.qkv, lm->rope, kc, vc, B, n, H, hd, pos0, max_len, c.stream));
+            if (last) break;
             if (n == 1)
                 QA_TRY(launch_attention_decode(b.qkv, 3 * d, kc, vc, (long long)max_len * d, d, b.att, d, B, H, hd, pos0 + 1,
                                                scale, c.stream));
@@ -173,9 +216,14 @@ int lm_body(qa_lm* lm, Ctx& c, LMBuffers& b, int B, int n, int pos0, int max_len
                 QA_TRY(launch_attention(b.qkv, 3 * d, kc, vc, d, b.att, d, B, n, pos0 + n, (long long)max_len * d, H, hd, scale,
                                         1, c.stream));
             QA_TRY(lm_linear(c, b.att, rows, L.o, b.x, b.x));
-            QA_TRY(launch_rmsnorm(b.x, L.ln2, b.hn, rows, d, sp.rms_eps, c.stream));
-            QA_TRY(lm_linear(c, b.hn, rows, L.gate, b.g));
-            QA_TRY(lm_linear(c, b.hn, rows, L.up, b.u, nullptr, b.g));
+            if (dec && L.gate_up) {
+                QA_TRY(launch_skinny_gemm(b.x, d, L.gate_up, nullptr, nullptr, 0, nullptr, 0, b.u, L.gate.N, (int)rows, L.gate.N, d,
+                                          ACT_NONE, c.stream, sp.rms_eps, 1));
+            } else {
+                QA_TRY(launch_rmsnorm(b.x, lm->ones, b.hn, rows, d, sp.rms_eps, c.stream));
+                QA_TRY(lm_linear(c, b.hn, rows, L.gate, b.g));
+                QA_TRY(lm_linear(c, b.hn, rows, L.up, b.u, nullptr, b.g));
+            }
             QA_TRY(lm_linear(c, b.u, rows, L.down, b.x, b.x));
         }
     }
@@ -220,9 +268,14 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
         for (int st = 0; st < steps; ++st, ++pos) {
             QA_TRY(launch_embed(b.tok, lm->codec_emb, b.x, B, d, c.stream));
             QA_TRY(lm_body(lm, c, b, B, 1, pos, max_len, false));
-            QA_TRY(launch_rmsnorm(b.x, lm->norm, b.hn, B, d, sp.rms_eps, c.stream));
-            // only the rows of output_head inside the active vocabulary slice are multiplied (the mask sets the rest to -inf)
-            QA_TRY(lm_linear(c, b.hn, B, lm->head, b.logits, nullptr, nullptr, width, lm->head.w + (size_t)lo * d));
+            // final RMSNorm fused (its weight is folded into output_head); only the rows of output_head inside the active
+            // vocabulary slice are multiplied (the mask sets the rest to -inf)
+            if (skinny_ok(B, lm->head)) {
+                QA_TRY(lm_linear(c, b.x, B, lm->head, b.logits, nullptr, nullptr, width, lm->head.w + (size_t)lo * d, sp.rms_eps));
+            } else {
+                QA_TRY(launch_rmsnorm(b.x, lm->ones, b.hn, B, d, sp.rms_eps, c.stream));
+                QA_TRY(lm_linear(c, b.hn, B, lm->head, b.logits, nullptr, nullptr, width, lm->head.w + (size_t)lo * d));
+            }
             QA_TRY(launch_argmax(b.logits, B, width, width, lo, b.tok, st < keep ? ids : nullptr, ids_ld, st, c.stream));
         }
         return QA_OK;
