@@ -11,6 +11,10 @@ from tests.util import conv1d_cl  # noqa: E402
 from unified_audio_amd import load_library  # noqa: E402
 
 SHAPES = [  # name, M(rows), N, Cin, k, stride
+    ("cal.4096^3", 4096, 4096, 4096, 1, 1), ("cal.8192x4096x4096", 8192, 4096, 4096, 1, 1), ("cal.16384x1024x2048", 16384, 1024, 2048, 1, 1),
+    ("mimi.in_proj", 9056, 1536, 512, 1, 1), ("mimi.out_proj", 9056, 512, 512, 1, 1), ("mimi.lin1", 9056, 2048, 512, 1, 1),
+    ("mimi.lin2", 9056, 512, 2048, 1, 1), ("bt.in_proj", 8000, 3072, 1024, 1, 1), ("bt.lin1", 8000, 2048, 1024, 1, 1),
+    ("bt.lin2", 8000, 1024, 2048, 1, 1),
     ("convnext.pw1", 16000, 2304, 768, 1, 1), ("convnext.pw2", 16000, 768, 2304, 1, 1),
     ("dec.k3", 16000, 768, 768, 3, 1), ("dec.lstm_ih", 16000, 3072, 768, 1, 1), ("dec.qkv", 16000, 2304, 768, 1, 1),
     ("dec.w2", 16000, 768, 3072, 1, 1), ("enc.lstm_ih", 16000, 2048, 512, 1, 1), ("enc.o", 16000, 512, 512, 1, 1),
@@ -24,7 +28,10 @@ def main():
     lib = load_library()
     dev = torch.device("cuda:0")
     tot_t = tot_f = 0.0
+    only = os.environ.get("QA_BENCH_ONLY")
     for name, M, N, C, k, s in SHAPES:
+        if only and not any(name.startswith(o) for o in only.split(",")):
+            continue
         T = M * s  # one batch item; zero padding, enough frames for M outputs
         x = torch.randn(1, T + k, C, device=dev)
         w = torch.randn(N, k, C, device=dev) * 0.05

@@ -20,13 +20,13 @@ namespace qa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int BM, int BN, int WM, int WN, bool PRO_ELU>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p) {
-    constexpr int BK = 32;
+template <int BM, int BN, int WM, int WN, bool PRO_ELU, int BK = 32>
+__global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(const ConvParams p) {
     constexpr int LDS = BK + 4;
+    constexpr int RPP = 256 / (BK / 4);  // rows staged per pass: 8 (BK=32) or 4 (BK=16) threads cover one row chunk
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;
+    constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
 
@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p) {
     const int m0 = (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * BN;
 
-    const int ld_row = tid >> 3;       // 0..31
-    const int ld_c4 = (tid & 7) * 4;   // float offset inside the 32-wide K chunk
+    const int ld_row = tid / (BK / 4);          // 0..RPP-1
+    const int ld_c4 = (tid % (BK / 4)) * 4;     // float offset inside the BK-wide K chunk
 
     // Per-thread A rows: batch base offset and first source frame.  Rows past M are clamped to row M-1 and columns past
     // N to column N-1 (their results are never stored), so every load below is unconditional: hipcc would otherwise
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p) {
     int a_t0[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int m = min(m0 + ld_row + 32 * i, p.M - 1);
+        const int m = min(m0 + ld_row + RPP * i, p.M - 1);
         const int b = m / p.T_out;
         const int t = m - b * p.T_out;
         a_base[i] = (long long)b * p.T_in * p.ldx + ld_c4;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p) {
     const float* b_ptr[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int n = min(n0 + ld_row + 32 * i, p.N - 1);
+        const int n = min(n0 + ld_row + RPP * i, p.N - 1);
         b_ptr[i] = p.w + (long long)n * p.K + ld_c4;
     }
 
@@ -119,10 +119,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p) {
             if (PRO_ELU) {                                                                                     \
                 v.x = elu_f(v.x); v.y = elu_f(v.y); v.z = elu_f(v.z); v.w = elu_f(v.w);                        \
             }                                                                                                  \
-            *reinterpret_cast<float4*>(a_ + (ld_row + 32 * i) * LDS + ld_c4) = v;                              \
+            *reinterpret_cast<float4*>(a_ + (ld_row + RPP * i) * LDS + ld_c4) = v;                             \
         }                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < B_IT; ++i)                                                       \
-            *reinterpret_cast<float4*>(b_ + (ld_row + 32 * i) * LDS + ld_c4) = b_reg[i];                       \
+            *reinterpret_cast<float4*>(b_ + (ld_row + RPP * i) * LDS + ld_c4) = b_reg[i];                      \
     }
 
     QA_LOAD_GLOBAL(0)
@@ -145,9 +145,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; kk < BK / 8; ++kk) {
                 const int cb = kk & 1, nb = cb ^ 1;
-                if (kk < 3) {
+                if (kk < BK / 8 - 1) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
                         af[nb][i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS + (kk + 1) * 8);
@@ -207,7 +207,16 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
         const double n = p.algo_n ? p.algo_n : p.N, k = p.algo_k ? p.algo_k : p.K;
         profile_record_begin(cfg, 2.0 * (double)p.M * n * k, stream);
     }
-    if (p.prologue == ACT_ELU)
+    // Short-K layers (K <= 512: 16 chunks or fewer per tile) are dominated by per-tile fixed costs; the BK = 16 variant needs
+    // 41 KB / 31 KB of LDS, so 3-4 workgroups are co-resident per CU and cover each other's prologue / epilogue
+    // (measured on M = 9056, K = 512: +10 % for N = 1536, +25 % for N = 2048; neutral from K = 1024 up).
+    static const int bk16_max_k = [] {
+        const char* e = getenv("QA_GEMM_BK16");
+        return e ? atoi(e) : 512;
+    }();
+    if (BN >= 64 && p.prologue != ACT_ELU && p.K <= bk16_max_k)
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, (BN >= 64 ? 16 : 32)>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
+    else if (p.prologue == ACT_ELU)
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
     else
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
