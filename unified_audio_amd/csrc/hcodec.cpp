@@ -96,6 +96,8 @@ struct qa_hcodec {
     MimiW agg_sem, agg_ac, bottleneck;
     const float *qemb_sem = nullptr, *qemb_ac = nullptr;
     int* host_sync = nullptr;  // pinned host scalar for the data-dependent group / frame counts
+    hipStream_t side = nullptr;  // second stream: the two aggregator stacks are independent and run concurrently
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // workspace
     char* ws = nullptr;
     size_t ws_cap = 0;
@@ -382,26 +384,54 @@ int transformer_op(Ctx& c, const TransformerW& tw, float* x, int B, int N, const
 }
 
 // StreamingTransformer.forward, non-causal / non-streaming (mimi/transformer.py:377-425,553-594,674-698), in place on x
-int mimi_op(Ctx& c, const MimiW& mw, float* x, int B, int N) {
+struct MimiTemps {
+    float *hn, *qkv, *att, *u;
+};
+MimiTemps mimi_temps(Ctx& c, const MimiW& mw, int64_t rows) {
+    MimiTemps t;
+    t.hn = c.arena.alloc<float>(rows * mw.d);
+    t.qkv = c.arena.alloc<float>(rows * 3 * mw.d);
+    t.att = c.arena.alloc<float>(rows * mw.d);
+    t.u = c.arena.alloc<float>(rows * mw.ff);
+    return t;
+}
+int mimi_layer(Ctx& c, const MimiW& mw, const MimiLayerW& L, float* x, const MimiTemps& t, int B, int N) {
     const int d = mw.d, H = mw.heads, hd = d / H;
     const int64_t rows = (int64_t)B * N;
+    QA_TRY(launch_layernorm(x, L.n1w, L.n1b, t.hn, rows, d, 1e-5f, c.stream));
+    QA_TRY(linear_op(c, t.hn, rows, L.in_proj, t.qkv));
+    QA_TRY(launch_rope(t.qkv, mw.rope, B, N, H, hd, 3 * d, 0, c.stream, 1));
+    QA_TRY(launch_attention(t.qkv, 3 * d, t.qkv + d, t.qkv + 2 * d, 3 * d, t.att, d, B, N, N, (long long)N * 3 * d, H, hd,
+                            1.0f / std::sqrt((float)hd), 0, c.stream));
+    QA_TRY(linear_op(c, t.att, rows, L.out_proj, x, ACT_NONE, x, nullptr, L.ls1));
+    QA_TRY(launch_layernorm(x, L.n2w, L.n2b, t.hn, rows, d, 1e-5f, c.stream));
+    QA_TRY(linear_op(c, t.hn, rows, L.lin1, t.u, ACT_GELU));
+    return linear_op(c, t.u, rows, L.lin2, x, ACT_NONE, x, nullptr, L.ls2);
+}
+int mimi_op(Ctx& c, const MimiW& mw, float* x, int B, int N) {
     QA_REQUIRE(N <= MAX_POS, "mimi transformer: sequence of %d tokens exceeds %d", N, MAX_POS);
     const size_t mark = c.arena.mark();
-    float* hn = c.arena.alloc<float>(rows * d);
-    float* qkv = c.arena.alloc<float>(rows * 3 * d);
-    float* att = c.arena.alloc<float>(rows * d);
-    float* u = c.arena.alloc<float>(rows * mw.ff);
+    const MimiTemps t = mimi_temps(c, mw, (int64_t)B * N);
+    if (!c.dry)
+        for (const MimiLayerW& L : mw.layers) QA_TRY(mimi_layer(c, mw, L, x, t, B, N));
+    c.arena.release(mark);
+    return QA_OK;
+}
+// two independent stacks of equal depth, layer-interleaved on two streams (xa on the caller's stream, xb on `side`)
+int mimi_pair_op(Ctx& c, hipStream_t side, const MimiW& wa, float* xa, const MimiW& wb, float* xb, int B, int N) {
+    QA_REQUIRE(N <= MAX_POS && wa.layers.size() == wb.layers.size(), "mimi pair: mismatched stacks");
+    const size_t mark = c.arena.mark();
+    const MimiTemps ta = mimi_temps(c, wa, (int64_t)B * N);
+    const MimiTemps tb = mimi_temps(c, wb, (int64_t)B * N);
     if (!c.dry) {
-        for (const MimiLayerW& L : mw.layers) {
-            QA_TRY(launch_layernorm(x, L.n1w, L.n1b, hn, rows, d, 1e-5f, c.stream));
-            QA_TRY(linear_op(c, hn, rows, L.in_proj, qkv));
-            QA_TRY(launch_rope(qkv, mw.rope, B, N, H, hd, 3 * d, 0, c.stream, 1));
-            QA_TRY(launch_attention(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, B, N, N, (long long)N * 3 * d, H, hd,
-                                    1.0f / std::sqrt((float)hd), 0, c.stream));
-            QA_TRY(linear_op(c, att, rows, L.out_proj, x, ACT_NONE, x, nullptr, L.ls1));
-            QA_TRY(launch_layernorm(x, L.n2w, L.n2b, hn, rows, d, 1e-5f, c.stream));
-            QA_TRY(linear_op(c, hn, rows, L.lin1, u, ACT_GELU));
-            QA_TRY(linear_op(c, u, rows, L.lin2, x, ACT_NONE, x, nullptr, L.ls2));
+        hipStream_t main = c.stream;
+        for (size_t l = 0; l < wa.layers.size(); ++l) {
+            c.stream = main;
+            int st = mimi_layer(c, wa, wa.layers[l], xa, ta, B, N);
+            c.stream = side;
+            if (st == QA_OK) st = mimi_layer(c, wb, wb.layers[l], xb, tb, B, N);
+            c.stream = main;
+            QA_TRY(st);
         }
     }
     c.arena.release(mark);
@@ -685,18 +715,26 @@ int encode_adaptive_graph(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, 
     }
     *G_out = G;
     const int S = N + G;
-    float* inter = c.arena.alloc<float>((size_t)B * S * D);
+    float* inter_s = c.arena.alloc<float>((size_t)B * S * D);
+    float* inter_a = c.arena.alloc<float>((size_t)B * S * D);
     float* agg_a = c.arena.alloc<float>((size_t)B * G * D);
     float* agg_s = c.arena.alloc<float>((size_t)B * G * D);
-    // semantic_aggregator(sem), acoustic_aggregator(emb): both use the alignment of the semantic stream
-    if (!c.dry) QA_TRY(launch_agg_build(sem, seg, start, len, nseg, h->qemb_sem, inter, B, N, G, D, c.stream));
-    QA_TRY(mimi_op(c, h->agg_sem, inter, B, S));
+    // semantic_aggregator(sem), acoustic_aggregator(emb): both use the alignment of the semantic stream and are otherwise
+    // independent, so the two 32-layer stacks run concurrently on two streams (fork / join with events; no host sync)
     if (!c.dry) {
-        QA_TRY(launch_agg_gather(inter, start, len, nseg, agg_s, B, N, G, D, c.stream));
-        QA_TRY(launch_agg_build(emb, seg, start, len, nseg, h->qemb_ac, inter, B, N, G, D, c.stream));
+        QA_TRY(launch_agg_build(sem, seg, start, len, nseg, h->qemb_sem, inter_s, B, N, G, D, c.stream));
+        QA_TRY(launch_agg_build(emb, seg, start, len, nseg, h->qemb_ac, inter_a, B, N, G, D, c.stream));
+        QA_HIP(hipEventRecord(h->ev_fork, c.stream));
+        QA_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     }
-    QA_TRY(mimi_op(c, h->agg_ac, inter, B, S));
-    if (!c.dry) QA_TRY(launch_agg_gather(inter, start, len, nseg, agg_a, B, N, G, D, c.stream));
+    QA_TRY(mimi_pair_op(c, h->side, h->agg_sem, inter_s, h->agg_ac, inter_a, B, S));
+    if (!c.dry) {
+        hipStream_t main = c.stream;
+        QA_TRY(launch_agg_gather(inter_s, start, len, nseg, agg_s, B, N, G, D, main));
+        QA_TRY(launch_agg_gather(inter_a, start, len, nseg, agg_a, B, N, G, D, h->side));
+        QA_HIP(hipEventRecord(h->ev_join, h->side));
+        QA_HIP(hipStreamWaitEvent(main, h->ev_join, 0));
+    }
     c.tap("enc.emb_agg", agg_a, (int64_t)B * G * D);
     c.tap("enc.sem_agg", agg_s, (int64_t)B * G * D);
     long long* ia = c.arena.alloc<long long>((size_t)B * G * Q);
@@ -939,6 +977,9 @@ int build(qa_hcodec* h, const HostTable& tab) {
     }
     if (!b.f.ok) return b.f.status;
     QA_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->host_sync), sizeof(int) * 4));
+    QA_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    QA_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    QA_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     QA_TRY(h->store.upload());
     b.resolve();
     // |e|^2 tables
@@ -986,6 +1027,9 @@ void qa_hcodec_destroy(qa_hcodec* h) {
     if (h->e2_dev) (void)hipFree(h->e2_dev);
     if (h->ws) (void)hipFree(h->ws);
     if (h->host_sync) (void)hipHostFree(h->host_sync);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
 }
 
