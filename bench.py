@@ -220,6 +220,17 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(out).all()
 
+    # the same kernels with the library's internal stream concurrency switched off (every launch alone on the device):
+    # what a kernel achieves by itself, as opposed to while it shares the CUs with the other stream's kernels
+    iso = (C.c_double * 9)()
+    _lib.check(lib.qa_set_serial(1))
+    _lib.check(lib.qa_profile_begin())
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(dev)
+    _lib.check(lib.qa_profile_end(iso, 9))
+    _lib.check(lib.qa_set_serial(0))
+
     # secondary: the same step with host (pageable) tensors in and out, as HCodecTokenizer's __main__ moves them
     # (audio_tokenizer.py:79,84: wav.to(device) ... wav_rec.cpu()); never `value`
     wav_h, feats_h = wav.cpu(), feats.cpu()
@@ -283,8 +294,16 @@ def main():
                          "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
-                         "gemm_share_of_step_time": gemm_ms * 1e-3 / elapsed, "all_gemm_configs": cfgs},
+                         "gemm_share_of_step_time": gemm_ms * 1e-3 / elapsed, "all_gemm_configs": cfgs,
+                         "note": "live HIP events in the timed region; kernels on the library's concurrent internal streams share the "
+                                 "CUs, so their durations overlap (shares can sum past 1). `isolated` = the same kernel with "
+                                 "qa_set_serial(1), alone on the device (what rocprofv3 under QA_SERIAL=1 reports)"},
         }
+        di = CFG_NAMES.index(dom["kernel"])
+        if iso[3 * di + 2]:
+            tf = iso[3 * di] / (iso[3 * di + 1] * 1e-3) / 1e12
+            line["roofline"]["isolated"] = {"achieved": tf, "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                                            "avg_launch_us": 1e3 * iso[3 * di + 1] / iso[3 * di + 2]}
         line["pcie_inclusive"] = {"value": B * T / SR / pcie_elapsed, "unit": "audio-seconds/sec", "ms_per_step": 1e3 * pcie_elapsed,
                                   "note": "rank-0 only: wav+features H2D from pageable memory, codes D2H+H2D, waveform D2H included"}
         if lm_line is not None:

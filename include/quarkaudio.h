@@ -186,6 +186,9 @@ int64_t qa_resolve_frame(int64_t r, int64_t L, int32_t max_pad, int32_t pad_mode
  * for the three tile configurations cfg = 0 (128x32), 1 (128x64), 2 (128x128).  Not thread-safe; process-wide. */
 int qa_profile_begin(void);
 int qa_profile_end(double* out, int32_t n_out);
+/* qa_set_serial(1) (or QA_SERIAL=1 in the environment) collapses the library's internal streams onto the caller's, so that a
+ * profiler sees every kernel alone on the device; results are bit-identical either way.  Process-wide. */
+int qa_set_serial(int32_t on);
 
 /* ---- UniSE AR-LM ------------------------------------------------------------------------------------ */
 

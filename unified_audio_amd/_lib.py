@@ -84,6 +84,7 @@ SYMBOLS = {
     "qa_resolve_frame": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "qa_profile_begin": (C.c_int, []),
     "qa_profile_end": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
+    "qa_set_serial": (C.c_int, [C.c_int32]),
     "qa_lm_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(qa_lm_spec), C.POINTER(qa_tensor), C.c_int64, C.c_int]),
     "qa_lm_destroy": (None, [C.c_void_p]),
     "qa_lm_generate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
@@ -93,7 +94,8 @@ SYMBOLS = {
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, _LIB_NAME)
+    # QA_LIBRARY: kernel-tuning experiments load an alternative BUILD of this same library (tools/variants.py)
+    return os.environ.get("QA_LIBRARY") or os.path.join(_HERE, _LIB_NAME)
 
 
 def load_library() -> C.CDLL:

@@ -1,6 +1,7 @@
 // api.cpp - error channel and the kernel-level C-ABI entry points.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "kernels.h"
@@ -36,6 +37,11 @@ static hipEvent_t prof_event() {
     return e;
 }
 bool profile_enabled() { return g_prof_on; }
+static bool g_serial = [] {
+    const char* e = getenv("QA_SERIAL");
+    return e && *e && *e != '0';
+}();
+bool serial_mode() { return g_serial; }
 void profile_record_begin(int cfg, double flops, hipStream_t s) {
     ProfRec r{prof_event(), prof_event(), cfg, flops};
     (void)hipEventRecord(r.a, s);
@@ -47,6 +53,11 @@ void profile_record_end(hipStream_t s) { (void)hipEventRecord(g_prof.back().b, s
 using namespace qa;
 
 extern "C" {
+
+int qa_set_serial(int on) {
+    g_serial = on != 0;
+    return QA_OK;
+}
 
 int qa_profile_begin(void) {
     for (auto& r : g_prof) {

@@ -102,11 +102,14 @@ struct ConvParams {
     int algo_n, algo_k;  // un-padded N / K for the algorithmic FLOP count (0 = use N / K)
     int xcd_swizzle;
     int in_rep;  // >1: the input is read as if every frame were repeated in_rep times (x.repeat_interleave, H-Codec 2.0 decoder)
+    int vec_epi;  // epilogue may move float4 (set by launch_conv_gemm from N, leading dimensions and pointer alignment)
+    unsigned rep_magic, rep_one;  // r / in_rep == __umulhi(r, rep_magic) + r * rep_one  (branch-free; set by launch_conv_gemm)
 };
 
 // Live measurement hook (bench.py): when enabled every conv_gemm launch is bracketed by HIP events on its own stream.
 enum { PROF_CFG_128x32 = 0, PROF_CFG_128x64 = 1, PROF_CFG_128x128 = 2, PROF_NCFG = 3 };
 bool profile_enabled();
+bool serial_mode();  // qa_set_serial / QA_SERIAL=1: no internal stream concurrency (every kernel alone on the device)
 void profile_record_begin(int cfg, double flops, hipStream_t s);
 void profile_record_end(hipStream_t s);
 

@@ -16,9 +16,56 @@
 
 #include "common.h"
 
+// tuning knobs of tools/variants.py
+#ifndef QA_LOAD_AT  // MFMA group of a K chunk that carries the next chunk's global loads
+#define QA_LOAD_AT 0
+#endif
+
+#ifdef QA_TIMING  // tuning builds only (tools/variants.py): per-phase shader-cycle totals of the main loop, summed over waves
+__device__ unsigned long long g_qa_timing[10];
+#define QA_TICK(i)                                              \
+    {                                                           \
+        const long long now_ = __builtin_readcyclecounter();    \
+        tacc[i] += now_ - tlast;                                \
+        tlast = now_;                                           \
+    }
+extern "C" int qa_debug_timing(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qa_timing), sizeof(g_qa_timing)) != hipSuccess) return -1;  // out[10]
+    if (reset) {
+        unsigned long long z[10] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_qa_timing), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define QA_TICK(i)
+#endif
+
 namespace qa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (float4 arrays were left as scratch allocas)
+
+constexpr int TAP_WIN = 8;  // taps per LDS source-frame table window (ksize <= 8: built once per tile)
+
+// epilogue of 4 consecutive output channels of one row: v = acc + bias -> gate -> act -> gamma -> residual -> post_act
+__device__ __forceinline__ f32x4 epilogue4(f32x4 v, const ConvParams& p, long long m, int n, f32x4 bias, f32x4 gamma) {
+    v += bias;
+    if (p.gate) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(p.gate + m * p.ldg + n);
+        v.x *= silu_f(g.x); v.y *= silu_f(g.y); v.z *= silu_f(g.z); v.w *= silu_f(g.w);
+    }
+    if (p.act != ACT_NONE) {
+        v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+    }
+    if (p.gamma) v *= gamma;
+    if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + n);
+    if (p.post_act != ACT_NONE) {
+        v.x = apply_act(v.x, p.post_act); v.y = apply_act(v.y, p.post_act); v.z = apply_act(v.z, p.post_act);
+        v.w = apply_act(v.w, p.post_act);
+    }
+    return v;
+}
 
 template <int BM, int BN, int WM, int WN, bool PRO_ELU, int BK = 32>
 __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(const ConvParams p) {
@@ -31,6 +78,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(cons
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
 
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS];
+    __shared__ int s_tap[BM * TAP_WIN];  // source-frame offset (floats, relative to the clip) of (row, tap); -1 = zero padding
     float* sA = smem;
     float* sB = smem + 2 * BM * LDS;
 
@@ -52,18 +100,39 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(cons
     const int ld_row = tid / (BK / 4);          // 0..RPP-1
     const int ld_c4 = (tid % (BK / 4)) * 4;     // float offset inside the BK-wide K chunk
 
-    // Per-thread A rows: batch base offset and first source frame.  Rows past M are clamped to row M-1 and columns past
-    // N to column N-1 (their results are never stored), so every load below is unconditional: hipcc would otherwise
-    // branch around each predicated load and drain vmcnt per element.
-    long long a_base[A_IT];
-    int a_t0[A_IT];
+    // Source-frame table.  The im2col row of output frame t is the ksize frames src(t, j); padding (reflect with the
+    // short-input rule of pad1d, or zeros) and repeat_interleave are resolved HERE, once per (row, tap), so that the main
+    // loop's address arithmetic is one LDS read per staged row: vector ALU instructions issued beside the other wave's
+    // MFMAs cost ~30 cycles each (measured), and the per-chunk resolve used to take as long as the MFMA phase itself.
+    // Rows past M are clamped to row M-1 and columns past N to column N-1 (their results are never stored), so every
+    // load in the main loop is unconditional.
+    const bool reflect = p.pad_mode == PAD_REFLECT;
+    const int ldx_i = (int)p.ldx;
+    const int t_virtual = p.T_in * (p.in_rep > 1 ? p.in_rep : 1);
+    auto build_taps = [&](int jbase) {
+        for (int e = tid; e < BM * TAP_WIN; e += 256) {
+            const int row = e / TAP_WIN, j = jbase + (e % TAP_WIN);
+            const int m = min(m0 + row, p.M - 1);
+            const int t = m % p.T_out;
+            int r = t * p.stride - p.pad_left + j;
+            const int rr = r < 0 ? -r : (r >= p.Lp ? 2 * (p.Lp - 1) - r : r);  // = resolve_frame()
+            r = reflect ? rr : r;
+            const bool ok = r >= 0 && r < t_virtual && j < p.ksize;
+            const unsigned ru = ok ? (unsigned)r : 0u;
+            const unsigned src = __umulhi(ru, p.rep_magic) + ru * p.rep_one;  // = r / in_rep
+            s_tap[e] = ok ? (int)(src * (unsigned)ldx_i) : -1;
+        }
+    };
+    build_taps(0);
+    int jbase = 0;
+
+    const float* a_ptr[A_IT];  // clip base + this thread's column offset inside a chunk
+    int a_tab[A_IT];           // byte offset of the row's table line
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int m = min(m0 + ld_row + RPP * i, p.M - 1);
-        const int b = m / p.T_out;
-        const int t = m - b * p.T_out;
-        a_base[i] = (long long)b * p.T_in * p.ldx + ld_c4;
-        a_t0[i] = t * p.stride - p.pad_left;
+        a_ptr[i] = p.x + (long long)(m / p.T_out) * p.T_in * p.ldx + ld_c4;
+        a_tab[i] = (ld_row + RPP * i) * TAP_WIN;
     }
     const float* b_ptr[B_IT];
 #pragma unroll
@@ -71,12 +140,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(cons
         const int n = min(n0 + ld_row + RPP * i, p.N - 1);
         b_ptr[i] = p.w + (long long)n * p.K + ld_c4;
     }
-
-    const bool reflect = p.pad_mode == PAD_REFLECT;
-    const int ldx_i = (int)p.ldx;
     const int nk = p.K / BK;
-    const int in_rep = p.in_rep;
-    const int t_virtual = p.T_in * (in_rep > 1 ? in_rep : 1);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -86,11 +150,9 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Staging registers of the NEXT K chunk.  No lambdas / conditionals around them: every iteration loads (the last one
-    // re-loads chunk nk-1, harmlessly) so that hipcc keeps them in VGPRs and issues the loads before the MFMAs.  (Keeping
-    // the row pointers incrementally under a wave-uniform "tap changed" branch was measured 13 % SLOWER: the branch splits
-    // the block and the address VALU no longer interleaves with the MFMAs.)
-    float4 a_reg[A_IT], b_reg[B_IT];
+    // Staging registers of the NEXT K chunk (native vector type: float4 arrays were left as scratch allocas).  Every
+    // iteration loads (the last one re-loads chunk nk-1, harmlessly).
+    f32x4 a_reg[A_IT], b_reg[B_IT];
     float a_keep[A_IT];  // 0 for frames that fall into zero padding (select on the data at LDS-store time, not on the load)
 
 #define QA_LOAD_GLOBAL(KC)                                                                                     \
@@ -98,103 +160,161 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(cons
         const int k0_ = (KC) * BK;                                                                             \
         const int j_ = k0_ / p.C_in;                                                                           \
         const int c_ = k0_ - j_ * p.C_in;                                                                      \
-        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                                     \
-            int r_ = a_t0[i] + j_;                                                                             \
-            const int rr_ = r_ < 0 ? -r_ : (r_ >= p.Lp ? 2 * (p.Lp - 1) - r_ : r_); /* = resolve_frame() */    \
-            r_ = reflect ? rr_ : r_;                                                                           \
-            const bool ok_ = r_ >= 0 && r_ < t_virtual;                                                        \
-            a_keep[i] = ok_ ? 1.f : 0.f;                                                                       \
-            r_ = in_rep > 1 ? r_ / in_rep : r_;                                                                \
-            a_reg[i] = *reinterpret_cast<const float4*>(p.x + a_base[i] + (unsigned)((ok_ ? r_ : 0) * ldx_i + c_)); \
+        if (j_ >= jbase + TAP_WIN) { /* block-uniform; only for ksize > TAP_WIN */                             \
+            jbase = j_;                                                                                        \
+            build_taps(jbase);                                                                                 \
+            __syncthreads();                                                                                   \
         }                                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) b_reg[i] = *reinterpret_cast<const float4*>(b_ptr[i] + k0_); \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                                     \
+            const int off_ = s_tap[a_tab[i] + (j_ - jbase)];                                                   \
+            a_keep[i] = off_ >= 0 ? 1.f : 0.f;                                                                 \
+            a_reg[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + (unsigned)(max(off_, 0) + c_));              \
+        }                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) b_reg[i] = *reinterpret_cast<const f32x4*>(b_ptr[i] + k0_); \
     }
 #define QA_STORE_LDS(BUF)                                                                                      \
     {                                                                                                          \
         float* a_ = sA + (BUF) * BM * LDS;                                                                     \
         float* b_ = sB + (BUF) * BN * LDS;                                                                     \
         _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                                     \
-            float4 v = a_reg[i];                                                                               \
-            v.x *= a_keep[i]; v.y *= a_keep[i]; v.z *= a_keep[i]; v.w *= a_keep[i];                            \
+            f32x4 v = a_reg[i] * a_keep[i];                                                                    \
             if (PRO_ELU) {                                                                                     \
                 v.x = elu_f(v.x); v.y = elu_f(v.y); v.z = elu_f(v.z); v.w = elu_f(v.w);                        \
             }                                                                                                  \
-            *reinterpret_cast<float4*>(a_ + (ld_row + RPP * i) * LDS + ld_c4) = v;                             \
+            *reinterpret_cast<f32x4*>(a_ + (ld_row + RPP * i) * LDS + ld_c4) = v;                              \
         }                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < B_IT; ++i)                                                       \
-            *reinterpret_cast<float4*>(b_ + (ld_row + RPP * i) * LDS + ld_c4) = b_reg[i];                      \
+            *reinterpret_cast<f32x4*>(b_ + (ld_row + RPP * i) * LDS + ld_c4) = b_reg[i];                       \
     }
 
+    __syncthreads();  // tap table visible
     QA_LOAD_GLOBAL(0)
     QA_STORE_LDS(0)
     __syncthreads();
 
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
+#ifdef QA_TIMING
+    long long tacc[5] = {0, 0, 0, 0, 0};
+    long long tlast = __builtin_readcyclecounter();
+    const long long tbegin = tlast;
+    const unsigned long long rbegin = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz
+#endif
+    // One K chunk = BK/8 groups of 4*TM*TN MFMAs.  The next chunk's address arithmetic + global loads ride in group 0 and
+    // its LDS stores in the last group, pinned there by sched_barriers: a wave's non-MFMA instructions must sit BETWEEN ITS
+    // OWN MFMAs.  Bunched before / after the MFMA phase they have to issue while the co-resident workgroup's wave owns the
+    // SIMD with back-to-back 64-cycle MFMAs, and then get roughly one issue slot per MFMA (measured: ~55 cycles per
+    // instruction, the "address phase" lasted as long as the whole MFMA phase).
+    constexpr int NKK = BK / 8;
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = kc & 1;
         const int nxt = min(kc + 1, nk - 1);
-        QA_LOAD_GLOBAL(nxt)
         const float* a = sA + cur * BM * LDS + (wm * WTM + frag_row) * LDS + frag_k;
         const float* b = sB + cur * BN * LDS + (wn * WTN + frag_row) * LDS + frag_k;
-        {
-            // fragment double buffering: the ds_read_b128 of k-group kk+1 are issued before the MFMAs of group kk
-            float4 af[2][TM], bf[2][TN];
+        // fragment double buffering: the ds_read_b128 of k-group kk+1 are issued before the MFMAs of group kk
+        f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS);
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDS);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS);
+        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDS);
 #pragma unroll
-            for (int kk = 0; kk < BK / 8; ++kk) {
-                const int cb = kk & 1, nb = cb ^ 1;
-                if (kk < BK / 8 - 1) {
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int cb = kk & 1, nb = cb ^ 1;
+            if (kk < NKK - 1) {
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        af[nb][i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS + (kk + 1) * 8);
+                for (int i = 0; i < TM; ++i) af[nb][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDS + (kk + 1) * 8);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        bf[nb][j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS + (kk + 1) * 8);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].x, bf[cb][j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].y, bf[cb][j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].z, bf[cb][j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].w, bf[cb][j].w, acc[i][j], 0, 0, 0);
-                    }
+                for (int j = 0; j < TN; ++j) bf[nb][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDS + (kk + 1) * 8);
             }
+            if (kk == QA_LOAD_AT) QA_LOAD_GLOBAL(nxt)
+            if (kk == NKK - 1) QA_STORE_LDS(cur ^ 1)
+            // operands swapped on purpose: the W fragment is the MFMA's row operand and the activation fragment its
+            // column operand, so D = (A W^T)^T and every lane ends up with 4 CONSECUTIVE output channels of one output
+            // row per register quad -> the epilogue moves float4, not scalars
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[cb][j].x, af[cb][i].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[cb][j].y, af[cb][i].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[cb][j].z, af[cb][i].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[cb][j].w, af[cb][i].w, acc[i][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        QA_STORE_LDS(cur ^ 1)
         __syncthreads();
     }
+#ifdef QA_TIMING
+    const long long tloop = __builtin_readcyclecounter();
+#endif
 #undef QA_LOAD_GLOBAL
 #undef QA_STORE_LDS
 
-    // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-    const int col_l = lane & 31, row_h = 4 * (lane >> 5);
+    // Epilogue.  D layout of the 32x32 MFMA with swapped operands: output row m <- lane & 31, output channel
+    // n <- (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5): registers 4g..4g+3 are channels 8g + 4h .. +3 of row m.
+    // The accumulators take one trip through LDS (the operand buffers are free now) so that (a) global traffic is whole
+    // 512-byte row segments per wave, float4 per lane, for the store AND for the fused residual / gate loads, and (b) the
+    // bias / gate / activation / gamma / residual code exists once, in a rolled loop - fully unrolled over the 64
+    // accumulator registers it was ~20k instructions per kernel and the epilogue alone cost 20 K-chunks of time.
+    constexpr int EP_LD = BN + 4;          // staging row stride (floats)
+    constexpr int EP_ROWS = WM * 32;       // rows staged per pass
+    constexpr int EP_C4 = BN / 4;          // float4 per row
+    static_assert(EP_ROWS * EP_LD <= 2 * (BM + BN) * LDS, "epilogue staging must fit in the operand buffers");
+    static_assert(256 % EP_C4 == 0, "a thread keeps its column group across iterations");
+    float* stage = smem;
+    const int row_l = lane & 31, col_h = 4 * (lane >> 5);
+    const int ep_c4 = tid % EP_C4, ep_r0 = tid / EP_C4;
+    const int ep_n = n0 + 4 * ep_c4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+    f32x4 bias4 = zero4, gamma4 = one4;
+    if (p.vec_epi && ep_n < p.N) {
+        if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + ep_n);
+        if (p.gamma) gamma4 = *reinterpret_cast<const f32x4*>(p.gamma + ep_n);
+    }
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+        __syncthreads();  // operand buffers (i = 0) / previous pass (i > 0) no longer read
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WTN + j * 32 + col_l;
-            if (n >= p.N) continue;
-            const float bias = p.bias ? p.bias[n] : 0.f;
-            const float gamma = p.gamma ? p.gamma[n] : 1.f;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] + bias;
-                if (p.gate) v = silu_f(p.gate[(long long)m * p.ldg + n]) * v;
-                v = apply_act(v, p.act);
-                if (p.gamma) v *= gamma;
-                if (p.res) v += p.res[(long long)m * p.ldr + n];
-                v = apply_act(v, p.post_act);
-                p.y[(long long)m * p.ldy + n] = v;
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(stage + (wm * 32 + row_l) * EP_LD + wn * WTN + j * 32 + 8 * g + col_h) = v;
+            }
+        __syncthreads();
+#pragma unroll 1
+        for (int r = ep_r0; r < EP_ROWS; r += 256 / EP_C4) {
+            const long long m = m0 + (r >> 5) * WTM + i * 32 + (r & 31);
+            if (m >= p.M || ep_n >= p.N) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * EP_LD + 4 * ep_c4);
+            if (p.vec_epi) {  // N % 4 == 0, every leading dimension and pointer 16-byte aligned
+                v = epilogue4(v, p, m, ep_n, bias4, gamma4);
+                *reinterpret_cast<f32x4*>(p.y + m * p.ldy + ep_n) = v;
+            } else {
+                for (int e = 0; e < 4 && ep_n + e < p.N; ++e) {
+                    const int n = ep_n + e;
+                    float u = v[e] + (p.bias ? p.bias[n] : 0.f);
+                    if (p.gate) u = silu_f(p.gate[m * p.ldg + n]) * u;
+                    u = apply_act(u, p.act);
+                    if (p.gamma) u *= p.gamma[n];
+                    if (p.res) u += p.res[m * p.ldr + n];
+                    u = apply_act(u, p.post_act);
+                    p.y[m * p.ldy + n] = u;
+                }
             }
         }
+    }
+#ifdef QA_TIMING
+    if (lane == 0) {
+        const long long tend = __builtin_readcyclecounter();
+        for (int i = 0; i < 4; ++i) atomicAdd(&g_qa_timing[i], (unsigned long long)tacc[i]);
+        atomicAdd(&g_qa_timing[4], (unsigned long long)(tend - tloop));   // epilogue
+        atomicAdd(&g_qa_timing[5], (unsigned long long)(tend - tbegin));  // main loop + epilogue
+        atomicAdd(&g_qa_timing[6], 1ULL);                                 // waves
+        atomicAdd(&g_qa_timing[7], (unsigned long long)nk);               // chunks
+        atomicAdd(&g_qa_timing[8], __builtin_amdgcn_s_memrealtime() - rbegin);  // same interval as [5] in 100 MHz ticks
+    }
+#endif
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -243,6 +363,12 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
     }();
     ConvParams q = p;
     q.xcd_swizzle = swz;
+    // frame / in_rep by multiply-high: exact for frame * in_rep < 2^32 (frames of one clip are < 2^31 / ldx)
+    auto al16 = [](const void* ptr) { return ((uintptr_t)ptr % 16) == 0; };
+    q.vec_epi = p.N % 4 == 0 && p.ldy % 4 == 0 && al16(p.y) && (!p.bias || al16(p.bias)) && (!p.gamma || al16(p.gamma)) &&
+                (!p.res || (p.ldr % 4 == 0 && al16(p.res))) && (!p.gate || (p.ldg % 4 == 0 && al16(p.gate)));
+    q.rep_one = p.in_rep > 1 ? 0u : 1u;
+    q.rep_magic = p.in_rep > 1 ? (unsigned)(((1ULL << 32) + p.in_rep - 1) / p.in_rep) : 0u;
     QA_REQUIRE(p.in_rep <= 1 || p.pad_mode == PAD_ZERO, "conv_gemm: in_rep needs zero padding");
     int cfg;
     if (forced >= 0) cfg = forced;

@@ -721,18 +721,19 @@ int encode_adaptive_graph(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, 
     float* agg_s = c.arena.alloc<float>((size_t)B * G * D);
     // semantic_aggregator(sem), acoustic_aggregator(emb): both use the alignment of the semantic stream and are otherwise
     // independent, so the two 32-layer stacks run concurrently on two streams (fork / join with events; no host sync)
+    hipStream_t side = serial_mode() ? c.stream : h->side;  // qa_set_serial(1): one stream, for per-kernel profiling
     if (!c.dry) {
         QA_TRY(launch_agg_build(sem, seg, start, len, nseg, h->qemb_sem, inter_s, B, N, G, D, c.stream));
         QA_TRY(launch_agg_build(emb, seg, start, len, nseg, h->qemb_ac, inter_a, B, N, G, D, c.stream));
         QA_HIP(hipEventRecord(h->ev_fork, c.stream));
-        QA_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        QA_HIP(hipStreamWaitEvent(side, h->ev_fork, 0));
     }
-    QA_TRY(mimi_pair_op(c, h->side, h->agg_sem, inter_s, h->agg_ac, inter_a, B, S));
+    QA_TRY(mimi_pair_op(c, side, h->agg_sem, inter_s, h->agg_ac, inter_a, B, S));
     if (!c.dry) {
         hipStream_t main = c.stream;
         QA_TRY(launch_agg_gather(inter_s, start, len, nseg, agg_s, B, N, G, D, main));
-        QA_TRY(launch_agg_gather(inter_a, start, len, nseg, agg_a, B, N, G, D, h->side));
-        QA_HIP(hipEventRecord(h->ev_join, h->side));
+        QA_TRY(launch_agg_gather(inter_a, start, len, nseg, agg_a, B, N, G, D, side));
+        QA_HIP(hipEventRecord(h->ev_join, side));
         QA_HIP(hipStreamWaitEvent(main, h->ev_join, 0));
     }
     c.tap("enc.emb_agg", agg_a, (int64_t)B * G * D);
