@@ -38,6 +38,7 @@ def parse():
                     help="H-Codec version (BASELINE configs[1] is 1.5; 2.0 = configs[4]'s per-GPU share: use --batch 16 --seconds 30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=2, help="clips in the bounded CPU-baseline sample")
+    ap.add_argument("--lean", action="store_true", help="profiling runs: only warm-up + timed region (no isolated / PCIe / LM / CPU passes)")
     ap.add_argument("--no-lm", action="store_true", help="skip the secondary UniSE AR-LM tokens/sec measurement")
     ap.add_argument("--lm-batch", type=int, default=16, help="UniSE segments per GPU (BASELINE configs[2]: batch=16)")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
@@ -212,8 +213,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
-    prof = (C.c_double * 9)()
-    _lib.check(lib.qa_profile_end(prof, 9))
+    prof = (C.c_double * 12)()
+    _lib.check(lib.qa_profile_end(prof, 12))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -222,13 +223,13 @@ def main():
 
     # the same kernels with the library's internal stream concurrency switched off (every launch alone on the device):
     # what a kernel achieves by itself, as opposed to while it shares the CUs with the other stream's kernels
-    iso = (C.c_double * 9)()
+    iso = (C.c_double * 12)()
     _lib.check(lib.qa_set_serial(1))
     _lib.check(lib.qa_profile_begin())
-    for _ in range(2):
+    for _ in range(0 if args.lean else 2):
         step()
     torch.cuda.synchronize(dev)
-    _lib.check(lib.qa_profile_end(iso, 9))
+    _lib.check(lib.qa_profile_end(iso, 12))
     _lib.check(lib.qa_set_serial(0))
 
     # secondary: the same step with host (pageable) tensors in and out, as HCodecTokenizer's __main__ moves them
@@ -236,7 +237,7 @@ def main():
     wav_h, feats_h = wav.cpu(), feats.cpu()
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
-    for _ in range(2):
+    for _ in range(1 if args.lean else 2):
         w_d, f_d = wav_h.to(dev), feats_h.to(dev)
         if adaptive:
             codes = codec.encode(w_d.unsqueeze(1), f_d.transpose(1, 2))
@@ -244,11 +245,11 @@ def main():
         else:
             a_, s_ = codec.encode(w_d.unsqueeze(1), f_d.transpose(1, 2))
             rec_h = codec.decode(a_.cpu().to(dev), s_.cpu().to(dev)).cpu()
-    pcie_elapsed = (time.perf_counter() - t1) / 2
+    pcie_elapsed = (time.perf_counter() - t1) / (1 if args.lean else 2)
     del rec_h
 
     lm_line = None
-    if not args.no_lm:
+    if not args.no_lm and not args.lean:
         del out
         log("UniSE LM generate ...")
         lm_line = lm_bench(dev, rank, world, dist, args.lm_batch)
@@ -257,22 +258,23 @@ def main():
         audio_s = world * B * T / SR * args.steps
         cfgs = []
         for i, name in enumerate(CFG_NAMES):
-            fl, ms, n = prof[3 * i], prof[3 * i + 1], prof[3 * i + 2]
+            fl, ms, n, by = prof[4 * i], prof[4 * i + 1], prof[4 * i + 2], prof[4 * i + 3]
             if n:
                 cfgs.append({"kernel": name, "launches_per_step": n / args.steps, "avg_us": 1e3 * ms / n,
-                             "tflops": fl / (ms * 1e-3) / 1e12, "share_of_step_time": ms * 1e-3 / elapsed})
+                             "tflops": fl / (ms * 1e-3) / 1e12, "share_of_step_time": ms * 1e-3 / elapsed,
+                             "algorithmic_bytes_per_launch": by / n, "flop_per_launch": fl / n})
         dom = max(cfgs, key=lambda c: c["share_of_step_time"])
         # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950
         # correction, + WRITE_SIZE) over this same command, summarised under profiles/ (PMC cannot be sampled from inside the run)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, mfma_busy = None, None, None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic_hcodec15.json")
         if args.model == "1.5" and B == 32 and abs(args.seconds - 10.0) < 1e-6 and os.path.exists(pmc_file):
             want = dom["kernel"].replace("conv_gemm_kernel<", "").rstrip(">").replace(",", ", ")
             for k, v in json.load(open(pmc_file)).items():
-                if f"conv_gemm_kernel<{want}, false>" in k:
-                    traffic, traffic_src = v["hbm_bytes_per_launch"], "profiles/r01_d_hcodec15_pmc_hbm_mfma.md (2*FETCH_SIZE + WRITE_SIZE, per launch)"
+                if f"conv_gemm_kernel<{want}> (all" in k:
+                    traffic, traffic_src = v["hbm_bytes_per_launch"], "profiles/r01_g_hcodec15_pmc_hbm_mfma.md (2*FETCH_SIZE + WRITE_SIZE, per launch)"
                     mfma_busy = v["mfma_busy_frac"]
-        gemm_ms = sum(prof[3 * i + 1] for i in range(3))
+        gemm_ms = sum(prof[4 * i + 1] for i in range(3))
         line = {
             "metric": "audio-seconds/sec H-Codec encode+decode @16kHz b=32",
             "value": audio_s / elapsed,
@@ -293,6 +295,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                         "traffic_algorithmic": dom["algorithmic_bytes_per_launch"], "flop_per_launch": dom["flop_per_launch"],
+                         "mfma_busy_frac_pmc": mfma_busy,
                          "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
                          "gemm_share_of_step_time": gemm_ms * 1e-3 / elapsed, "all_gemm_configs": cfgs,
                          "note": "live HIP events in the timed region; kernels on the library's concurrent internal streams share the "
@@ -300,17 +304,17 @@ def main():
                                  "qa_set_serial(1), alone on the device (what rocprofv3 under QA_SERIAL=1 reports)"},
         }
         di = CFG_NAMES.index(dom["kernel"])
-        if iso[3 * di + 2]:
-            tf = iso[3 * di] / (iso[3 * di + 1] * 1e-3) / 1e12
+        if iso[4 * di + 2]:
+            tf = iso[4 * di] / (iso[4 * di + 1] * 1e-3) / 1e12
             line["roofline"]["isolated"] = {"achieved": tf, "frac": tf / MFMA_F32_PEAK_TFLOPS,
-                                            "avg_launch_us": 1e3 * iso[3 * di + 1] / iso[3 * di + 2]}
+                                            "avg_launch_us": 1e3 * iso[4 * di + 1] / iso[4 * di + 2]}
         line["pcie_inclusive"] = {"value": B * T / SR / pcie_elapsed, "unit": "audio-seconds/sec", "ms_per_step": 1e3 * pcie_elapsed,
                                   "note": "rank-0 only: wav+features H2D from pageable memory, codes D2H+H2D, waveform D2H included"}
         if lm_line is not None:
             line["unise_lm"] = lm_line
         if args.model == "2.0":
             line["metric"] = "audio-seconds/sec H-Codec 2.0 encode+decode @48kHz (BASELINE configs[4], per-GPU share)"
-        if world == 1 and not args.no_cpu_baseline and args.model != "2.0":
+        if world == 1 and not args.no_cpu_baseline and not args.lean and args.model != "2.0":
             log("cpu baseline ...")
             line["cpu_baseline"] = cpu_baseline(args.cpu_clips, args.seconds, model=args.model)
             if line["cpu_baseline"]["value"]:

@@ -182,8 +182,9 @@ int64_t qa_resolve_frame(int64_t r, int64_t L, int32_t max_pad, int32_t pad_mode
 
 /* ---- measurement hook (bench.py) ------------------------------------------------------------------------
  * Between qa_profile_begin() and qa_profile_end() every implicit-GEMM launch is bracketed by HIP events recorded on
- * the stream it is launched on.  qa_profile_end fills out[cfg*3 + {0,1,2}] = {algorithmic FLOPs, elapsed ms, launches}
- * for the three tile configurations cfg = 0 (128x32), 1 (128x64), 2 (128x128).  Not thread-safe; process-wide. */
+ * the stream it is launched on.  qa_profile_end fills out[cfg*4 + {0,1,2,3}] = {algorithmic FLOPs, elapsed ms, launches,
+ * algorithmic bytes (input frames + weights + outputs + fused residual / gate reads, each once)} for the three tile
+ * configurations cfg = 0 (128x32), 1 (128x64), 2 (128x128); n_out >= 12.  Not thread-safe; process-wide. */
 int qa_profile_begin(void);
 int qa_profile_end(double* out, int32_t n_out);
 /* qa_set_serial(1) (or QA_SERIAL=1 in the environment) collapses the library's internal streams onto the caller's, so that a

@@ -21,7 +21,7 @@ namespace qa {
 struct ProfRec {
     hipEvent_t a, b;
     int cfg;
-    double flops;
+    double flops, bytes;
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
@@ -42,8 +42,8 @@ static bool g_serial = [] {
     return e && *e && *e != '0';
 }();
 bool serial_mode() { return g_serial; }
-void profile_record_begin(int cfg, double flops, hipStream_t s) {
-    ProfRec r{prof_event(), prof_event(), cfg, flops};
+void profile_record_begin(int cfg, double flops, double bytes, hipStream_t s) {
+    ProfRec r{prof_event(), prof_event(), cfg, flops, bytes};
     (void)hipEventRecord(r.a, s);
     g_prof.push_back(r);
 }
@@ -69,21 +69,22 @@ int qa_profile_begin(void) {
     return QA_OK;
 }
 
-// out[cfg*3 + {0,1,2}] = {algorithmic FLOPs, elapsed ms, launches} for cfg in {128x32, 128x64, 128x128}
+// out[cfg*4 + {0,1,2,3}] = {algorithmic FLOPs, elapsed ms, launches, algorithmic bytes} for cfg in {128x32, 128x64, 128x128}
 int qa_profile_end(double* out, int32_t n_out) {
     g_prof_on = false;
-    if (!out || n_out < PROF_NCFG * 3) {
-        set_error("qa_profile_end: need room for %d doubles", PROF_NCFG * 3);
+    if (!out || n_out < PROF_NCFG * 4) {
+        set_error("qa_profile_end: need room for %d doubles", PROF_NCFG * 4);
         return QA_ERR_INVALID;
     }
-    for (int i = 0; i < PROF_NCFG * 3; ++i) out[i] = 0.0;
+    for (int i = 0; i < PROF_NCFG * 4; ++i) out[i] = 0.0;
     for (auto& r : g_prof) {
         QA_HIP(hipEventSynchronize(r.b));
         float ms = 0.f;
         QA_HIP(hipEventElapsedTime(&ms, r.a, r.b));
-        out[r.cfg * 3 + 0] += r.flops;
-        out[r.cfg * 3 + 1] += ms;
-        out[r.cfg * 3 + 2] += 1.0;
+        out[r.cfg * 4 + 0] += r.flops;
+        out[r.cfg * 4 + 1] += ms;
+        out[r.cfg * 4 + 2] += 1.0;
+        out[r.cfg * 4 + 3] += r.bytes;
     }
     return QA_OK;
 }

@@ -325,14 +325,17 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
     if (prof) {
         const int cfg = BN == 32 ? PROF_CFG_128x32 : (BN == 64 ? PROF_CFG_128x64 : PROF_CFG_128x128);
         const double n = p.algo_n ? p.algo_n : p.N, k = p.algo_k ? p.algo_k : p.K;
-        profile_record_begin(cfg, 2.0 * (double)p.M * n * k, stream);
+        // algorithmic bytes: every input frame, weight and output element once (+ fused residual / gate reads)
+        const double elems = (double)p.B * p.T_in * p.C_in + n * k + (double)p.M * n * (1.0 + (p.res ? 1.0 : 0.0) + (p.gate ? 1.0 : 0.0));
+        profile_record_begin(cfg, 2.0 * (double)p.M * n * k, 4.0 * elems, stream);
     }
-    // Short-K layers (K <= 512: 16 chunks or fewer per tile) are dominated by per-tile fixed costs; the BK = 16 variant needs
-    // 41 KB / 31 KB of LDS, so 3-4 workgroups are co-resident per CU and cover each other's prologue / epilogue
-    // (measured on M = 9056, K = 512: +10 % for N = 1536, +25 % for N = 2048; neutral from K = 1024 up).
+    // BK = 16 chunks need 45 KB / 35 KB of LDS, so 3-4 workgroups are co-resident per CU (BK = 32: 2) and cover each
+    // other's barriers, prologues and epilogues: +10..25 % on the K = 512 layers of the aggregator stacks, +3..5 % on
+    // K = 768..3072 (per-shape sweep, tools/gemm_bench.py with QA_GEMM_BK16=0 / default).  QA_GEMM_BK16 = largest K that
+    // takes the BK = 16 variant.
     static const int bk16_max_k = [] {
         const char* e = getenv("QA_GEMM_BK16");
-        return e ? atoi(e) : 512;
+        return e ? atoi(e) : 1 << 30;
     }();
     if (BN >= 64 && p.prologue != ACT_ELU && p.K <= bk16_max_k)
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, (BN >= 64 ? 16 : 32)>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
