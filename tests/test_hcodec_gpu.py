@@ -222,3 +222,42 @@ def test_hcodec20_full_width_parity(qa_lib, gpu_device):
     print(report, agree)
     assert all(v < 2 * STAGE_TOL for v in report.values()), report
     assert min(agree) > 0.95
+
+
+# ---- product mode overlaps the two H-Codec 1.5 aggregator stacks on internal streams; with taps enabled or qa_set_serial(1)
+# everything stays on the caller's stream.  Same integers, same floats (and for 1.0: repeated calls re-use the arena).
+def _streams_vs_serial(codec, wav, feat, adaptive):
+    outs = []
+    for taps in (True, False):
+        codec.enable_taps(taps)
+        enc = codec.encode(wav, feat)
+        torch.cuda.synchronize()
+        ac, sc = (enc["acoustic_codes"], enc["semantic_codes"]) if adaptive else enc
+        w = codec.decode(ac, sc)
+        torch.cuda.synchronize()
+        outs.append((ac.clone(), sc.clone(), w.clone()))
+    (ac0, sc0, w0), (ac1, sc1, w1) = outs
+    assert torch.equal(ac0, ac1) and torch.equal(sc0, sc1) and torch.equal(w0, w1)
+
+
+def test_internal_streams_match_serial_mini(qa_lib, gpu_device):
+    ospec, sd, codec = _make(MINI, 71, gpu_device)
+    B, T = 5, ospec.enc_hop * 40
+    wav = synth.synth_wav(72, B, T).to(gpu_device)
+    feat = synth.synth_feat(73, B, T // (ospec.enc_hop // 2), ospec.sem_in).to(gpu_device)
+    for _ in range(3):  # repeated calls re-use the arena: a stale-buffer race would show up as a changed result
+        _streams_vs_serial(codec, wav.unsqueeze(1), feat, False)
+
+
+def test_internal_streams_match_serial_hcodec15(qa_lib, gpu_device):
+    import unified_audio_amd as qa
+
+    ospec = _spec15(agg_layers=2, bt_layers=2, threshold=0.7)
+    sd = synth.hcodec10_state_dict(81, ospec)
+    kw = {f: getattr(ospec, f) for f in ospec.__dataclass_fields__}
+    codec = qa.Codec(None, None, None, spec=qa.HCodecSpec(**kw), device=gpu_device).load_state_dict(sd)
+    B, T = 4, 640 * 25
+    wav = synth.synth_wav(82, B, T).to(gpu_device)
+    feat = synth.synth_feat(83, B, T // 320, ospec.sem_in).to(gpu_device)
+    for _ in range(2):
+        _streams_vs_serial(codec, wav.unsqueeze(1), feat, True)
