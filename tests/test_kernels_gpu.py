@@ -25,6 +25,10 @@ CONV_CASES = [
     dict(B=2, T=100, Cin=64, N=64, k=4, stride=2, mode="zero1"),              # semantic strided conv (pad 1,1)
     dict(B=4, T=250, Cin=256, N=300, k=3, mode="zero"),                       # 128x128 tiles, ragged N
     dict(B=1, T=1, Cin=32, N=32, k=1),                                        # single row
+    dict(B=2, T=330, Cin=64, N=160, k=16, stride=8, mode="reflect"),          # ksize > 8: source-frame table rebuilt mid-tile (128x64/128 tiles)
+    dict(B=3, T=97, Cin=32, N=136, k=9, stride=4, mode="reflect", res=True),  # ragged M, N % 8 == 0 only, residual, two table windows
+    dict(B=1, T=300, Cin=96, N=66, k=3, mode="zero", gate=True, act=3),       # N % 4 != 0: scalar epilogue path
+    dict(B=2, T=129, Cin=512, N=512, k=1, gamma=True, res=True, post=1),      # K = 512 (BK = 16 variant), every epilogue stage but the gate
 ]
 
 
