@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=2, help="clips in the bounded CPU-baseline sample")
     ap.add_argument("--lean", action="store_true", help="profiling runs: only warm-up + timed region (no isolated / PCIe / LM / CPU passes)")
+    ap.add_argument("--no-ssl", action="store_true", help="skip the secondary SSL front-end measurement")
     ap.add_argument("--no-lm", action="store_true", help="skip the secondary UniSE AR-LM tokens/sec measurement")
     ap.add_argument("--lm-batch", type=int, default=16, help="UniSE segments per GPU (BASELINE configs[2]: batch=16)")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
@@ -94,6 +95,75 @@ def cpu_baseline(clips, seconds, reps=2, model="1.5"):
     except Exception as e:  # noqa: BLE001 - a failed baseline must not lose the GPU measurement
         return {"value": None, "unit": "audio-seconds/sec", "cores": threads, "kind": "port",
                 "sample": f"FAILED: {type(e).__name__}: {str(e)[:300]}"}
+
+
+def _ssl_state_dict(spec, seed=21):
+    """Seeded random weights in the transformers HubertModel / Wav2Vec2Model key layout (shapes only depend on the spec)."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *shape, scale=0.02: torch.randn(*shape, generator=g) * scale  # noqa: E731
+    sd = {}
+    cin = 1
+    for i, (c, k) in enumerate(zip(spec.conv_dim, spec.conv_kernel)):
+        pre = f"feature_extractor.conv_layers.{i}."
+        sd[pre + "conv.weight"] = rn(c, cin, k, scale=(2.0 / (cin * k)) ** 0.5)
+        if spec.conv_bias:
+            sd[pre + "conv.bias"] = rn(c)
+        if spec.feat_extract_norm == "layer" or i == 0:
+            sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"] = 1.0 + rn(c, scale=0.1), rn(c)
+        cin = c
+    d, inter = spec.hidden_size, spec.intermediate_size
+    sd["feature_projection.layer_norm.weight"], sd["feature_projection.layer_norm.bias"] = 1.0 + rn(cin, scale=0.1), rn(cin)
+    sd["feature_projection.projection.weight"], sd["feature_projection.projection.bias"] = rn(d, cin, scale=cin ** -0.5), rn(d)
+    cg = d // spec.num_conv_pos_embedding_groups
+    sd["encoder.pos_conv_embed.conv.weight"] = rn(d, cg, spec.num_conv_pos_embeddings, scale=(cg * spec.num_conv_pos_embeddings) ** -0.5)
+    sd["encoder.pos_conv_embed.conv.bias"] = rn(d)
+    sd["encoder.layer_norm.weight"], sd["encoder.layer_norm.bias"] = 1.0 + rn(d, scale=0.1), rn(d)
+    for i in range(spec.num_hidden_layers):
+        pre = f"encoder.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[pre + f"attention.{nm}.weight"], sd[pre + f"attention.{nm}.bias"] = rn(d, d, scale=d ** -0.5), rn(d)
+        sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"] = 1.0 + rn(d, scale=0.1), rn(d)
+        sd[pre + "feed_forward.intermediate_dense.weight"], sd[pre + "feed_forward.intermediate_dense.bias"] = rn(inter, d, scale=d ** -0.5), rn(inter)
+        sd[pre + "feed_forward.output_dense.weight"], sd[pre + "feed_forward.output_dense.bias"] = rn(d, inter, scale=inter ** -0.5), rn(d)
+        sd[pre + "final_layer_norm.weight"], sd[pre + "final_layer_norm.bias"] = 1.0 + rn(d, scale=0.1), rn(d)
+    return sd
+
+
+def ssl_bench(dev, model, B, seconds, reps=3):
+    """Secondary: the SSL feature extraction in front of Codec.encode - XLSR-53 architecture for H-Codec 1.5
+    (audio_tokenizer.py:47), HuBERT-base for 1.0 - on B clips of `seconds` at 16 kHz, waveform resident in HBM."""
+    import unified_audio_amd as qa
+
+    spec, name = (qa.SPEC_XLSR53, "wav2vec2-large-xlsr-53") if model == "1.5" else (qa.SPEC_HUBERT_BASE, "hubert_base")
+    sd = _ssl_state_dict(spec)
+    n_params = sum(v.numel() for v in sd.values())
+    fx = qa.SSLFeatureExtractor(spec, device=dev).load_state_dict(sd)
+    del sd
+    T = int(seconds * 16000)
+    g = torch.Generator().manual_seed(5)
+    wav = (torch.randn(B, T, generator=g) * 0.1).to(dev)
+    feats = fx(wav)
+    torch.cuda.synchronize(dev)
+    assert torch.isfinite(feats).all()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        feats = fx(wav)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / reps
+    # contraction FLOPs of one pass (conv stack from layer 1, projections, positional conv, encoder GEMMs + attention)
+    L = T + 2 * spec.pad
+    fl, cin = 0.0, 1
+    for i, (c, k, st) in enumerate(zip(spec.conv_dim, spec.conv_kernel, spec.conv_stride)):
+        L = (L - k) // st + 1
+        fl += 2.0 * L * c * cin * k
+        cin = c
+    d, inter = spec.hidden_size, spec.intermediate_size
+    fl += 2.0 * L * d * cin + 2.0 * L * d * (d // spec.num_conv_pos_embedding_groups) * spec.num_conv_pos_embeddings
+    fl += spec.num_hidden_layers * (2.0 * L * d * (4 * d + 2 * inter) + 4.0 * L * L * d)
+    return {"metric": "audio-seconds/sec SSL feature extraction (front-end of Codec.encode)", "value": B * seconds / dt, "unit": "audio-seconds/sec",
+            "ms_per_pass": 1e3 * dt, "tflops": B * fl / dt / 1e12,
+            "config": {"workload": f"{name} architecture ({n_params / 1e6:.0f} M parameters, seeded random weights), {B} clips x {seconds:.0f} s @16 kHz, "
+                                   f"{L} frames x {d} per clip, hidden-state average + |x|^0.3 compression", "dtype": "f32"}}
 
 
 def lm_bench(dev, rank, world, dist, batch, reps=2):
@@ -254,6 +324,14 @@ def main():
         log("UniSE LM generate ...")
         lm_line = lm_bench(dev, rank, world, dist, args.lm_batch)
 
+    ssl_line = None
+    if world == 1 and not args.lean and not args.no_ssl and args.model != "2.0":
+        log("SSL front-end ...")
+        try:
+            ssl_line = ssl_bench(dev, args.model, B, args.seconds)
+        except Exception as e:  # secondary: never take the headline line down with it
+            ssl_line = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+
     if rank == 0:
         audio_s = world * B * T / SR * args.steps
         cfgs = []
@@ -312,6 +390,8 @@ def main():
                                   "note": "rank-0 only: wav+features H2D from pageable memory, codes D2H+H2D, waveform D2H included"}
         if lm_line is not None:
             line["unise_lm"] = lm_line
+        if ssl_line is not None:
+            line["ssl_frontend"] = ssl_line
         if args.model == "2.0":
             line["metric"] = "audio-seconds/sec H-Codec 2.0 encode+decode @48kHz (BASELINE configs[4], per-GPU share)"
         if world == 1 and not args.no_cpu_baseline and not args.lean and args.model != "2.0":

@@ -191,6 +191,41 @@ int qa_profile_end(double* out, int32_t n_out);
  * profiler sees every kernel alone on the device; results are bit-identical either way.  Process-wide. */
 int qa_set_serial(int32_t on);
 
+/* ---- SSL front-end ---------------------------------------------------------------------------
+ * HCodecTokenizer.extract_wav2vec2_features (QuarkAudio-HCodec/HCodec-1.0/audio_tokenizer.py:35-48, HCodec-1.5/audio_tokenizer.py:53-67):
+ * zero-pad `pad` samples each side, run the HuBERT / wav2vec 2.0 model (transformers HubertModel / Wav2Vec2Model: 7-layer
+ * Conv1d feature extractor, feature projection, grouped positional convolution, post-LN or stable-LN encoder), average the
+ * selected hidden states, compress sign * |x|^e.  Weights: the HF state_dict (keys feature_extractor.conv_layers.*,
+ * feature_projection.*, encoder.pos_conv_embed.conv.{parametrizations.weight.original0/1 | weight_g/weight_v | weight}, ...). */
+typedef struct qa_ssl_spec {
+    int32_t n_conv;             /* 7 */
+    int32_t conv_dim[8];        /* 512 x 7 */
+    int32_t conv_kernel[8];     /* 10,3,3,3,3,2,2 */
+    int32_t conv_stride[8];     /* 5,2,2,2,2,2,2 */
+    int32_t conv_bias;          /* 0 HuBERT base; 1 wav2vec2-large / XLSR */
+    int32_t feat_norm_layer;    /* 0 = "group" (GroupNorm on layer 0 only), 1 = "layer" (LayerNorm after every conv) */
+    int32_t hidden;             /* 768 / 1024 */
+    int32_t n_layers;           /* 12 / 24 */
+    int32_t n_heads;            /* 12 / 16 */
+    int32_t intermediate;       /* 3072 / 4096 */
+    int32_t stable_layer_norm;  /* 0 post-LN (base), 1 pre-LN + final LN (large / XLSR) */
+    int32_t pos_kernel;         /* 128 */
+    int32_t pos_groups;         /* 16 */
+    int32_t pad;                /* 160 (F.pad(wavs, (160, 160))) */
+    int32_t n_select;           /* number of hidden states averaged; 0 = all n_layers + 1 (torch.stack(hidden_states).mean) */
+    int32_t select[32];         /* their indices into hidden_states (1.5: 11, 14, 16) */
+    float layer_norm_eps;       /* 1e-5 */
+    float compress_exponent;    /* 0.3; <= 0: return the plain average */
+} qa_ssl_spec;
+typedef struct qa_ssl qa_ssl;
+int qa_ssl_create(qa_ssl** out, const qa_ssl_spec* spec, const qa_tensor* tensors, int64_t n_tensors, int device);
+void qa_ssl_destroy(qa_ssl* h);
+/* frames the model yields for T samples (after padding); negative status when T is too short */
+int64_t qa_ssl_frames(const qa_ssl* h, int64_t T);
+/* wav float32 [B, T] (device) -> feats float32 [B, frames, hidden] (device, channel-last: what qa_hcodec_encode takes as `feat`
+ * with strides (frames*hidden, 1, hidden)) */
+int qa_ssl_forward(qa_ssl* h, const float* wav, int64_t B, int64_t T, float* feats, void* stream);
+
 /* ---- UniSE AR-LM ------------------------------------------------------------------------------------ */
 
 typedef struct qa_lm_spec {

@@ -2,11 +2,13 @@
 
 Only the path BASELINE.json's north_star names lives here: H-Codec encode -> RVQ -> decode and the UniSE AR-LM generate
 loop, as hand-written HIP kernels behind the C-ABI in include/quarkaudio.h, plus the thin Python mirror of the
-reference's own interface (`Codec.encode/decode`, `HCodecTokenizer.tokenize/detokenize`, `LLM_SFT.generate`).
+reference's own interface (`Codec.encode/decode`, `HCodecTokenizer.tokenize/detokenize`, `LLM_SFT.generate`), and - the first
+"next" row of SURVEY.md section 8f - the SSL feature extraction in front of `Codec.encode` (`SSLFeatureExtractor`).
 There is no CPU / PyTorch fallback: if libquarkaudio_hip.so is missing or no gfx950 device is visible, calls raise.
 """
 from ._lib import QuarkAudioError, lib_path, load_library  # noqa: F401
 from .hcodec import Codec, HCodecSpec, HCodecTokenizer, SPEC_10, SPEC_15, SPEC_20  # noqa: F401
 from .llm import LLM_SFT  # noqa: F401
+from .ssl import SPEC_HUBERT_BASE, SPEC_XLSR53, SSLFeatureExtractor, SSLSpec  # noqa: F401
 
-__all__ = ["LLM_SFT", "Codec", "HCodecSpec", "HCodecTokenizer", "SPEC_10", "SPEC_15", "SPEC_20", "QuarkAudioError", "load_library", "lib_path"]
+__all__ = ["SSLFeatureExtractor", "SSLSpec", "SPEC_HUBERT_BASE", "SPEC_XLSR53", "LLM_SFT", "Codec", "HCodecSpec", "HCodecTokenizer", "SPEC_10", "SPEC_15", "SPEC_20", "QuarkAudioError", "load_library", "lib_path"]

@@ -58,6 +58,16 @@ class qa_lm_spec(C.Structure):
     ]
 
 
+class qa_ssl_spec(C.Structure):
+    _fields_ = [
+        ("n_conv", C.c_int32), ("conv_dim", C.c_int32 * 8), ("conv_kernel", C.c_int32 * 8), ("conv_stride", C.c_int32 * 8),
+        ("conv_bias", C.c_int32), ("feat_norm_layer", C.c_int32), ("hidden", C.c_int32), ("n_layers", C.c_int32),
+        ("n_heads", C.c_int32), ("intermediate", C.c_int32), ("stable_layer_norm", C.c_int32), ("pos_kernel", C.c_int32),
+        ("pos_groups", C.c_int32), ("pad", C.c_int32), ("n_select", C.c_int32), ("select", C.c_int32 * 32),
+        ("layer_norm_eps", C.c_float), ("compress_exponent", C.c_float),
+    ]
+
+
 # every symbol include/quarkaudio.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "qa_version": (C.c_int, []),
@@ -85,6 +95,10 @@ SYMBOLS = {
     "qa_profile_begin": (C.c_int, []),
     "qa_profile_end": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
     "qa_set_serial": (C.c_int, [C.c_int32]),
+    "qa_ssl_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(qa_ssl_spec), C.POINTER(qa_tensor), C.c_int64, C.c_int]),
+    "qa_ssl_destroy": (None, [C.c_void_p]),
+    "qa_ssl_frames": (C.c_int64, [C.c_void_p, C.c_int64]),
+    "qa_ssl_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "qa_lm_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(qa_lm_spec), C.POINTER(qa_tensor), C.c_int64, C.c_int]),
     "qa_lm_destroy": (None, [C.c_void_p]),
     "qa_lm_generate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,

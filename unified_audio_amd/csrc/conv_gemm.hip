@@ -337,7 +337,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
         const char* e = getenv("QA_GEMM_BK16");
         return e ? atoi(e) : 1 << 30;
     }();
-    if (BN >= 64 && p.prologue != ACT_ELU && p.K <= bk16_max_k)
+    if (BN >= 64 && p.prologue != ACT_ELU && (p.K <= bk16_max_k || p.C_in % 32 != 0))
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, (BN >= 64 ? 16 : 32)>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
     else if (p.prologue == ACT_ELU)
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
@@ -349,7 +349,11 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
 }
 
 int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
-    QA_REQUIRE(p.K % 32 == 0 && p.C_in % 32 == 0, "conv_gemm: K=%d / C_in=%d must be multiples of 32", p.K, p.C_in);
+    // a K chunk never straddles two taps: C_in must be a multiple of the chunk width (16 for the BK = 16 variants, which
+    // exist for N > 32 without the ELU prologue - e.g. the 48-channel groups of the SSL positional convolution; 32 otherwise)
+    QA_REQUIRE(p.K % 16 == 0 && p.C_in % 16 == 0, "conv_gemm: K=%d / C_in=%d must be multiples of 16", p.K, p.C_in);
+    QA_REQUIRE(p.C_in % 32 == 0 || (p.N > 32 && p.prologue != ACT_ELU),
+               "conv_gemm: C_in=%d is not a multiple of 32 (only supported for N > 32 without the ELU prologue)", p.C_in);
     QA_REQUIRE((p.ldx % 4) == 0, "conv_gemm: ldx=%lld must be a multiple of 4 floats", p.ldx);
     QA_REQUIRE((long long)p.T_in * p.ldx < (1LL << 31), "conv_gemm: one batch item spans %lld floats (limit 2^31)",
                (long long)p.T_in * p.ldx);

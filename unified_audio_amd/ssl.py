@@ -1,0 +1,121 @@
+"""Python mirror of the reference's SSL feature extraction, backed by libquarkaudio_hip.so.
+
+    SSLFeatureExtractor(wavs)  <->  HCodecTokenizer.extract_wav2vec2_features
+                                    (QuarkAudio-HCodec/HCodec-1.0/audio_tokenizer.py:35-48: hubert_base, mean of all hidden states;
+                                     HCodec-1.5/audio_tokenizer.py:53-67: wav2vec2-large-xlsr-53, hidden states 11, 14, 16)
+
+Weights come as the HF model's state_dict (`AutoModel.from_pretrained(...).state_dict()`), keys unchanged.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+
+@dataclasses.dataclass(frozen=True)
+class SSLSpec:
+    """Architecture constants (transformers HubertConfig / Wav2Vec2Config field names in the comments)."""
+    conv_dim: Tuple[int, ...] = (512,) * 7              # conv_dim
+    conv_kernel: Tuple[int, ...] = (10, 3, 3, 3, 3, 2, 2)  # conv_kernel
+    conv_stride: Tuple[int, ...] = (5, 2, 2, 2, 2, 2, 2)   # conv_stride
+    conv_bias: bool = False                             # conv_bias
+    feat_extract_norm: str = "group"                    # feat_extract_norm: "group" | "layer"
+    hidden_size: int = 768
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    do_stable_layer_norm: bool = False
+    num_conv_pos_embeddings: int = 128
+    num_conv_pos_embedding_groups: int = 16
+    layer_norm_eps: float = 1e-5
+    pad: int = 160                                      # F.pad(wavs, (160, 160))
+    select: Tuple[int, ...] = ()                        # hidden_states averaged; () = all
+    compress_exponent: float = 0.3                      # sign * |x| ** 0.3; 0 = off
+
+    def to_c(self) -> _lib.qa_ssl_spec:
+        s = _lib.qa_ssl_spec()
+        s.n_conv = len(self.conv_dim)
+        for i in range(s.n_conv):
+            s.conv_dim[i], s.conv_kernel[i], s.conv_stride[i] = self.conv_dim[i], self.conv_kernel[i], self.conv_stride[i]
+        s.conv_bias, s.feat_norm_layer = int(self.conv_bias), int(self.feat_extract_norm == "layer")
+        s.hidden, s.n_layers, s.n_heads, s.intermediate = (self.hidden_size, self.num_hidden_layers, self.num_attention_heads,
+                                                           self.intermediate_size)
+        s.stable_layer_norm = int(self.do_stable_layer_norm)
+        s.pos_kernel, s.pos_groups, s.pad = self.num_conv_pos_embeddings, self.num_conv_pos_embedding_groups, self.pad
+        s.n_select = len(self.select)
+        for i, v in enumerate(self.select):
+            s.select[i] = v
+        s.layer_norm_eps, s.compress_exponent = self.layer_norm_eps, self.compress_exponent
+        return s
+
+
+SPEC_HUBERT_BASE = SSLSpec()  # bosonai/hubert_base as H-Codec 1.0 / 2.0 use it
+SPEC_XLSR53 = SSLSpec(conv_bias=True, feat_extract_norm="layer", hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+                      intermediate_size=4096, do_stable_layer_norm=True, select=(11, 14, 16))  # H-Codec 1.5
+
+
+class SSLFeatureExtractor:
+    def __init__(self, spec: SSLSpec = SPEC_HUBERT_BASE, *, device: str | torch.device = "cuda:0"):
+        if spec.feat_extract_norm not in ("group", "layer"):
+            raise ValueError(f"feat_extract_norm={spec.feat_extract_norm!r}")
+        self.spec = spec
+        self.device = torch.device(device)
+        self._lib = _lib.load_library()
+        self._handle = C.c_void_p()
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        _lib.require_device()
+        self._free()
+        table, n, keep = _lib.tensor_table(state_dict)
+        handle = C.c_void_p()
+        cspec = self.spec.to_c()
+        _lib.check(self._lib.qa_ssl_create(C.byref(handle), C.byref(cspec), table, n, self.device.index or 0))
+        del keep
+        self._handle = handle
+        return self
+
+    def eval(self):
+        return self
+
+    def frames(self, n_samples: int) -> int:
+        self._require_loaded()
+        n = self._lib.qa_ssl_frames(self._handle, int(n_samples))
+        if n < 0:
+            _lib.check(int(n))
+        return int(n)
+
+    @torch.no_grad()
+    def __call__(self, wavs: torch.Tensor) -> torch.Tensor:
+        """wavs float32 [B, T] on the device -> feats_mix float32 [B, frames, hidden] (what the reference transposes to (b, d, t))."""
+        self._require_loaded()
+        if wavs.dim() != 2:
+            raise ValueError(f"wavs must be [B, T], got {tuple(wavs.shape)}")
+        wavs = wavs.to(device=self.device, dtype=torch.float32).contiguous()
+        B, T = wavs.shape
+        out = torch.empty(B, self.frames(T), self.spec.hidden_size, device=self.device, dtype=torch.float32)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.qa_ssl_forward(self._handle, C.c_void_p(wavs.data_ptr()), B, T, C.c_void_p(out.data_ptr()),
+                                            C.c_void_p(stream)))
+        return out
+
+    extract_wav2vec2_features = __call__
+
+    def _require_loaded(self):
+        if not self._handle.value:
+            raise _lib.QuarkAudioError(-1, "SSLFeatureExtractor: call load_state_dict first")
+
+    def _free(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.qa_ssl_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
