@@ -81,3 +81,29 @@ def test_ssl_rejects_short_input(qa_lib, gpu_device):
     fx = qa.SSLFeatureExtractor(qa.SSLSpec(**kw), device=gpu_device).load_state_dict(sd)
     with pytest.raises(qa.QuarkAudioError):
         fx(torch.zeros(1, 50, device=gpu_device))
+
+
+def test_tokenizer_with_hip_front_end_equals_precomputed_features(qa_lib, gpu_device):
+    """HCodecTokenizer.tokenize(wav) with the SSLFeatureExtractor in front == tokenize(wav, feats=extractor(wav))
+    (audio_tokenizer.py:56-62), and the frame count is the N50 the codec expects."""
+    import unified_audio_amd as qa
+    from oracle import hcodec_ref as R
+    from oracle import synth
+    from tests.util import MINI
+
+    sspec = S.SSLSpec(conv_dim=(64,) * 7, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
+                      num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=1)
+    ssd = S.synth_state_dict(9, sspec)
+    fx = qa.SSLFeatureExtractor(qa.SSLSpec(**{f: getattr(sspec, f) for f in sspec.__dataclass_fields__}), device=gpu_device).load_state_dict(ssd)
+    # a codec whose frame rates match the extractor: hop 640 = 2 * prod(ratios) with ratios (8, 5, 4, 2)
+    kw = dict(MINI, ratios=(8, 5, 4, 2), dimension=512, code_dim=512, enc_heads=8, hop=320, n_fft=1280)
+    ospec = R.HCodecSpec(**kw)
+    sd = synth.hcodec10_state_dict(13, ospec)
+    tok = qa.HCodecTokenizer(state_dict=sd, feature_extractor=fx, device=gpu_device, spec=qa.HCodecSpec(**kw))
+    wav = synth.synth_wav(14, 2, 640 * 12 - 100).to(gpu_device)  # not a multiple of the hop: pad_wav applies
+    ac, sc = tok.tokenize(wav)
+    feats = fx(tok.pad_wav(wav))
+    assert feats.shape[1] == 2 * ac.shape[-1]
+    ac2, sc2 = tok.tokenize(wav, feats=feats)
+    assert torch.equal(ac, ac2) and torch.equal(sc, sc2)
+    assert tok.detokenize(ac, sc).shape == (2, 640 * 12)

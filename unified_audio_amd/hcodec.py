@@ -249,8 +249,10 @@ class Codec:
 class HCodecTokenizer:
     """Drop-in for the reference's HCodecTokenizer (audio_tokenizer.py:18-66).
 
-    `feature_extractor(wav[B,T+320]) -> hidden_states` stays a PyTorch module (third-party SSL model, SURVEY.md 2.1
-    #18); pass it in, or pass precomputed features to `tokenize(wav, feats=...)`.
+    `feature_extractor`: either a `unified_audio_amd.SSLFeatureExtractor` (the HuBERT / XLSR front-end on the same HIP
+    library: `tokenize(wav)` then never leaves the device path), or the reference's PyTorch module
+    (`feature_extractor(wav[B,T+320], output_hidden_states=True).hidden_states`); or pass precomputed features to
+    `tokenize(wav, feats=...)`.
     """
 
     def __init__(self, pt_path=None, *, state_dict=None, feature_extractor: Optional[Callable] = None,
@@ -269,6 +271,10 @@ class HCodecTokenizer:
         """audio_tokenizer.py:35-48: pad (160,160), mean of all hidden states, sign*|x|^0.3 compression."""
         if self.feature_extractor is None:
             raise _lib.QuarkAudioError(-3, "no feature_extractor was given; pass feats= to tokenize()")
+        from .ssl import SSLFeatureExtractor
+
+        if isinstance(self.feature_extractor, SSLFeatureExtractor):  # padding, averaging and compression happen in the library
+            return self.feature_extractor(wavs)
         wavs = torch.nn.functional.pad(wavs, (160, 160))
         feats = self.feature_extractor(wavs, output_hidden_states=True)
         feats_mix = torch.stack(feats.hidden_states, dim=1).mean(1)
