@@ -193,7 +193,8 @@ int qa_set_serial(int32_t on);
 
 /* ---- SSL front-end ---------------------------------------------------------------------------
  * HCodecTokenizer.extract_wav2vec2_features (QuarkAudio-HCodec/HCodec-1.0/audio_tokenizer.py:35-48, HCodec-1.5/audio_tokenizer.py:53-67):
- * zero-pad `pad` samples each side, run the HuBERT / wav2vec 2.0 model (transformers HubertModel / Wav2Vec2Model: 7-layer
+ * and UniSE's Model.extract_semantic_features (QuarkAudio-UniSE/model/model.py:38-51, microsoft/wavlm-base-plus, no compression):
+ * zero-pad `pad` samples each side, run the HuBERT / wav2vec 2.0 / WavLM model (transformers HubertModel / Wav2Vec2Model / WavLMModel: 7-layer
  * Conv1d feature extractor, feature projection, grouped positional convolution, post-LN or stable-LN encoder), average the
  * selected hidden states, compress sign * |x|^e.  Weights: the HF state_dict (keys feature_extractor.conv_layers.*,
  * feature_projection.*, encoder.pos_conv_embed.conv.{parametrizations.weight.original0/1 | weight_g/weight_v | weight}, ...). */
@@ -215,7 +216,10 @@ typedef struct qa_ssl_spec {
     int32_t n_select;           /* number of hidden states averaged; 0 = all n_layers + 1 (torch.stack(hidden_states).mean) */
     int32_t select[32];         /* their indices into hidden_states (1.5: 11, 14, 16) */
     float layer_norm_eps;       /* 1e-5 */
-    float compress_exponent;    /* 0.3; <= 0: return the plain average */
+    float compress_exponent;    /* 0.3; <= 0: return the plain average (UniSE, QuarkAudio-UniSE/model/model.py:38-51) */
+    int32_t rel_pos_buckets;    /* 0 HuBERT / wav2vec2; 320 WavLM: gated relative position bias (WavLMAttention), keys
+                                   encoder.layers.0.attention.rel_attn_embed.weight, ...attention.gru_rel_pos_{linear,const} */
+    int32_t rel_pos_max_distance; /* 800 */
 } qa_ssl_spec;
 typedef struct qa_ssl qa_ssl;
 int qa_ssl_create(qa_ssl** out, const qa_ssl_spec* spec, const qa_tensor* tensors, int64_t n_tensors, int device);

@@ -6,7 +6,9 @@ What it restates
     HCodecTokenizer.extract_wav2vec2_features
         QuarkAudio-HCodec/HCodec-1.0/audio_tokenizer.py:35-48  (bosonai/hubert_base: mean over ALL hidden states)
         QuarkAudio-HCodec/HCodec-1.5/audio_tokenizer.py:53-67  (facebook/wav2vec2-large-xlsr-53: hidden states 11, 14, 16)
-    The model body is THIRD-PARTY: `transformers` HubertModel / Wav2Vec2Model (requirements pin 4.49.0 / 4.57.1; container has
+    Model.extract_semantic_features
+        QuarkAudio-UniSE/model/model.py:38-51                  (microsoft/wavlm-base-plus: mean over all hidden states, no compression)
+    The model body is THIRD-PARTY: `transformers` HubertModel / Wav2Vec2Model / WavLMModel (requirements pin 4.49.0 / 4.57.1; container has
     5.15.0), absent from /root/reference.  Its published algorithm is restated below with plain torch ops, module by module
     (transformers/models/hubert/modeling_hubert.py: HubertFeatureEncoder, HubertFeatureProjection,
     HubertPositionalConvEmbedding, HubertEncoder / HubertEncoderStableLayerNorm and their layers), driven by the HF
@@ -21,6 +23,7 @@ Pinning
 from __future__ import annotations
 
 import dataclasses
+import math
 from typing import Dict, List, Tuple
 
 import torch
@@ -45,19 +48,25 @@ class SSLSpec:
     pad: int = 160
     select: Tuple[int, ...] = ()
     compress_exponent: float = 0.3
+    num_buckets: int = 0            # WavLM: 320 (gated relative position bias); 0 = HuBERT / wav2vec 2.0
+    max_bucket_distance: int = 800
 
 
 SPEC_HUBERT_BASE = SSLSpec()
+# UniSE: Model.extract_semantic_features (QuarkAudio-UniSE/model/model.py:30,38-51): wavlm-base-plus, mean of all hidden states,
+# the compression lines are commented out in the reference
+SPEC_WAVLM_BASE_PLUS = SSLSpec(num_buckets=320, max_bucket_distance=800, compress_exponent=0.0)
 SPEC_XLSR53 = SSLSpec(conv_bias=True, feat_extract_norm="layer", hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
                       intermediate_size=4096, do_stable_layer_norm=True, select=(11, 14, 16))
 
 
 def hf_config(spec: SSLSpec, kind: str = "hubert"):
     """The transformers config whose model this spec describes (used by the pinning test and the weight synthesiser)."""
-    from transformers import HubertConfig, Wav2Vec2Config
+    from transformers import HubertConfig, Wav2Vec2Config, WavLMConfig
 
-    cls = HubertConfig if kind == "hubert" else Wav2Vec2Config
-    return cls(conv_dim=list(spec.conv_dim), conv_kernel=list(spec.conv_kernel), conv_stride=list(spec.conv_stride),
+    cls = {"hubert": HubertConfig, "wav2vec2": Wav2Vec2Config, "wavlm": WavLMConfig}[kind]
+    extra = dict(num_buckets=spec.num_buckets, max_bucket_distance=spec.max_bucket_distance) if kind == "wavlm" else {}
+    return cls(**extra, conv_dim=list(spec.conv_dim), conv_kernel=list(spec.conv_kernel), conv_stride=list(spec.conv_stride),
                conv_bias=spec.conv_bias, feat_extract_norm=spec.feat_extract_norm, hidden_size=spec.hidden_size,
                num_hidden_layers=spec.num_hidden_layers, num_attention_heads=spec.num_attention_heads,
                intermediate_size=spec.intermediate_size, do_stable_layer_norm=spec.do_stable_layer_norm,
@@ -69,10 +78,10 @@ def hf_config(spec: SSLSpec, kind: str = "hubert"):
 def synth_state_dict(seed: int, spec: SSLSpec, kind: str = "hubert") -> Dict[str, torch.Tensor]:
     """Seeded random weights in the HF key layout: the HF module's own initialisation under torch.manual_seed, with the
     norm affine parameters and biases perturbed so that every term of the computation is exercised."""
-    from transformers import HubertModel, Wav2Vec2Model
+    from transformers import HubertModel, Wav2Vec2Model, WavLMModel
 
     torch.manual_seed(seed)
-    model = (HubertModel if kind == "hubert" else Wav2Vec2Model)(hf_config(spec, kind)).eval()
+    model = {"hubert": HubertModel, "wav2vec2": Wav2Vec2Model, "wavlm": WavLMModel}[kind](hf_config(spec, kind)).eval()
     g = torch.Generator().manual_seed(seed + 1)
     sd = {}
     for k, v in model.state_dict().items():
@@ -83,6 +92,10 @@ def synth_state_dict(seed: int, spec: SSLSpec, kind: str = "hubert") -> Dict[str
             v = 1.0 + 0.1 * torch.randn(v.shape, generator=g)
         elif k.endswith(".bias"):
             v = 0.05 * torch.randn(v.shape, generator=g)
+        elif k.endswith("gru_rel_pos_const"):
+            v = 1.0 + 0.3 * torch.randn(v.shape, generator=g)
+        elif k.endswith("rel_attn_embed.weight") or k.endswith("gru_rel_pos_linear.weight"):
+            v = 0.5 * torch.randn(v.shape, generator=g)
         sd[k] = v
     return sd
 
@@ -132,12 +145,35 @@ def hidden_states(sd: Dict[str, torch.Tensor], wavs: torch.Tensor, spec: SSLSpec
     d, H = spec.hidden_size, spec.num_attention_heads
     hd = d // H
 
+    position_bias = None
+    if spec.num_buckets:
+        # WavLMAttention.compute_bias + _relative_positions_bucket (transformers/models/wavlm/modeling_wavlm.py): only layer 0
+        # owns rel_attn_embed, every layer re-uses its bias
+        n = x.shape[1]
+        rel = torch.arange(n)[None, :] - torch.arange(n)[:, None]  # memory_position - context_position
+        nb = spec.num_buckets // 2
+        bucket = (rel > 0).long() * nb
+        a = rel.abs()
+        max_exact = nb // 2
+        large = torch.log(a.float() / max_exact) / math.log(spec.max_bucket_distance / max_exact) * (nb - max_exact)
+        large = torch.min((max_exact + large).long(), torch.full_like(a, nb - 1))
+        bucket = bucket + torch.where(a < max_exact, a, large)
+        position_bias = F.embedding(bucket, sd["encoder.layers.0.attention.rel_attn_embed.weight"]).permute(2, 0, 1)  # [H, N, N]
+
     def attention(h, pre):
         B, N, _ = h.shape
         q = F.linear(h, sd[pre + "q_proj.weight"], sd[pre + "q_proj.bias"]).view(B, N, H, hd).transpose(1, 2)
         kk = F.linear(h, sd[pre + "k_proj.weight"], sd[pre + "k_proj.bias"]).view(B, N, H, hd).transpose(1, 2)
         v = F.linear(h, sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"]).view(B, N, H, hd).transpose(1, 2)
-        a = torch.softmax((q * hd ** -0.5) @ kk.transpose(-1, -2), dim=-1) @ v
+        scores = (q * hd ** -0.5) @ kk.transpose(-1, -2)
+        if position_bias is not None:  # WavLMAttention.forward: gate from the layer input, per (batch, head, query)
+            gh = h.view(B, N, H, hd).permute(0, 2, 1, 3)
+            proj = F.linear(gh, sd[pre + "gru_rel_pos_linear.weight"], sd[pre + "gru_rel_pos_linear.bias"])
+            proj = proj.view(B, H, N, 2, 4).sum(-1)
+            gate_a, gate_b = torch.sigmoid(proj).chunk(2, dim=-1)
+            gate = gate_a * (gate_b * sd[pre + "gru_rel_pos_const"] - 1.0) + 2.0  # [B, H, N, 1]
+            scores = scores + gate * position_bias[None]
+        a = torch.softmax(scores, dim=-1) @ v
         return F.linear(a.transpose(1, 2).reshape(B, N, d), sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
 
     def ffn(h, pre):

@@ -107,3 +107,21 @@ def test_tokenizer_with_hip_front_end_equals_precomputed_features(qa_lib, gpu_de
     ac2, sc2 = tok.tokenize(wav, feats=feats)
     assert torch.equal(ac, ac2) and torch.equal(sc, sc2)
     assert tok.detokenize(ac, sc).shape == (2, 640 * 12)
+
+
+def test_ssl_small_wavlm_gated_relative_bias(qa_lib, gpu_device):
+    """WavLM: few buckets / short saturation distance, so 26 frames cover the exact, logarithmic and saturated buckets."""
+    spec = S.SSLSpec(conv_dim=(64,) * 7, hidden_size=96, num_hidden_layers=3, num_attention_heads=3, intermediate_size=192,
+                     num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=2, num_buckets=16, max_bucket_distance=10)
+    err, cerr = _run(spec, "wavlm", B=2, T=8200, device=gpu_device)
+    print(err, cerr)
+    assert err < TOL and cerr < 1e-3
+
+
+def test_ssl_wavlm_base_plus_width(qa_lib, gpu_device):
+    """wavlm-base-plus widths and its 320 buckets / 800 max distance, 2 layers, 3 s (149 frames: exact + logarithmic buckets);
+    UniSE's recipe: plain mean of the hidden states (QuarkAudio-UniSE/model/model.py:38-51)."""
+    spec = dataclasses.replace(S.SPEC_WAVLM_BASE_PLUS, num_hidden_layers=2, compress_exponent=0.3)
+    err, cerr = _run(spec, "wavlm", B=2, T=48000, device=gpu_device)
+    print(err, cerr)
+    assert err < TOL and cerr < 1e-3

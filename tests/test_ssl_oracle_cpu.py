@@ -10,14 +10,16 @@ SMALL = dict(conv_dim=(64,) * 7, hidden_size=96, num_hidden_layers=3, num_attent
              num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=2)
 
 
-@pytest.mark.parametrize("kind,flavour", [("hubert", "base"), ("wav2vec2", "large"), ("hubert", "large")])
+@pytest.mark.parametrize("kind,flavour", [("hubert", "base"), ("wav2vec2", "large"), ("hubert", "large"), ("wavlm", "base")])
 def test_restatement_matches_transformers(kind, flavour):
-    from transformers import HubertModel, Wav2Vec2Model
+    from transformers import HubertModel, Wav2Vec2Model, WavLMModel
 
     spec = S.SSLSpec(**SMALL) if flavour == "base" else S.SSLSpec(**SMALL, conv_bias=True, feat_extract_norm="layer",
                                                                   do_stable_layer_norm=True, select=(1, 3))
+    if kind == "wavlm":  # few buckets and a short saturation distance so that 13 frames exercise exact, log and saturated buckets
+        spec = dataclasses.replace(spec, num_buckets=16, max_bucket_distance=10)
     sd = S.synth_state_dict(5, spec, kind)
-    model = (HubertModel if kind == "hubert" else Wav2Vec2Model)(S.hf_config(spec, kind)).eval()
+    model = {"hubert": HubertModel, "wav2vec2": Wav2Vec2Model, "wavlm": WavLMModel}[kind](S.hf_config(spec, kind)).eval()
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected and all("masked_spec_embed" in m for m in missing), (missing, unexpected)
     torch.manual_seed(0)

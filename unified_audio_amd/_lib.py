@@ -65,6 +65,7 @@ class qa_ssl_spec(C.Structure):
         ("n_heads", C.c_int32), ("intermediate", C.c_int32), ("stable_layer_norm", C.c_int32), ("pos_kernel", C.c_int32),
         ("pos_groups", C.c_int32), ("pad", C.c_int32), ("n_select", C.c_int32), ("select", C.c_int32 * 32),
         ("layer_norm_eps", C.c_float), ("compress_exponent", C.c_float),
+        ("rel_pos_buckets", C.c_int32), ("rel_pos_max_distance", C.c_int32),
     ]
 
 

@@ -16,11 +16,14 @@ namespace qa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int HD>
+// BIAS: WavLM's gated relative position bias (transformers WavLMAttention.forward): score(i, j) += gate[b, head, i] *
+// relbias[head][clamp(j - i, -R, R) + R]; the bucket function saturates below R, so the clamp is exact.
+template <int HD, bool BIAS>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, long long ldq,
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         long long ldkv, long long kv_bstride, float* __restrict__ out,
-                                                        long long ldo, int n_q, int n_keys, float scale, int causal) {
+                                                        long long ldo, int n_q, int n_keys, float scale, int causal,
+                                                        const float* __restrict__ gate, const float* __restrict__ relbias, int R) {
     constexpr int LD = HD + 4;
     constexpr int DT = HD / 32;
     constexpr int NG = HD / 8;
@@ -44,6 +47,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
             const float4 t = *reinterpret_cast<const float4*>(qp + 8 * g);
             qreg[4 * g + 0] = t.x; qreg[4 * g + 1] = t.y; qreg[4 * g + 2] = t.z; qreg[4 * g + 3] = t.w;
         }
+    }
+
+    float gate_q = 0.f;
+    const float* rb = nullptr;
+    if (BIAS) {
+        gate_q = gate[((long long)b * gridDim.y + head) * n_q + (qi < n_q ? qi : n_q - 1)];
+        rb = relbias + (long long)head * (2 * R + 1) + R;
     }
 
     f32x16 o[DT];
@@ -100,7 +110,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         for (int r = 0; r < 16; ++r) {
             const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             const bool ok = key < n_keys && (!causal || key <= qi + off);
-            s[r] = ok ? s[r] * scale : -INFINITY;
+            float sc = s[r] * scale;
+            if (BIAS) sc += gate_q * rb[max(-R, min(R, key - qi))];
+            s[r] = ok ? sc : -INFINITY;
             tmax = fmaxf(tmax, s[r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -145,15 +157,22 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
+// gate [B, H, n_q] and relbias [H, 2R+1] (both optional, together): gated relative position bias, see attention_kernel
 int launch_attention(const float* q, long long ldq, const float* k, const float* v, long long ldkv, float* out,
                      long long ldo, int B, int n_q, int n_keys, long long kv_batch_stride, int H, int hd, float scale,
-                     int causal, hipStream_t s) {
+                     int causal, hipStream_t s, const float* gate, const float* relbias, int R) {
     QA_REQUIRE(n_q > 0 && n_keys > 0 && (!causal || n_keys >= n_q), "attention: n_q=%d n_keys=%d", n_q, n_keys);
     QA_REQUIRE((ldq % 4) == 0 && (ldkv % 4) == 0 && (ldo % 4) == 0, "attention: strides must be multiples of 4");
+    QA_REQUIRE((gate == nullptr) == (relbias == nullptr) && (!gate || (R >= 0 && !causal && n_q == n_keys)),
+               "attention: gate and relbias come together, for non-causal self-attention");
     dim3 grid((unsigned)ceil_div(n_q, 128), H, B);
-#define QA_ATT(HD)                                                                                                  \
-    hipLaunchKernelGGL(attention_kernel<HD>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, \
-                       n_keys, scale, causal)
+#define QA_ATT(HD)                                                                                                          \
+    if (gate)                                                                                                                \
+        hipLaunchKernelGGL((attention_kernel<HD, true>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, \
+                           n_keys, scale, causal, gate, relbias, R);                                                        \
+    else                                                                                                                     \
+        hipLaunchKernelGGL((attention_kernel<HD, false>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, \
+                           n_keys, scale, causal, nullptr, nullptr, 0)
     switch (hd) {
         case 32: QA_ATT(32); break;
         case 64: QA_ATT(64); break;

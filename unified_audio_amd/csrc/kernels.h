@@ -41,9 +41,11 @@ int launch_istft_ola(const float* frames, const float* win, float* out, int B, i
 // attention.hip : softmax(Q K^T * scale) V over a fused [B*N, 3*H*hd] QKV buffer (RoPE already applied)
 //   causal = 0: full attention over the N keys of the same batch item (codec transformers)
 //   causal = 1: key j visible to query i iff j <= i + (n_keys - n_q) (LM prefill / decode over a KV cache)
+//   gate [B, H, n_q] + relbias [H, 2R+1] (optional): score(i, j) += gate[b,h,i] * relbias[h][clamp(j - i, -R, R) + R]
+//   (WavLM gated relative position bias)
 int launch_attention(const float* q, long long ldq, const float* k, const float* v, long long ldkv, float* out,
                      long long ldo, int B, int n_q, int n_keys, long long kv_batch_stride, int H, int hd, float scale,
-                     int causal, hipStream_t s);
+                     int causal, hipStream_t s, const float* gate = nullptr, const float* relbias = nullptr, int R = 0);
 
 // lstm.hip : one nn.LSTM layer (batch_first, zero initial state) given the precomputed input projection
 //   xw [B, T, 4d] = x W_ih^T + b_ih + b_hh with the 4d axis permuted to (unit, gate) order,

@@ -16,6 +16,8 @@ size_t ssl_conv0_scratch_bytes(int B, int T1, int C0);
 int launch_ssl_conv0(const float* wav, const float* w_kc, const float* bias, const float* gamma, const float* beta, float* y,
                      void* scratch, int B, int T, int T1, int C0, int ksize, int stride, int pad, int norm_group, float eps, int act,
                      hipStream_t s);
+int launch_ssl_gate(const float* hidden, const float* wab, const float* bab, const float* cst, float* gate, int B, int N, int H, int hd,
+                    hipStream_t s);
 int launch_ssl_accumulate(float* dst, const float* src, long long n, int first, hipStream_t s);
 int launch_ssl_act(float* x, long long n, int act, hipStream_t s);
 int launch_ssl_compress(const float* sum, float* out, long long n, float scale, float expo, hipStream_t s);
@@ -27,6 +29,7 @@ namespace {
 struct SslLayer {
     ConvW qkv, o, ff1, ff2;
     const float *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr;
+    const float *gate_w = nullptr, *gate_b = nullptr, *gate_c = nullptr;  // WavLM: folded gru_rel_pos_linear [2][hd], [2]; const [H]
 };
 }  // namespace
 
@@ -42,6 +45,7 @@ struct qa_ssl {
     ConvW fp;
     std::vector<ConvW> pos;                        // one per group
     const float *enc_ln_w = nullptr, *enc_ln_b = nullptr;
+    const float* relbias = nullptr;  // WavLM: [H][2R+1] relative position bias by clamped distance, R = rel_pos_max_distance
     std::vector<SslLayer> layers;
     std::vector<int> select;
     char* ws = nullptr;
@@ -241,6 +245,52 @@ int build(qa_ssl* h, const HostTable& tab) {
         linw(&L.ff2, pre + "feed_forward.output_dense", d, I);
         vec(&L.ln2w, pre + "final_layer_norm.weight", d);
         vec(&L.ln2b, pre + "final_layer_norm.bias", d);
+        if (sp.rel_pos_buckets > 0) {  // gate = f(sum of 4 outputs): fold rows 0..3 and 4..7 of the 8 x hd projection
+            const int hd = d / H;
+            const float* gw = tab.get(pre + "attention.gru_rel_pos_linear.weight", (int64_t)8 * hd);
+            const float* gb = tab.get(pre + "attention.gru_rel_pos_linear.bias", 8);
+            if (!gw || !gb) {
+                ok = false;
+            } else {
+                std::vector<float> w2((size_t)2 * hd, 0.f), b2(2, 0.f);
+                for (int r = 0; r < 8; ++r) {
+                    for (int e = 0; e < hd; ++e) w2[(size_t)(r / 4) * hd + e] += gw[(size_t)r * hd + e];
+                    b2[r / 4] += gb[r];
+                }
+                pend.push_back({&L.gate_w, st.add(w2)});
+                pend.push_back({&L.gate_b, st.add(b2)});
+            }
+            vec(&L.gate_c, pre + "attention.gru_rel_pos_const", H);
+        }
+    }
+    if (sp.rel_pos_buckets > 0) {
+        // WavLMAttention.compute_bias / _relative_positions_bucket, tabulated by relative distance r = key - query (float32
+        // arithmetic like the reference).  For |r| >= max_distance the bucket is saturated, so clamping r is exact.
+        QA_REQUIRE(sp.rel_pos_buckets % 4 == 0 && sp.rel_pos_max_distance > sp.rel_pos_buckets / 4, "ssl spec: relative position buckets");
+        const float* emb = tab.get("encoder.layers.0.attention.rel_attn_embed.weight", (int64_t)sp.rel_pos_buckets * H);
+        if (!emb) {
+            ok = false;
+        } else {
+            const int R = sp.rel_pos_max_distance, nb = sp.rel_pos_buckets / 2, max_exact = nb / 2;
+            std::vector<float> t((size_t)H * (2 * R + 1));
+            const float denom = (float)std::log((double)sp.rel_pos_max_distance / max_exact);
+            for (int r = -R; r <= R; ++r) {
+                int bucket = r > 0 ? nb : 0;
+                const int a = r < 0 ? -r : r;
+                if (a < max_exact) {
+                    bucket += a;
+                } else {
+                    float v = std::log((float)a / (float)max_exact);
+                    v = v / denom;
+                    v = v * (float)(nb - max_exact);
+                    long long big = (long long)((float)max_exact + v);
+                    if (big > nb - 1) big = nb - 1;
+                    bucket += (int)big;
+                }
+                for (int hh = 0; hh < H; ++hh) t[(size_t)hh * (2 * R + 1) + (r + R)] = emb[(size_t)bucket * H + hh];
+            }
+            pend.push_back({&h->relbias, st.add(t)});
+        }
     }
     if (!ok) return QA_ERR_INVALID;
     QA_TRY(st.upload());
@@ -296,6 +346,8 @@ int forward_graph(qa_ssl* h, Ctx& c, const float* wav, int B, int T, float* feat
     float* att = c.arena.alloc<float>((size_t)rows * d);
     float* ffu = c.arena.alloc<float>((size_t)rows * I);
     float* acc = c.arena.alloc<float>((size_t)rows * d);
+    const bool rel = sp.rel_pos_buckets > 0;
+    float* gate = rel ? c.arena.alloc<float>((size_t)rows * H) : nullptr;
     QA_TRY(layernorm(c, x, h->fp_ln_w, h->fp_ln_b, t0, rows, C, eps));
     QA_TRY(linear(c, t0, rows, h->fp, hcur));
     // ---- encoder front: h = h + GELU(pos_conv(h))  (HubertPositionalConvEmbedding; the even kernel's extra output frame is
@@ -327,9 +379,11 @@ int forward_graph(qa_ssl* h, Ctx& c, const float* wav, int B, int T, float* feat
         const SslLayer& Lw = h->layers[i];
         if (!sp.stable_layer_norm) {  // HubertEncoderLayer: x = LN(x + Attn(x)); x = LN(x + FFN(x))
             QA_TRY(linear(c, hcur, rows, Lw.qkv, qkv));
-            if (!c.dry)
+            if (!c.dry) {
+                if (rel) QA_TRY(launch_ssl_gate(hcur, Lw.gate_w, Lw.gate_b, Lw.gate_c, gate, B, N, H, hd, c.stream));
                 QA_TRY(launch_attention(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, B, N, N, (long long)N * 3 * d, H, hd, scale, 0,
-                                        c.stream));
+                                        c.stream, gate, rel ? h->relbias : nullptr, sp.rel_pos_max_distance));
+            }
             QA_TRY(linear(c, att, rows, Lw.o, tmp, ACT_NONE, hcur));
             QA_TRY(layernorm(c, tmp, Lw.ln1w, Lw.ln1b, hnext, rows, d, eps));
             QA_TRY(linear(c, hnext, rows, Lw.ff1, ffu, ACT_GELU));
@@ -339,9 +393,11 @@ int forward_graph(qa_ssl* h, Ctx& c, const float* wav, int B, int T, float* feat
         } else {  // HubertEncoderLayerStableLayerNorm: x = x + Attn(LN(x)); x = x + FFN(LN(x)); final LN after the last layer
             QA_TRY(layernorm(c, hcur, Lw.ln1w, Lw.ln1b, tmp, rows, d, eps));
             QA_TRY(linear(c, tmp, rows, Lw.qkv, qkv));
-            if (!c.dry)
+            if (!c.dry) {
+                if (rel) QA_TRY(launch_ssl_gate(tmp, Lw.gate_w, Lw.gate_b, Lw.gate_c, gate, B, N, H, hd, c.stream));
                 QA_TRY(launch_attention(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, B, N, N, (long long)N * 3 * d, H, hd, scale, 0,
-                                        c.stream));
+                                        c.stream, gate, rel ? h->relbias : nullptr, sp.rel_pos_max_distance));
+            }
             QA_TRY(linear(c, att, rows, Lw.o, hcur, ACT_NONE, hcur));
             QA_TRY(layernorm(c, hcur, Lw.ln2w, Lw.ln2b, tmp, rows, d, eps));
             QA_TRY(linear(c, tmp, rows, Lw.ff1, ffu, ACT_GELU));

@@ -116,6 +116,41 @@ int launch_ssl_conv0(const float* wav, const float* w_kc, const float* bias, con
     return QA_OK;
 }
 
+// ---- WavLM: gate of the relative position bias (WavLMAttention.forward steps 1-3) -----------------------------------------
+// gate[b, h, i] = a * (bb * const[h] - 1) + 2 with a = sigmoid(wA . x + bA), bb = sigmoid(wB . x + bB), x = hidden[b, i, h*hd : (h+1)*hd];
+// wA / wB are the sums of rows 0..3 / 4..7 of gru_rel_pos_linear (the reference sums the 4 outputs before the sigmoid).
+// One wave per (row, head).
+__global__ __launch_bounds__(256) void ssl_gate_kernel(const float* __restrict__ hidden, const float* __restrict__ wab,
+                                                       const float* __restrict__ bab, const float* __restrict__ cst,
+                                                       float* __restrict__ gate, int B, int N, int H, int hd) {
+    const int lane = threadIdx.x & 63;
+    const long long job = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (job >= (long long)B * N * H) return;
+    const int h = (int)(job % H);
+    const long long row = job / H;
+    const float* x = hidden + row * H * hd + (long long)h * hd;
+    float sa = 0.f, sb = 0.f;
+    for (int i = lane; i < hd; i += 64) {
+        const float xv = x[i];
+        sa = fmaf(xv, wab[i], sa);
+        sb = fmaf(xv, wab[hd + i], sb);
+    }
+    sa = wave_sum(sa);
+    sb = wave_sum(sb);
+    if (lane == 0) {
+        const float a = sigmoid_f(sa + bab[0]), bb = sigmoid_f(sb + bab[1]);
+        const int b = (int)(row / N), i = (int)(row % N);
+        gate[((long long)b * H + h) * N + i] = a * (bb * cst[h] - 1.f) + 2.f;
+    }
+}
+int launch_ssl_gate(const float* hidden, const float* wab, const float* bab, const float* cst, float* gate, int B, int N, int H, int hd,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(ssl_gate_kernel, dim3((unsigned)ceil_div((long long)B * N * H, 4)), dim3(256), 0, s, hidden, wab, bab, cst, gate, B,
+                       N, H, hd);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
 // ---- elementwise tail ---------------------------------------------------------------------------------------------------
 // dst = (first ? 0 : dst) + src                        (sum of the selected hidden states)
 __global__ void ssl_accumulate_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n4, int first) {

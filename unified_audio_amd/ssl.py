@@ -3,6 +3,8 @@
     SSLFeatureExtractor(wavs)  <->  HCodecTokenizer.extract_wav2vec2_features
                                     (QuarkAudio-HCodec/HCodec-1.0/audio_tokenizer.py:35-48: hubert_base, mean of all hidden states;
                                      HCodec-1.5/audio_tokenizer.py:53-67: wav2vec2-large-xlsr-53, hidden states 11, 14, 16)
+                               <->  Model.extract_semantic_features (QuarkAudio-UniSE/model/model.py:38-51: wavlm-base-plus,
+                                     mean of all hidden states, no compression) with SPEC_WAVLM_BASE_PLUS
 
 Weights come as the HF model's state_dict (`AutoModel.from_pretrained(...).state_dict()`), keys unchanged.
 """
@@ -36,6 +38,8 @@ class SSLSpec:
     pad: int = 160                                      # F.pad(wavs, (160, 160))
     select: Tuple[int, ...] = ()                        # hidden_states averaged; () = all
     compress_exponent: float = 0.3                      # sign * |x| ** 0.3; 0 = off
+    num_buckets: int = 0                                # WavLM gated relative position bias: 320 (0 = HuBERT / wav2vec2)
+    max_bucket_distance: int = 800
 
     def to_c(self) -> _lib.qa_ssl_spec:
         s = _lib.qa_ssl_spec()
@@ -51,12 +55,17 @@ class SSLSpec:
         for i, v in enumerate(self.select):
             s.select[i] = v
         s.layer_norm_eps, s.compress_exponent = self.layer_norm_eps, self.compress_exponent
+        s.rel_pos_buckets, s.rel_pos_max_distance = self.num_buckets, self.max_bucket_distance
         return s
 
 
 SPEC_HUBERT_BASE = SSLSpec()  # bosonai/hubert_base as H-Codec 1.0 / 2.0 use it
 SPEC_XLSR53 = SSLSpec(conv_bias=True, feat_extract_norm="layer", hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
                       intermediate_size=4096, do_stable_layer_norm=True, select=(11, 14, 16))  # H-Codec 1.5
+
+
+# microsoft/wavlm-base-plus as UniSE uses it (QuarkAudio-UniSE/model/model.py:30,38-51): mean of all hidden states, no compression
+SPEC_WAVLM_BASE_PLUS = SSLSpec(num_buckets=320, max_bucket_distance=800, compress_exponent=0.0)
 
 
 class SSLFeatureExtractor:
