@@ -126,6 +126,12 @@ def _ssl_state_dict(spec, seed=21):
         sd[pre + "feed_forward.intermediate_dense.weight"], sd[pre + "feed_forward.intermediate_dense.bias"] = rn(inter, d, scale=d ** -0.5), rn(inter)
         sd[pre + "feed_forward.output_dense.weight"], sd[pre + "feed_forward.output_dense.bias"] = rn(d, inter, scale=inter ** -0.5), rn(d)
         sd[pre + "final_layer_norm.weight"], sd[pre + "final_layer_norm.bias"] = 1.0 + rn(d, scale=0.1), rn(d)
+        if spec.num_buckets:  # WavLM
+            hd = d // spec.num_attention_heads
+            sd[pre + "attention.gru_rel_pos_linear.weight"], sd[pre + "attention.gru_rel_pos_linear.bias"] = rn(8, hd, scale=hd ** -0.5), rn(8)
+            sd[pre + "attention.gru_rel_pos_const"] = 1.0 + rn(1, spec.num_attention_heads, 1, 1, scale=0.1)
+            if i == 0:
+                sd[pre + "attention.rel_attn_embed.weight"] = rn(spec.num_buckets, spec.num_attention_heads, scale=0.5)
     return sd
 
 
@@ -134,7 +140,8 @@ def ssl_bench(dev, model, B, seconds, reps=3):
     (audio_tokenizer.py:47), HuBERT-base for 1.0 - on B clips of `seconds` at 16 kHz, waveform resident in HBM."""
     import unified_audio_amd as qa
 
-    spec, name = (qa.SPEC_XLSR53, "wav2vec2-large-xlsr-53") if model == "1.5" else (qa.SPEC_HUBERT_BASE, "hubert_base")
+    spec, name = {"1.5": (qa.SPEC_XLSR53, "wav2vec2-large-xlsr-53"), "unise": (qa.SPEC_WAVLM_BASE_PLUS, "wavlm-base-plus")}.get(
+        model, (qa.SPEC_HUBERT_BASE, "hubert_base"))
     sd = _ssl_state_dict(spec)
     n_params = sum(v.numel() for v in sd.values())
     fx = qa.SSLFeatureExtractor(spec, device=dev).load_state_dict(sd)
@@ -163,7 +170,8 @@ def ssl_bench(dev, model, B, seconds, reps=3):
     return {"metric": "audio-seconds/sec SSL feature extraction (front-end of Codec.encode)", "value": B * seconds / dt, "unit": "audio-seconds/sec",
             "ms_per_pass": 1e3 * dt, "tflops": B * fl / dt / 1e12,
             "config": {"workload": f"{name} architecture ({n_params / 1e6:.0f} M parameters, seeded random weights), {B} clips x {seconds:.0f} s @16 kHz, "
-                                   f"{L} frames x {d} per clip, hidden-state average + |x|^0.3 compression", "dtype": "f32"}}
+                                   f"{L} frames x {d} per clip, hidden-state average" + (" + |x|^0.3 compression" if spec.compress_exponent > 0 else ""),
+                       "dtype": "f32"}}
 
 
 def lm_bench(dev, rank, world, dist, batch, reps=2):
@@ -329,6 +337,8 @@ def main():
         log("SSL front-end ...")
         try:
             ssl_line = ssl_bench(dev, args.model, B, args.seconds)
+            if lm_line is not None:  # UniSE's own front-end (Model.extract_semantic_features): WavLM on the LM's 16 x 5 s segments
+                lm_line["ssl_frontend"] = ssl_bench(dev, "unise", args.lm_batch, 5.0)
         except Exception as e:  # secondary: never take the headline line down with it
             ssl_line = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
 
