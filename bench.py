@@ -178,11 +178,11 @@ def lm_bench(dev, rank, world, dist, batch, reps=2):
     """Secondary metric of BASELINE.json: UniSE AR tokens/sec = B * (33 + N) generated tokens / wall time of generate()
     (prefill included), SE prompt of 252 embeddings (5 s segment), 283 greedy steps, features resident in HBM."""
     import unified_audio_amd as qa
-    from oracle import llm_ref as L
+    from unified_audio_amd import synth
 
-    sd = L.lm_state_dict(4321)
+    sd = synth.lm_state_dict(4321)
     lm = qa.LLM_SFT(device=dev).load_state_dict(sd)
-    mix = L.synth_feats(50 + rank, batch, 250).to(dev)
+    mix = synth.synth_feats(50 + rank, batch, 250).to(dev)
     mel = torch.zeros(batch, 250, 80)
     best = float("inf")
     for i in range(reps + 1):
@@ -234,26 +234,22 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import unified_audio_amd as qa
-    from unified_audio_amd import _lib
-    from oracle import hcodec_ref as R
-    from oracle import synth
+    from unified_audio_amd import _lib, synth  # synthetic weights / inputs: data generation only; nothing under oracle/ is
+    #                                            imported outside the cpu_baseline worker
 
     lib = qa.load_library()
     global SR
     log(f"generating seeded H-Codec {args.model} weights ...")
     if args.model == "2.0":
-        from oracle import hcodec20_ref as R20
-
         SR = 48000
-        spec = R20.SPEC_20
+        spec = synth.Shapes20()
         sd = synth.hcodec20_state_dict(1234, spec)
         codec = qa.Codec(None, None, None, spec=qa.SPEC_20, device=dev).load_state_dict(sd)
         hop_in, frame_hop = spec.hop, spec.frame_hop
     else:
-        spec = R.SPEC_15 if args.model == "1.5" else R.SPEC_10
+        spec = qa.SPEC_15 if args.model == "1.5" else qa.SPEC_10
         sd = synth.hcodec10_state_dict(1234, spec)
-        kw = {f: getattr(spec, f) for f in spec.__dataclass_fields__}
-        codec = qa.Codec(None, None, None, spec=qa.HCodecSpec(**kw), device=dev).load_state_dict(sd)
+        codec = qa.Codec(None, None, None, spec=spec, device=dev).load_state_dict(sd)
         hop_in, frame_hop = 320, spec.enc_hop
     adaptive = getattr(spec, "adaptive", False)
     n_params = sum(v.numel() for v in sd.values())

@@ -61,46 +61,13 @@ SPEC_UNISE = LMSpec()
 TASK_MAP = {"se": 0, "tse": 1, "rtse": 2}  # config.yaml:132-136
 
 
+from unified_audio_amd.synth import synth_feats  # noqa: E402,F401  (pure data generation lives on the product side)
+from unified_audio_amd import synth as _synth  # noqa: E402
+
+
 def lm_state_dict(seed: int, spec: LMSpec = SPEC_UNISE) -> Dict[str, Tensor]:
-    """Seeded random weights (numpy PCG64) with the reference's key names.  Embedding / head scales are chosen so the
-    greedy arg-max is well separated most of the time, like a trained model's."""
-    rng = np.random.default_rng(seed)
-    d, v = spec.hidden, spec.vocab
-
-    def t(a):
-        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
-
-    def lin(o, i, gain=1.0):
-        return t(rng.uniform(-gain / math.sqrt(i), gain / math.sqrt(i), size=(o, i)))
-
-    sd = {
-        "task_embedding.weight": t(rng.standard_normal((spec.num_tasks, d))),
-        "enroll_sos_embedding.weight": t(rng.standard_normal((1, d))),
-        "mix_sos_embedding.weight": t(rng.standard_normal((1, d))),
-        "adapter.weight": lin(d, spec.feats_dim),
-        "adapter.bias": t(rng.uniform(-0.03, 0.03, size=d)),
-        "codec_embedding.weight": t(rng.standard_normal((v, d))),
-        "output_head.weight": lin(v, d, gain=3.0),
-        "norm.weight": t(1.0 + 0.1 * rng.standard_normal(d)),
-    }
-    for i in range(spec.n_layers):
-        p = f"layers.{i}"
-        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
-            sd[f"{p}.self_attn.{n}.weight"] = lin(d, d, gain=1.7)
-        sd[f"{p}.mlp.gate_proj.weight"] = lin(spec.intermediate, d, gain=1.7)
-        sd[f"{p}.mlp.up_proj.weight"] = lin(spec.intermediate, d, gain=1.7)
-        sd[f"{p}.mlp.down_proj.weight"] = lin(d, spec.intermediate, gain=1.7)
-        sd[f"{p}.input_layernorm.weight"] = t(1.0 + 0.1 * rng.standard_normal(d))
-        sd[f"{p}.post_attention_layernorm.weight"] = t(1.0 + 0.1 * rng.standard_normal(d))
-    return sd
-
-
-def synth_feats(seed: int, batch: int, frames: int, dim: int = 768) -> Tensor:
-    """WavLM-like features [B, frames, dim]: smoothed noise (model.py:38-51 takes the mean of 13 hidden states)."""
-    rng = np.random.default_rng(seed)
-    x = rng.standard_normal((batch, frames + 4, dim))
-    x = (x[:, :-4] + x[:, 1:-3] + x[:, 2:-2] + x[:, 3:-1] + x[:, 4:]) / math.sqrt(5.0)
-    return torch.from_numpy(x.astype(np.float32))
+    """Seeded random weights (numpy PCG64) with the reference's key names (generator: unified_audio_amd/synth.py)."""
+    return _synth.lm_state_dict(seed, spec)
 
 
 # ------------------------------------------------------------------------------- Llama body

@@ -8,7 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import unified_audio_amd as qa  # noqa: E402
-from oracle import llm_ref as L  # noqa: E402
+from unified_audio_amd import synth as L  # noqa: E402  (seeded weights / features: data generation only)
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
