@@ -1,0 +1,77 @@
+"""Host logic of the UniSE segmenting / batching driver against the reference's own lines (QuarkAudio-UniSE/model/model.py)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from unified_audio_amd import unise as U
+
+
+@pytest.mark.parametrize("T", [1, 7, 79999, 80000, 80001, 200000, 30001])
+def test_wrap_pad_is_numpy_wrap(T):
+    src = torch.arange(T, dtype=torch.float32)[None] * 0.5 - 3.0
+    seg_len = 5 * 16000
+    pad_len = math.ceil(src.size(-1) / seg_len) * seg_len - src.size(-1)          # model.py:176-177
+    want = torch.from_numpy(np.pad(src.numpy(), [(0, 0), (0, pad_len)], "wrap"))   # model.py:178
+    assert torch.equal(U.wrap_pad(src), want)
+
+
+def test_segment_se_normalises_by_utterance_peak_and_tse_does_not():
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn(1, 130001, generator=g) * 0.2
+    seg_len = 80000
+    pad_len = math.ceil(src.size(-1) / seg_len) * seg_len - src.size(-1)
+    want = torch.from_numpy(np.pad(src.numpy(), [(0, 0), (0, pad_len)], "wrap")).reshape(-1, seg_len)
+    assert torch.equal(U.segment(src, normalise=False), want)                      # model.py:199-203
+    assert torch.equal(U.segment(src, normalise=True), want / src.abs().max(dim=-1, keepdim=True)[0])  # model.py:179-182
+    with pytest.raises(ValueError):
+        U.segment(torch.zeros(2, 100), True)
+
+
+@pytest.mark.parametrize("T", [80000, 80001, 79999, 16000, 12345, 639, 641])
+def test_mel_frames_matches_torch_stft(T):
+    """stft_logmel of model.py:53-79 (hop 320, win = n_fft = 640, center=False) - frame count only."""
+    x = torch.zeros(1, T)
+    hop, win = 320, 640
+    pad_length = math.ceil(x.size(-1) / hop) * hop - x.size(-1)
+    xp = torch.nn.functional.pad(x, ((win - hop) // 2, pad_length + (win - hop) // 2))
+    spec = torch.stft(xp, win, hop, win_length=win, window=torch.hann_window(win), onesided=True, center=False, return_complex=True)
+    assert U.mel_frames(T) == spec.transpose(1, 2).shape[1]
+    assert U.mel_frames(80000) == 250
+
+
+def test_driver_batches_segments_of_several_utterances():
+    """Composition logic with stand-in models: segments of all utterances go through the front-end and the LM as ONE batch,
+    enrollments are tiled per utterance (model.py:207-210), tokens come back per utterance."""
+    calls = {}
+
+    class FakeSSL:
+        def __call__(self, wavs):
+            calls.setdefault("ssl", []).append(tuple(wavs.shape))
+            return wavs[:, :6:2].unsqueeze(-1).repeat(1, 1, 4)  # [B, 3, 4], carries the first samples of each segment
+
+    class FakeLM:
+        def generate(self, task_name, enroll_mel, enroll_feats, mix_mel, mix_feats, do_sample):
+            calls["lm"] = dict(task=task_name, B=mix_feats.shape[0], S=mix_mel.size(1),
+                               enroll=None if enroll_feats is None else enroll_feats.clone(), Ne=None if enroll_mel is None else enroll_mel.size(1))
+            B = mix_feats.shape[0]
+            return torch.arange(B * 32).view(B, 32), torch.arange(B * mix_mel.size(1)).view(B, -1)
+
+    drv = U.UniSE(FakeLM(), FakeSSL())
+    a, b = torch.randn(1, 90000), torch.randn(1, 170000)
+    out = drv.enhance_tokens("se", [a, b])
+    assert calls["ssl"] == [(5, 80000)] and calls["lm"]["B"] == 5 and calls["lm"]["S"] == 250 and calls["lm"]["enroll"] is None
+    assert [o[0].shape[0] for o in out] == [2, 3] and out[1][1][0, 0].item() == 2 * 250
+    ea, eb = torch.full((1, 48000), 1.0), torch.full((1, 48000), 2.0)
+    calls.clear()
+    out = drv.enhance_tokens("tse", [a, b], [ea, eb])
+    assert calls["ssl"] == [(5, 80000), (2, 48000)] and calls["lm"]["Ne"] == 150
+    e = calls["lm"]["enroll"]
+    assert e.shape[0] == 5 and (e[:2] == 1.0).all() and (e[2:] == 2.0).all()
+    with pytest.raises(ValueError):
+        drv.enhance_tokens("tse", [a, b], [ea])
+    with pytest.raises(KeyError):
+        drv.enhance_tokens("ss", [a])
+    with pytest.raises(RuntimeError):
+        drv.enhance("se", [a])
