@@ -621,7 +621,7 @@ int decode_tail(qa_hcodec* h, Ctx& c, const float* cat, int B, int N, float* wav
 
 int decode_graph(qa_hcodec* h, Ctx& c, const long long* ac, const long long* scodes, int B, int N, float* wav_out) {
     const qa_hcodec_spec& sp = h->spec;
-    const int Q = sp.num_quantizers, D = sp.code_dim, d = sp.dec_dim;
+    const int Q = sp.num_quantizers, D = sp.code_dim;
     const int64_t rows25 = (int64_t)B * N;
     long long* ia = c.arena.alloc<long long>(rows25 * Q);
     long long* is = c.arena.alloc<long long>(rows25 * Q);
