@@ -4,9 +4,12 @@ Follows /root/reference/QuarkAudio-UniSE/model/llm/llm_sft.py:93-195 (LLM_SFT.ge
 33 global + N semantic steps with vocabulary-range masks) and model/llm/llm.py:253-288 (sample_logits, greedy branch).
 The decoder body in the reference is HF transformers' LlamaDecoderLayer / LlamaRMSNorm / LlamaRotaryEmbedding
 (third-party, pins 4.49.0 / 4.57.1; llm.py:63-79,182-211); it is restated here from the published Llama arithmetic and
-validated against the container's transformers.LlamaModel by tests/test_llm_oracle_cpu.py.  The reference's own
-llm.py cannot be constructed under the installed transformers 5.x, and it ships no tests for this path
--> PARITY UNPINNED beyond that cross-check.  Nothing in the product path may import this module.
+validated against the container's transformers.LlamaModel by tests/test_llm_oracle_cpu.py.
+PINNED: tests/test_llm_pin_cpu.py runs the reference's own LLM_SFT.generate / sample_logits (imported from /root/reference
+through oracle/ref_llm_shim.py, three arithmetic-free compatibility patches for transformers 5.x) against this module on
+the same weights and inputs - greedy and sampled token streams are identical - and tests/golden/lm_*.npz hold token
+streams produced by that reference run (oracle/gen_golden_lm.py) for the GPU box.  Nothing in the product path may
+import this module.
 
 State-dict keys are the reference's (`LLM_SFT.state_dict()` = the Lightning checkpoint's `dnn.*` with the prefix
 stripped): task_embedding.weight, enroll_sos_embedding.weight, mix_sos_embedding.weight, adapter.{weight,bias},
@@ -144,13 +147,50 @@ def build_prompt(sd: Dict[str, Tensor], task: int, enroll_feats: Optional[Tensor
     return torch.cat(parts, dim=1)
 
 
+def filter_logits(logits: Tensor, top_k: int, top_p: float, temperature: float) -> Tensor:
+    """llm.py:262-279, the deterministic part of sample_logits on full-vocabulary logits (out-of-range entries already
+    -inf): top-k threshold (strictly-smaller entries removed, so ties with the k-th value survive) -> nucleus filter on
+    the descending sort (softmax, cumsum, shift right by one so the token that crosses top_p is kept) -> / temperature."""
+    logits = logits.clone()
+    if top_k > 0:
+        remove = logits < torch.topk(logits, top_k)[0][..., -1, None]
+        logits[remove] = float("-inf")
+    if top_p < 1.0:
+        sorted_logits, sorted_indices = torch.sort(logits, descending=True)
+        cumulative = torch.cumsum(F.softmax(sorted_logits, dim=-1), dim=-1)
+        sorted_remove = cumulative > top_p
+        sorted_remove[..., 1:] = sorted_remove[..., :-1].clone()
+        sorted_remove[..., 0] = 0
+        remove = sorted_remove.scatter(-1, sorted_indices, sorted_remove)
+        logits[remove] = float("-inf")
+    assert 0 < temperature <= 1.0  # llm.py:278
+    return logits / temperature
+
+
+def sample_logits(logits: Tensor, temperature: float = 0.8, top_k: int = 50, top_p: float = 0.95, do_sample: bool = True,
+                  generator: Optional[torch.Generator] = None) -> Tensor:
+    """CustomLlamaModel.sample_logits (llm.py:253-288): returns [B, 1] int64.  Sampling draws from torch's RNG exactly
+    like the reference (softmax + torch.multinomial), so under the same seed the two produce the same tokens."""
+    logits = filter_logits(logits, top_k, top_p, temperature)
+    if do_sample:
+        return torch.multinomial(F.softmax(logits, dim=-1), num_samples=1, generator=generator)
+    return torch.argmax(logits, dim=-1, keepdim=True)
+
+
+def sampling_distribution(logits: Tensor, temperature: float = 0.8, top_k: int = 50, top_p: float = 0.95) -> Tensor:
+    """Exact categorical distribution sample_logits draws from (for distribution tests of another sampler)."""
+    return F.softmax(filter_logits(logits, top_k, top_p, temperature), dim=-1)
+
+
 @torch.no_grad()
 def generate(sd: Dict[str, Tensor], task_name: str, enroll_feats: Optional[Tensor], mix_feats: Tensor,
-             semantic_length: int, global_length: int = 32, spec: LMSpec = SPEC_UNISE, forced: Optional[Tensor] = None):
-    """LLM_SFT.generate with do_sample=False (model.py:173).  Returns (global_ids [B,G], semantic_ids [B,S],
-    tokens [B, G+1+S] raw vocabulary ids, gaps [B, G+1+S] = top-1 minus top-2 logit inside the active range).
-    `forced` (raw ids [B, G+1+S]) teacher-forces the fed-back tokens so a different implementation's stream can be
-    audited step by step."""
+             semantic_length: int, global_length: int = 32, spec: LMSpec = SPEC_UNISE, forced: Optional[Tensor] = None,
+             do_sample: bool = False, temperature: float = 0.8, top_k: int = 50, top_p: float = 0.95,
+             generator: Optional[torch.Generator] = None, logits_out: Optional[list] = None):
+    """LLM_SFT.generate (llm_sft.py:93-195; the test path runs do_sample=False, model.py:173).  Returns (global_ids [B,G],
+    semantic_ids [B,S], tokens [B, G+1+S] raw vocabulary ids, gaps [B, G+1+S] = top-1 minus top-2 logit inside the active
+    range).  `forced` (raw ids [B, G+1+S]) teacher-forces the fed-back tokens so a different implementation's stream can
+    be audited step by step; `logits_out` (a list) collects the masked full-vocabulary logits of every step."""
     cache = KVCache(spec.n_layers)
     llm_forward(sd, build_prompt(sd, TASK_MAP[task_name], enroll_feats, mix_feats), cache, spec)
     b = mix_feats.shape[0]
@@ -160,9 +200,13 @@ def generate(sd: Dict[str, Tensor], task_name: str, enroll_feats: Optional[Tenso
         ids = torch.full((b,), first_id, dtype=torch.long)
         for _ in range(steps):
             hs = llm_forward(sd, sd["codec_embedding.weight"][ids][:, None, :], cache, spec)
-            logits = F.linear(hs[:, 0], sd["output_head.weight"])[:, lo:hi]  # range mask, llm_sft.py:150-153 / :180-182
-            top2 = logits.topk(2, dim=-1).values
-            nxt = logits.argmax(dim=-1) + lo  # sample_logits greedy branch (llm.py:286): top-k/top-p cannot move the arg-max
+            full = F.linear(hs[:, 0], sd["output_head.weight"])
+            masked = torch.full_like(full, float("-inf"))  # range mask, llm_sft.py:150-153 / :180-182
+            masked[:, lo:hi] = full[:, lo:hi]
+            if logits_out is not None:
+                logits_out.append(masked.clone())
+            top2 = masked.topk(2, dim=-1).values
+            nxt = sample_logits(masked, temperature, top_k, top_p, do_sample, generator)[:, 0]  # llm.py:253-288
             toks.append(nxt)
             gaps.append(top2[:, 0] - top2[:, 1])
             ids = nxt if forced is None else forced[:, len(toks) - 1]

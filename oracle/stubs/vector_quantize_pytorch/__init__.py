@@ -6,8 +6,10 @@ HCodec-1.0/vq/codec.py:101-119 (ctor), :171-172 (forward), :183-184 (get_output_
 in-tree statement of the same algorithm: vq/core_vq.py:223-231 (distance / arg-max of the negative),
 :394-404 (residual loop) and :406-412 (decode = sum of look-ups).
 
-PARITY UNPINNED: the real package is not reachable here, so this restatement has never been diffed
-against it ("Oracle").
+PINNED to the reference's in-tree statement: tests/test_rvq_pin_cpu.py runs this stand-in, oracle/rvq_ref.c and
+oracle/hcodec_ref.rvq_search/rvq_lookup against `vq.core_vq.ResidualVectorQuantization.encode/decode` imported from
+/root/reference (bit-exact indices and sums) and against tests/golden/rvq_corevq_*.npz which that module produced.
+The pip package itself (1.22.15) is not reachable here and has never been diffed ("Oracle").
 """
 import torch
 from torch import nn
