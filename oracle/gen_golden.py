@@ -4,7 +4,7 @@
 Run in the build container (the GPU box has no /root/reference):   python -m oracle.gen_golden
 The fixtures only hold seeds, integer codes, the reconstructed waveform and a few activation samples; weights and
 inputs are regenerated from the seeds (oracle/synth.py, numpy PCG64).  The RVQ stage of the reference is the third-party
-vector_quantize_pytorch package, replaced here by oracle/stubs (PARITY UNPINNED for that stage).
+vector_quantize_pytorch package, replaced here by oracle/stubs (pinned to vq/core_vq.py by tests/test_rvq_pin_cpu.py).
 """
 from __future__ import annotations
 

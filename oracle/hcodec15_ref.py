@@ -10,7 +10,7 @@ de-aggregation and a bottleneck transformer on decode).  Paths relative to /root
     interleaved-pair RoPE                          adaptive/model_blocks/mimi/module/rope.py:13-69
 
 Pinned against the reference's own modules by tests/test_oracle_cpu.py (where /root/reference exists) and by the
-committed golden vectors tests/golden/hcodec15_*.npz.  RVQ stage: third-party, PARITY UNPINNED (see hcodec_ref.py).
+committed golden vectors tests/golden/hcodec15_*.npz.  RVQ stage: third-party, pinned to vq/core_vq.py (see hcodec_ref.py).
 """
 from __future__ import annotations
 

@@ -9,7 +9,7 @@
     shared blocks                  same files as H-Codec 1.0 (restated in oracle/hcodec_ref.py)
 
 Pinned against the reference's own modules (constructed from a reduced YAML config, which is the reference's own code path) by
-tests/test_oracle_cpu.py and tests/golden/hcodec20_*.npz.  RVQ: third-party, PARITY UNPINNED.
+tests/test_oracle_cpu.py and tests/golden/hcodec20_*.npz.  RVQ: third-party, pinned to vq/core_vq.py (see hcodec_ref.py).
 """
 from __future__ import annotations
 

@@ -12,7 +12,9 @@ generate tests/golden/*), (b) this file on the GPU box, where /root/reference do
 Pinning status: validated against the reference's own modules on seeded weights by
 tests/test_oracle_vs_reference.py (runs where /root/reference exists) and against the committed
 vectors in tests/golden/ everywhere.  The RVQ stage is third-party in the reference
-(vector-quantize-pytorch==1.22.15, not vendored, not installed) -> that stage is PARITY UNPINNED.
+(vector-quantize-pytorch==1.22.15, not vendored, not installed); `rvq_search` / `rvq_lookup` here are pinned bit-exact to
+the reference's in-tree statement of the same algorithm, vq/core_vq.py:223-231,394-412 (tests/test_rvq_pin_cpu.py, live
+and through tests/golden/rvq_corevq_*.npz); the pip package itself has never been diffed.
 """
 from __future__ import annotations
 

@@ -1,11 +1,13 @@
 /* TEST INFRASTRUCTURE ONLY - plain-C restatement of the residual-VQ arithmetic of the H-Codec hot path.
  *
- * The reference calls the third-party vector_quantize_pytorch.ResidualVQ (==1.22.15, not vendored, not installed:
- * PARITY UNPINNED) at QuarkAudio-HCodec/HCodec-1.0/vq/codec.py:171-172 / :183-184; the same algorithm is stated
+ * The reference calls the third-party vector_quantize_pytorch.ResidualVQ (==1.22.15, not vendored, not installed;
+ * never diffed against that package) at QuarkAudio-HCodec/HCodec-1.0/vq/codec.py:171-172 / :183-184; the same algorithm is stated
  * in-tree by vq/core_vq.py:
  *   :223-231  dist = -(|x|^2 - 2 x.e^T + |e|^2), index = argmax(dist)  (first maximum wins)
  *   :394-404  for each stage: idx = quantize(residual); residual -= E[idx]
  *   :406-412  decode = sum over stages of E_q[idx_q]
+ * PINNED to that in-tree statement: tests/test_rvq_pin_cpu.py (bit-exact against core_vq.ResidualVectorQuantization
+ * imported from /root/reference, and against tests/golden/rvq_corevq_*.npz produced by it).
  * Nothing in the product path links this file; only tests/, smoke() and bench.py's cpu_baseline leg load it.
  */
 #include <math.h>
