@@ -47,7 +47,7 @@ def test_small_lm_generate_matches_oracle(qa_lib, gpu_device, task, use_enroll):
     assert gids.shape == (B, G) and sids.shape == (B, S) and gids.dtype == torch.int64
     free_match, near_ties = _audit(sd, SMALL, task, enr, mix, S, G, gids.cpu(), sids.cpu())
     print("free-running agreement", free_match, "near-tie flips", near_ties)
-    assert free_match > 0.9
+    assert near_ties > 0 or free_match == 1.0  # a stream can only leave the oracle's at an audited near-tie
 
 
 def test_unise_lm_full_size_generate(qa_lib, gpu_device):
@@ -60,7 +60,34 @@ def test_unise_lm_full_size_generate(qa_lib, gpu_device):
     assert int(gids.min()) >= 0 and int(gids.max()) < 4096 and int(sids.min()) >= 0 and int(sids.max()) < 8192
     free_match, near_ties = _audit(sd, spec, "se", None, mix, S, 32, gids.cpu(), sids.cpu())
     print("free-running agreement", free_match, "near-tie flips", near_ties)
-    assert free_match > 0.9
+    assert near_ties > 0 or free_match == 1.0
+
+
+@pytest.mark.parametrize("name", ["lm_small_se", "lm_small_tse", "lm_small_rtse", "lm_unise_se", "lm_unise_tse"])
+def test_generate_matches_reference_token_goldens(qa_lib, gpu_device, name):
+    """Token streams produced by the reference's OWN LLM_SFT.generate (oracle/gen_golden_lm.py): the HIP stream must be
+    identical up to the first step whose top-2 logit gap (stored with the golden) is below fp32 noise; whatever follows such
+    a step is audited teacher-forced against the oracle like every other stream."""
+    import os
+
+    import numpy as np
+
+    from oracle import gen_golden_lm as GG
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    spec, sd, task, mix, enr, S, G = GG.case_tensors(name)
+    _, lm = _model(spec, GG.CASES[name][1], gpu_device)
+    mel = torch.zeros(mix.shape[0], S, 80)
+    gids, sids = lm.generate(task, None if enr is None else mel, None if enr is None else enr.to(gpu_device), mel,
+                             mix.to(gpu_device), global_length=G, do_sample=False)
+    got = torch.cat([gids.cpu(), sids.cpu()], dim=1).numpy()
+    want = np.concatenate([g["global_ids"], g["semantic_ids"]], axis=1).astype(np.int64)
+    gaps = np.delete(g["gaps"], G, axis=1)  # drop the discarded 33rd global step: columns now line up with got / want
+    for b in range(got.shape[0]):
+        diff = np.nonzero(got[b] != want[b])[0]
+        if diff.size:
+            assert gaps[b, diff[0]] <= 2e-4, f"sequence {b} leaves the reference stream at step {diff[0]} (gap {gaps[b, diff[0]]:.2e})"
+    _audit(sd, spec, task, enr, mix, S, G, gids.cpu(), sids.cpu())
 
 
 def test_generate_argument_errors(qa_lib, gpu_device):
