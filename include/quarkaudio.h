@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define QA_VERSION 100 /* 0.1.0 */
+#define QA_VERSION 101 /* 0.1.1 */
 
 typedef enum qa_status {
     QA_OK = 0,
@@ -260,6 +260,21 @@ void qa_lm_destroy(qa_lm* lm);
 int qa_lm_generate(qa_lm* lm, int32_t task, const float* enroll_feats, int64_t n_enroll, const float* mix_feats,
                    int64_t n_mix, int64_t B, int32_t global_length, int32_t semantic_length, float temperature,
                    int32_t top_k, float top_p, int64_t* global_ids, int64_t* semantic_ids, void* stream);
+
+/* LLM_SFT.generate with do_sample=True (the signature default, llm_sft.py:106): every step filters the logits of the active
+ * vocabulary slice as CustomLlamaModel.sample_logits does (llm.py:253-288: top-k threshold with ties kept, nucleus filter on the
+ * un-tempered logits that keeps the token crossing top_p, / temperature, softmax) and draws one token per sequence.  The
+ * reference draws from torch's global generator; here the draw is a Philox4x32-10 uniform keyed by (seed, sequence, step), so the
+ * same seed reproduces the same streams and the DISTRIBUTION equals the reference's (the streams cannot). */
+int qa_lm_generate_sampled(qa_lm* lm, int32_t task, const float* enroll_feats, int64_t n_enroll, const float* mix_feats,
+                           int64_t n_mix, int64_t B, int32_t global_length, int32_t semantic_length, float temperature,
+                           int32_t top_k, float top_p, uint64_t seed, int64_t* global_ids, int64_t* semantic_ids, void* stream);
+
+/* Kernel-level entry point of the sampler (parity / distribution tests): CustomLlamaModel.sample_logits (llm.py:253-288) on
+ * logits [B, width] (row stride ld, device).  out_index int64 [B] (device).  do_sample = 0: arg-max (first maximum).
+ * Synchronises `stream`. */
+int qa_sample_logits(const float* logits, int64_t B, int64_t width, int64_t ld, int32_t top_k, float top_p, float temperature,
+                     int32_t do_sample, uint64_t seed, int64_t* out_index, void* stream);
 
 #ifdef __cplusplus
 }

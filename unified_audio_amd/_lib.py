@@ -105,6 +105,11 @@ SYMBOLS = {
     "qa_lm_generate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                  C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
+    "qa_lm_generate_sampled": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                         C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_uint64, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
+    "qa_sample_logits": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_int32,
+                                   C.c_uint64, C.c_void_p, C.c_void_p]),
 }
 
 

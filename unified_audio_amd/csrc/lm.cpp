@@ -10,7 +10,10 @@
 // and each decode step on the weight-streaming skinny GEMM + single-query attention kernels.
 #include <memory>
 
+#include <cstdlib>
+
 #include "host_util.h"
+#include "lm_decode.h"
 
 namespace qa {
 int launch_assemble_prompt(float* x, const float* task_vec, const float* enroll_sos, const float* enroll_emb,
@@ -28,6 +31,7 @@ int launch_rope_kv(float* qkv, const float* cs, float* kc, float* vc, int B, int
 int launch_attention_decode(const float* q, long long ldq, const float* kc, const float* vc, long long kv_bstride,
                             long long ldkv, float* out, long long ldo, int B, int H, int hd, int n_keys, float scale,
                             hipStream_t s);
+
 }  // namespace qa
 
 using namespace qa;
@@ -37,13 +41,35 @@ struct LMLayer {
     // RMSNorm weights are folded into the consuming projections (W' = W diag(w)): qkv <- input_layernorm, gate/up <- post_attention_layernorm
     ConvW qkv, o, gate, up, down;
     const float* gate_up = nullptr;  // decode layout: per 16-column group 16 gate rows then 16 up rows (both norm-folded)
+    // fused decode step (lm_decode.hip): tile-major rows; qkv_dec pairs rotary partners (i, i + hd/2) inside a tile,
+    // gu_dec holds per tile NT/2 gate rows then NT/2 up rows (both norm-folded)
+    const float* qkv_dec = nullptr;
+    const float* gu_dec = nullptr;
 };
 constexpr int LM_MAX_POS = 4096;  // max_position_embeddings (conf/config.yaml:146)
 }  // namespace
 
+struct StepGraph {  // one captured decode step of a phase, replayable because every loop-carried scalar lives in device state
+    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph = nullptr;
+    uint64_t key = 0;
+    void reset() {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        exec = nullptr;
+        graph = nullptr;
+        key = 0;
+    }
+};
+
 struct qa_lm {
     qa_lm_spec spec{};
     int device = 0;
+    bool fused_ok = false;   // the shapes fit the fused decode step (otherwise the per-op decode path runs)
+    int nt_qkv = 0, nt_o = 0, nt_gu = 0, nt_down = 0;
+    hipStream_t cap_stream = nullptr;
+    StepGraph graphs[2];     // [0] global phase, [1] semantic phase
+    unsigned long long calls = 0;
     WeightStore store;
     const float *task_emb = nullptr, *enroll_sos = nullptr, *mix_sos = nullptr, *codec_emb = nullptr, *ones = nullptr,
                 *rope = nullptr;  // `ones`: unit RMSNorm weight (the learned ones are folded into the projections)
@@ -86,6 +112,13 @@ int build_lm(qa_lm* lm, const HostTable& tab) {
     const int hd = d / sp.n_heads;
     QA_REQUIRE(hd == 32 || hd == 64 || hd == 128, "lm spec: head_dim %d unsupported", hd);
     QA_REQUIRE(d % 32 == 0 && I % 32 == 0 && sp.feats_dim % 32 == 0, "lm spec: widths must be multiples of 32");
+    // fused decode step: K of every GEMV a multiple of 256, every N a multiple of its tile width, rotary pairs inside a tile
+    lm->nt_qkv = lm_pick_nt(3 * d);
+    lm->nt_o = lm_pick_nt(d);
+    lm->nt_gu = lm_pick_nt(2 * I);
+    lm->nt_down = lm_pick_nt(d);
+    lm->fused_ok = lm_gemv_supported(d, I) && d % lm->nt_qkv == 0 && hd % lm->nt_qkv == 0 && d % lm->nt_o == 0 &&
+                   (2 * I) % lm->nt_gu == 0 && hd % 8 == 0 && std::getenv("QA_LM_UNFUSED") == nullptr;
     WeightStore& st = lm->store;
     bool ok = true;
     std::vector<std::pair<const float**, size_t>> pend;
@@ -139,6 +172,20 @@ int build_lm(qa_lm* lm, const HostTable& tab) {
         }
         L.qkv.N = 3 * d; L.qkv.C_in = d;
         pend.push_back({&L.qkv.w, st.add(wq)});
+        if (lm->fused_ok) {  // tile t of a section: rows [t*NT/2, (t+1)*NT/2) of each head-half, first halves then partner halves
+            const int nt = lm->nt_qkv, hp = nt / 2;
+            std::vector<float> wd((size_t)3 * d * d);
+            size_t r = 0;
+            for (int sec = 0; sec < 3; ++sec)
+                for (int h = 0; h < sp.n_heads; ++h)
+                    for (int t = 0; t < hd / nt; ++t)
+                        for (int half = 0; half < 2; ++half)
+                            for (int j = 0; j < hp; ++j, ++r) {
+                                const size_t src = (size_t)sec * d + (size_t)h * hd + (size_t)half * (hd / 2) + (size_t)t * hp + j;
+                                std::memcpy(&wd[r * d], &wq[src * d], sizeof(float) * d);
+                            }
+            pend.push_back({&L.qkv_dec, st.add(wd)});
+        }
         L.o.N = d; L.o.C_in = d;
         vec(&L.o.w, p + ".self_attn.o_proj.weight", (int64_t)d * d);
         L.gate.N = I; L.gate.C_in = d;
@@ -155,6 +202,15 @@ int build_lm(qa_lm* lm, const HostTable& tab) {
                         std::memcpy(&gu[(size_t)(blk * 32 + 16) * d], &u[(size_t)(blk * 16) * d], sizeof(float) * 16 * d);
                     }
                     pend.push_back({&L.gate_up, st.add(gu)});
+                }
+                if (lm->fused_ok) {
+                    const int hp = lm->nt_gu / 2;
+                    std::vector<float> gd((size_t)2 * I * d);
+                    for (int t = 0; t < I / hp; ++t) {
+                        std::memcpy(&gd[(size_t)(t * 2 * hp) * d], &g[(size_t)(t * hp) * d], sizeof(float) * hp * d);
+                        std::memcpy(&gd[(size_t)(t * 2 * hp + hp) * d], &u[(size_t)(t * hp) * d], sizeof(float) * hp * d);
+                    }
+                    pend.push_back({&L.gu_dec, st.add(gd)});
                 }
             } else {
                 ok = false;
@@ -185,9 +241,21 @@ struct LMBuffers {
     float *x, *hn, *qkv, *att, *g, *u, *logits;
     float *kc, *vc;
     long long* tok;
+    // fused decode step
+    float *q, *att_part, *pmax;
+    int *pidx, *state;
+    long long *ids_g, *ids_s;
+    int cap, S_att;
 };
 
-// one pass of the Llama body over `n` new positions per sequence, positions pos0..pos0+n-1
+struct SampleCfg {
+    int do_sample;
+    int top_k;
+    float top_p, temperature;
+    unsigned long long seed;
+};
+
+// one pass of the Llama body over `n` new positions per sequence, positions pos0..pos0+n-1 (prefill; per-op decode fallback)
 int lm_body(qa_lm* lm, Ctx& c, LMBuffers& b, int B, int n, int pos0, int max_len, bool skip_last_mlp) {
     const qa_lm_spec& sp = lm->spec;
     const int d = sp.hidden, H = sp.n_heads, hd = d / H;
@@ -230,15 +298,95 @@ int lm_body(qa_lm* lm, Ctx& c, LMBuffers& b, int B, int n, int pos0, int max_len
     return QA_OK;
 }
 
-int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, const float* mix, int Nm, int B, int G,
-                   int S, long long* gids, long long* sids) {
+// tile width of the head GEMV over a vocabulary slice of `width` entries (0: the slice does not tile)
+int head_nt(int width) {
+    int nt = lm_pick_nt(width);
+    while (nt >= 4 && width % nt) nt >>= 1;
+    return nt >= 4 ? nt : 0;
+}
+
+// ONE decode step as 5 launches per layer + 2 (lm_decode.hip).  Everything step-dependent (position, ids column, RNG step) is read
+// from b.state on the device, so the launch arguments are identical for every step of a phase: the sequence can be captured once
+// into a hipGraph and replayed.
+int fused_step(qa_lm* lm, const LMBuffers& b, int B, int lo, int width, long long* ids, int ids_ld, int keep, const SampleCfg& sc,
+               hipStream_t s) {
     const qa_lm_spec& sp = lm->spec;
-    const int d = sp.hidden, I = sp.intermediate;
+    const int d = sp.hidden, H = sp.n_heads, hd = d / H, I = sp.intermediate;
+    const float scale = 1.0f / std::sqrt((float)hd);
+    const long long kv_bstride = (long long)b.cap * d;
+    const size_t cache_stride = (size_t)B * b.cap * d;
+    for (int i = 0; i < sp.n_layers; ++i) {
+        const LMLayer& L = lm->layers[i];
+        float* kc = b.kc + i * cache_stride;
+        float* vc = b.vc + i * cache_stride;
+        GemvArgs a{};
+        a.M = B; a.rms_eps = sp.rms_eps; a.state = b.state; a.H = H; a.hd = hd; a.d = d;
+        // 1. RMSNorm + QKV + RoPE + cache append; layer 0 gathers its input rows from codec_embedding (llm_sft.py:140,169)
+        GemvArgs q = a;
+        q.x = b.x; q.ldx = d;
+        if (i == 0) { q.tok = b.tok; q.table = lm->codec_emb; }
+        q.w = L.qkv_dec; q.N = 3 * d; q.K = d;
+        q.rope = lm->rope; q.q = b.q; q.kc = kc; q.vc = vc; q.kv_bstride = kv_bstride;
+        QA_TRY(launch_lm_gemv(q, GM_QKV, lm->nt_qkv, s));
+        // 2. attention over the cache (pos + 1 keys), split over S_att workgroups per (sequence, head)
+        QA_TRY(launch_lm_attn(b.q, d, kc, vc, kv_bstride, d, b.att_part, B, H, hd, b.S_att, b.state, scale, s));
+        // 3. merge of the partials + o_proj + residual
+        GemvArgs o = a;
+        o.att_part = b.att_part; o.S = b.S_att;
+        o.w = L.o.w; o.N = d; o.K = d; o.ldx = d;
+        if (i == 0) { o.res_tok = b.tok; o.res_table = lm->codec_emb; } else { o.res = b.x; }
+        o.ldr = d; o.y = b.x; o.ldy = d;
+        QA_TRY(launch_lm_gemv(o, GM_RESID, lm->nt_o, s));
+        // 4. RMSNorm + gate / up + SwiGLU
+        GemvArgs g = a;
+        g.x = b.x; g.ldx = d; g.w = L.gu_dec; g.N = 2 * I; g.K = d; g.y = b.u; g.ldy = I;
+        QA_TRY(launch_lm_gemv(g, GM_GATEUP, lm->nt_gu, s));
+        // 5. down_proj + residual
+        GemvArgs dn = a;
+        dn.x = b.u; dn.ldx = I; dn.w = L.down.w; dn.N = d; dn.K = I; dn.res = b.x; dn.ldr = d; dn.y = b.x; dn.ldy = d;
+        QA_TRY(launch_lm_gemv(dn, GM_RESID, lm->nt_down, s));
+    }
+    // 6. final RMSNorm (weight folded into output_head) + the rows of output_head inside the active vocabulary slice (the range
+    //    mask of llm_sft.py:150-153 / :180-182 sets everything else to -inf) + per-tile arg-max
+    const int nt = head_nt(width);
+    GemvArgs hg{};
+    hg.M = B; hg.rms_eps = sp.rms_eps; hg.state = b.state; hg.H = H; hg.hd = hd; hg.d = d;
+    hg.x = b.x; hg.ldx = d; hg.w = lm->head.w + (size_t)lo * d; hg.N = width; hg.K = d;
+    hg.pmax = b.pmax; hg.pidx = b.pidx; hg.logits = sc.do_sample ? b.logits : nullptr; hg.ldl = width;
+    QA_TRY(launch_lm_gemv(hg, GM_HEAD, nt, s));
+    // 7. next token
+    if (!sc.do_sample) {
+        QA_TRY(launch_lm_pick(b.pmax, b.pidx, width / nt, B, lo, b.tok, ids, ids_ld, keep, b.state, s));
+    } else {
+        QA_TRY(launch_lm_sample(b.logits, width, width, B, lo, sc.top_k, sc.top_p, sc.temperature, 1, b.tok, ids, ids_ld, keep, b.state, s));
+        QA_TRY(launch_lm_advance(b.state, s));
+    }
+    return QA_OK;
+}
+
+uint64_t mix_key(uint64_t h, uint64_t v) {
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    return h;
+}
+
+bool use_graphs() {
+    const char* e = std::getenv("QA_LM_GRAPH");
+    return !(e && e[0] == '0');
+}
+
+int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, const float* mix, int Nm, int B, int G,
+                   int S, long long* gids, long long* sids, const SampleCfg& sc) {
+    const qa_lm_spec& sp = lm->spec;
+    const int d = sp.hidden, I = sp.intermediate, H = sp.n_heads;
     const int L = 1 + (enroll ? 1 + Ne : 0) + 1 + Nm;
     const int max_len = L + G + 1 + S;
     QA_REQUIRE(max_len <= LM_MAX_POS, "generate: %d positions exceed max_position_embeddings %d", max_len, LM_MAX_POS);
+    const int cap = (int)round_up(max_len, 64);  // cache row stride: shapes that round alike share their captured step graphs
+    const bool fused = lm->fused_ok && B <= 32 && head_nt(sp.global_size) && head_nt(sp.semantic_size);
     const int64_t prow = (int64_t)B * L;
     LMBuffers b{};
+    b.cap = cap;
+    b.S_att = std::max(1, std::min(4, 256 / std::max(1, H * B)));
     b.x = c.arena.alloc<float>(prow * d);
     b.hn = c.arena.alloc<float>(prow * d);
     b.qkv = c.arena.alloc<float>(prow * 3 * d);
@@ -247,9 +395,16 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
     b.u = c.arena.alloc<float>(prow * I);
     const int wmax = std::max(sp.global_size, sp.semantic_size);
     b.logits = c.arena.alloc<float>((size_t)B * wmax);
-    b.kc = c.arena.alloc<float>((size_t)sp.n_layers * B * max_len * d);
-    b.vc = c.arena.alloc<float>((size_t)sp.n_layers * B * max_len * d);
+    b.kc = c.arena.alloc<float>((size_t)sp.n_layers * B * cap * d);
+    b.vc = c.arena.alloc<float>((size_t)sp.n_layers * B * cap * d);
     b.tok = c.arena.alloc<long long>(B);
+    b.q = c.arena.alloc<float>((size_t)B * d);
+    b.att_part = c.arena.alloc<float>((size_t)B * H * b.S_att * (d / H + 4));
+    b.pmax = c.arena.alloc<float>((size_t)B * (wmax / 4 + 1));
+    b.pidx = c.arena.alloc<int>((size_t)B * (wmax / 4 + 1));
+    b.state = c.arena.alloc<int>(ST_WORDS);
+    b.ids_g = c.arena.alloc<long long>((size_t)B * std::max(G, 1));
+    b.ids_s = c.arena.alloc<long long>((size_t)B * std::max(S, 1));
     float* emix = c.arena.alloc<float>((size_t)B * Nm * d);
     float* eenr = enroll ? c.arena.alloc<float>((size_t)B * Ne * d) : nullptr;
     if (c.dry) return QA_OK;
@@ -259,34 +414,74 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
     if (enroll) QA_TRY(lm_linear(c, enroll, (int64_t)B * Ne, lm->adapter, eenr));
     QA_TRY(launch_assemble_prompt(b.x, lm->task_emb + (size_t)task * d, enroll ? lm->enroll_sos : nullptr, eenr, lm->mix_sos,
                                   emix, B, Ne, Nm, d, c.stream));
-    QA_TRY(lm_body(lm, c, b, B, L, 0, max_len, true));
+    QA_TRY(lm_body(lm, c, b, B, L, 0, cap, true));
 
     // ---- decode: G+1 global tokens (the last is fed to the cache but discarded), then S semantic tokens
     int pos = L;
-    auto phase = [&](long long first_id, int steps, int lo, int width, long long* ids, int ids_ld, int keep) -> int {
-        QA_TRY(launch_fill_i64(b.tok, first_id, B, c.stream));
-        for (int st = 0; st < steps; ++st, ++pos) {
+    const bool graphs = fused && use_graphs();
+    auto phase = [&](int which, long long first_id, int steps, int lo, int width, long long* ids, int ids_ld, int keep) -> int {
+        QA_TRY(launch_lm_phase_init(b.tok, first_id, B, b.state, pos, which == 0, sc.seed, c.stream));
+        if (fused) {
+            if (graphs && steps > 0) {
+                StepGraph& g = lm->graphs[which];
+                uint64_t key = 0x51ull;
+                for (uint64_t v : {(uint64_t)(uintptr_t)lm->ws, (uint64_t)B, (uint64_t)cap, (uint64_t)L, (uint64_t)G, (uint64_t)S,
+                                   (uint64_t)Ne, (uint64_t)lo, (uint64_t)width, (uint64_t)keep, (uint64_t)sc.do_sample,
+                                   (uint64_t)sc.top_k, (uint64_t)(sc.top_p * 1e6f), (uint64_t)(sc.temperature * 1e6f)})
+                    key = mix_key(key, v);
+                if (!g.exec || g.key != key) {
+                    g.reset();
+                    if (!lm->cap_stream) QA_HIP(hipStreamCreateWithFlags(&lm->cap_stream, hipStreamNonBlocking));
+                    QA_HIP(hipStreamBeginCapture(lm->cap_stream, hipStreamCaptureModeThreadLocal));
+                    const int st = fused_step(lm, b, B, lo, width, ids, ids_ld, keep, sc, lm->cap_stream);
+                    hipGraph_t graph = nullptr;
+                    const hipError_t e = hipStreamEndCapture(lm->cap_stream, &graph);
+                    if (st != QA_OK) {
+                        if (graph) (void)hipGraphDestroy(graph);
+                        return st;
+                    }
+                    QA_HIP(e);
+                    g.graph = graph;
+                    QA_HIP(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+                    g.key = key;
+                }
+                for (int st = 0; st < steps; ++st) QA_HIP(hipGraphLaunch(g.exec, c.stream));
+            } else {
+                for (int st = 0; st < steps; ++st) QA_TRY(fused_step(lm, b, B, lo, width, ids, ids_ld, keep, sc, c.stream));
+            }
+            pos += steps;
+            return QA_OK;
+        }
+        for (int st = 0; st < steps; ++st, ++pos) {  // per-op fallback for shapes the fused step does not tile
             QA_TRY(launch_embed(b.tok, lm->codec_emb, b.x, B, d, c.stream));
-            QA_TRY(lm_body(lm, c, b, B, 1, pos, max_len, false));
-            // final RMSNorm fused (its weight is folded into output_head); only the rows of output_head inside the active
-            // vocabulary slice are multiplied (the mask sets the rest to -inf)
+            QA_TRY(lm_body(lm, c, b, B, 1, pos, cap, false));
             if (skinny_ok(B, lm->head)) {
                 QA_TRY(lm_linear(c, b.x, B, lm->head, b.logits, nullptr, nullptr, width, lm->head.w + (size_t)lo * d, sp.rms_eps));
             } else {
                 QA_TRY(launch_rmsnorm(b.x, lm->ones, b.hn, B, d, sp.rms_eps, c.stream));
                 QA_TRY(lm_linear(c, b.hn, B, lm->head, b.logits, nullptr, nullptr, width, lm->head.w + (size_t)lo * d));
             }
-            QA_TRY(launch_argmax(b.logits, B, width, width, lo, b.tok, st < keep ? ids : nullptr, ids_ld, st, c.stream));
+            if (sc.do_sample) {
+                QA_TRY(launch_lm_sample(b.logits, width, width, B, lo, sc.top_k, sc.top_p, sc.temperature, 1, b.tok, ids, ids_ld, keep,
+                                        b.state, c.stream));
+                QA_TRY(launch_lm_advance(b.state, c.stream));
+            } else {
+                QA_TRY(launch_argmax(b.logits, B, width, width, lo, b.tok, st < keep ? ids : nullptr, ids_ld, st, c.stream));
+            }
         }
         return QA_OK;
     };
-    QA_TRY(phase(0, G + 1, 3, sp.global_size, gids, G, G));                            // llm_sft.py:137-164
-    QA_TRY(phase(1, S, 3 + sp.global_size, sp.semantic_size, sids, S, S));             // llm_sft.py:166-193
+    QA_TRY(phase(0, 0, G + 1, 3, sp.global_size, b.ids_g, G, G));                            // llm_sft.py:137-164
+    QA_TRY(phase(1, 1, S, 3 + sp.global_size, sp.semantic_size, b.ids_s, S, S));            // llm_sft.py:166-193
+    if (G > 0) QA_HIP(hipMemcpyAsync(gids, b.ids_g, sizeof(long long) * (size_t)B * G, hipMemcpyDeviceToDevice, c.stream));
+    if (S > 0) QA_HIP(hipMemcpyAsync(sids, b.ids_s, sizeof(long long) * (size_t)B * S, hipMemcpyDeviceToDevice, c.stream));
     return QA_OK;
 }
 
 int ensure_ws(qa_lm* lm, size_t bytes) {
     if (bytes <= lm->ws_cap) return QA_OK;
+    QA_HIP(hipDeviceSynchronize());  // earlier calls may still be running out of the old workspace
+    for (StepGraph& g : lm->graphs) g.reset();  // captured steps point into the old workspace
     if (lm->ws) QA_HIP(hipFree(lm->ws));
     lm->ws = nullptr;
     lm->ws_cap = 0;
@@ -324,14 +519,16 @@ void qa_lm_destroy(qa_lm* lm) {
     if (!lm) return;
     (void)hipSetDevice(lm->device);
     (void)hipDeviceSynchronize();
+    for (StepGraph& g : lm->graphs) g.reset();
+    if (lm->cap_stream) (void)hipStreamDestroy(lm->cap_stream);
     lm->store.release();
     if (lm->ws) (void)hipFree(lm->ws);
     delete lm;
 }
 
-int qa_lm_generate(qa_lm* lm, int32_t task, const float* enroll_feats, int64_t n_enroll, const float* mix_feats,
-                   int64_t n_mix, int64_t B, int32_t global_length, int32_t semantic_length, float temperature,
-                   int32_t top_k, float top_p, int64_t* global_ids, int64_t* semantic_ids, void* stream) {
+static int lm_generate_impl(qa_lm* lm, int32_t task, const float* enroll_feats, int64_t n_enroll, const float* mix_feats,
+                            int64_t n_mix, int64_t B, int32_t global_length, int32_t semantic_length, const SampleCfg& sc,
+                            int64_t* global_ids, int64_t* semantic_ids, void* stream) {
     if (!lm || !mix_feats || !global_ids || !semantic_ids) {
         set_error("qa_lm_generate: null argument");
         return QA_ERR_INVALID;
@@ -339,20 +536,61 @@ int qa_lm_generate(qa_lm* lm, int32_t task, const float* enroll_feats, int64_t n
     QA_REQUIRE(task >= 0 && task < lm->spec.num_tasks, "qa_lm_generate: task %d out of range (KeyError in the reference)", task);
     QA_REQUIRE(B > 0 && n_mix > 0 && global_length >= 0 && semantic_length >= 0, "qa_lm_generate: bad shape");
     QA_REQUIRE(!enroll_feats || n_enroll > 0, "qa_lm_generate: enrollment given with no frames");
-    QA_REQUIRE(temperature > 0.f && temperature <= 1.0f, "qa_lm_generate: temperature must be in (0, 1] (llm.py:278)");
-    QA_REQUIRE(top_k >= 0 && top_p > 0.f, "qa_lm_generate: bad top_k / top_p");
+    QA_REQUIRE(sc.temperature > 0.f && sc.temperature <= 1.0f, "qa_lm_generate: temperature must be in (0, 1] (llm.py:278)");
+    QA_REQUIRE(sc.top_k >= 0 && sc.top_p > 0.f, "qa_lm_generate: bad top_k / top_p");
     QA_HIP(hipSetDevice(lm->device));
     Ctx& c = lm->ctx;
     c.stream = static_cast<hipStream_t>(stream);
     c.dry = true;
     c.arena.begin(nullptr, 0);
     QA_TRY(generate_graph(lm, c, task, enroll_feats, (int)n_enroll, mix_feats, (int)n_mix, (int)B, global_length, semantic_length,
-                          (long long*)global_ids, (long long*)semantic_ids));
+                          (long long*)global_ids, (long long*)semantic_ids, sc));
     QA_TRY(ensure_ws(lm, c.arena.peak()));
     c.dry = false;
     c.arena.begin(lm->ws, lm->ws_cap);
     return generate_graph(lm, c, task, enroll_feats, (int)n_enroll, mix_feats, (int)n_mix, (int)B, global_length, semantic_length,
-                          (long long*)global_ids, (long long*)semantic_ids);
+                          (long long*)global_ids, (long long*)semantic_ids, sc);
+}
+
+int qa_lm_generate(qa_lm* lm, int32_t task, const float* enroll_feats, int64_t n_enroll, const float* mix_feats,
+                   int64_t n_mix, int64_t B, int32_t global_length, int32_t semantic_length, float temperature,
+                   int32_t top_k, float top_p, int64_t* global_ids, int64_t* semantic_ids, void* stream) {
+    const SampleCfg sc{0, top_k, top_p, temperature, 0ull};
+    return lm_generate_impl(lm, task, enroll_feats, n_enroll, mix_feats, n_mix, B, global_length, semantic_length, sc, global_ids,
+                            semantic_ids, stream);
+}
+
+int qa_lm_generate_sampled(qa_lm* lm, int32_t task, const float* enroll_feats, int64_t n_enroll, const float* mix_feats,
+                           int64_t n_mix, int64_t B, int32_t global_length, int32_t semantic_length, float temperature,
+                           int32_t top_k, float top_p, uint64_t seed, int64_t* global_ids, int64_t* semantic_ids, void* stream) {
+    const SampleCfg sc{1, top_k, top_p, temperature, (unsigned long long)seed};
+    return lm_generate_impl(lm, task, enroll_feats, n_enroll, mix_feats, n_mix, B, global_length, semantic_length, sc, global_ids,
+                            semantic_ids, stream);
+}
+
+int qa_sample_logits(const float* logits, int64_t B, int64_t width, int64_t ld, int32_t top_k, float top_p, float temperature,
+                     int32_t do_sample, uint64_t seed, int64_t* out_index, void* stream) {
+    if (!logits || !out_index) {
+        set_error("qa_sample_logits: null argument");
+        return QA_ERR_INVALID;
+    }
+    QA_REQUIRE(B > 0 && width > 0 && ld >= width, "qa_sample_logits: bad shape");
+    QA_REQUIRE(temperature > 0.f && temperature <= 1.0f, "qa_sample_logits: temperature must be in (0, 1] (llm.py:278)");
+    QA_REQUIRE(top_k >= 0 && top_p > 0.f, "qa_sample_logits: bad top_k / top_p");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* scratch = nullptr;
+    QA_HIP(hipMalloc(reinterpret_cast<void**>(&scratch), 256 + sizeof(long long) * (size_t)B));
+    int* state = reinterpret_cast<int*>(scratch);
+    long long* tok = reinterpret_cast<long long*>(scratch + 256);
+    int st = launch_lm_phase_init(tok, 0, (int)B, state, 0, 1, (unsigned long long)seed, s);
+    if (st == QA_OK)
+        st = launch_lm_sample(logits, ld, (int)width, (int)B, 0, top_k, top_p, temperature, do_sample, tok, (long long*)out_index, 1, 1,
+                              state, s);
+    const hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(scratch);
+    if (st != QA_OK) return st;
+    QA_HIP(e);
+    return QA_OK;
 }
 
 }  // extern "C"

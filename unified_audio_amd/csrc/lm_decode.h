@@ -1,0 +1,59 @@
+// lm_decode.h - host-side interface of the fused UniSE decode step kernels (lm_decode.hip), used by lm.cpp and api.cpp.
+#pragma once
+#include "common.h"
+
+namespace qa {
+
+enum { GM_QKV = 0, GM_GATEUP = 1, GM_RESID = 2, GM_HEAD = 3 };
+// device-side loop state (int words): position of the token being processed (= keys already cached), ids column, RNG step, seed
+enum { ST_POS = 0, ST_COL = 1, ST_STEP = 2, ST_SEED_LO = 4, ST_SEED_HI = 5, ST_WORDS = 8 };
+
+struct GemvArgs {
+    // A operand: rows of x (or, with tok != nullptr, rows table[tok[m]] - the codec_embedding gather of the step's token)
+    const float* x;
+    long long ldx;
+    const long long* tok;
+    const float* table;
+    // ... or the merge of the attention partials (GM_RESID with att_part != nullptr)
+    const float* att_part;
+    int S, H, hd;
+    // B operand: [n_tiles * NT][K] rows in decode layout (tile-major; paired modes: NT/2 "first" rows then NT/2 "second" rows)
+    const float* w;
+    int M, N, K;
+    float rms_eps;
+    const int* state;
+    // GM_QKV
+    const float* rope;  // [pos][hd/2][2] cos, sin
+    float* q;           // [M, d]
+    float* kc;
+    float* vc;  // caches [M][cap][d]
+    long long kv_bstride;
+    int d;
+    // GM_RESID / GM_GATEUP output, GM_RESID residual (rows of `res`, or table[res_tok[m]])
+    const float* res;
+    long long ldr;
+    const long long* res_tok;
+    const float* res_table;
+    float* y;
+    long long ldy;
+    // GM_HEAD
+    float* pmax;
+    int* pidx;
+    float* logits;  // nullable: [M, N] full slice logits for the sampling path
+    long long ldl;
+};
+
+int lm_pick_nt(int N);
+bool lm_gemv_supported(int hidden, int intermediate);  // kernel instances exist for these K
+int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s);
+int launch_lm_attn(const float* q, long long ldq, const float* kc, const float* vc, long long kv_bstride, long long ldkv,
+                   float* part, int B, int H, int hd, int S, const int* state, float scale, hipStream_t s);
+int launch_lm_pick(const float* pmax, const int* pidx, int n_tiles, int B, int lo, long long* tok, long long* ids, long long ids_ld,
+                   int keep, int* state, hipStream_t s);
+int launch_lm_phase_init(long long* tok, long long first_id, int B, int* state, int pos, int reset_step, unsigned long long seed,
+                         hipStream_t s);
+int launch_lm_advance(int* state, hipStream_t s);
+int launch_lm_sample(const float* logits, long long ldl, int width, int B, int lo, int top_k, float top_p, float temperature,
+                     int do_sample, long long* tok, long long* ids, long long ids_ld, int keep, const int* state, hipStream_t s);
+
+}  // namespace qa

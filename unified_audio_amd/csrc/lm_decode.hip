@@ -1,0 +1,777 @@
+// lm_decode.hip - the UniSE AR-LM decode step as FIVE fat launches per layer plus two for the head
+// (QuarkAudio-UniSE/model/llm/llm.py:150-227 body, llm_sft.py:137-193 loop, llm.py:253-288 sampling):
+//
+//   per layer  1. qkv     RMSNorm (folded) + QKV GEMV + rotate-half RoPE + K/V append to the cache at `pos`
+//              2. attn    single-query attention over the cache, keys split over S workgroups -> (m, l, o) partials
+//              3. oproj   combine of the partials (inside the A-operand loader) + o_proj GEMV + residual
+//              4. gateup  RMSNorm (folded) + gate/up GEMV + SiLU(gate) * up
+//              5. down    down_proj GEMV + residual
+//   per step   6. head    final RMSNorm (folded) + output_head restricted to the active vocabulary slice + per-tile arg-max
+//              7. pick    arg-max over the tiles (or top-k / top-p / temperature / multinomial) -> next token, ids, pos++
+//
+// Why this cut (MI355X_MICROARCH.md, price list): every seam above is an all-to-all dependency (each output needs the whole
+// previous vector); a dependent kernel boundary costs ~1.2 us, any in-launch exchange across 256 CUs 3-5 us, so the step is
+// cut exactly at the all-to-all seams and everything else (norms, RoPE, cache append, SwiGLU, residuals, embedding gather,
+// softmax merge, arg-max) is fused into the GEMV that produces or consumes it.  Every GEMV streams its weights once from
+// HBM (non-temporal), spread over >= 128 workgroups by narrowing the column tile (NT = 16 / 8 / 4 real columns per MFMA tile)
+// instead of splitting K across workgroups (which would need another all-to-all combine).
+// All loop-carried scalars (position, ids column, RNG step) live in a small device-side state block that kernel 7 advances,
+// so one captured hipGraph of a step can be replayed for every step of a phase (lm.cpp).
+#include <cstdlib>
+
+#include "kernels.h"
+#include "lm_decode.h"
+
+namespace qa {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// streamed-once data (weights, KV rows): non-temporal 16-byte load
+__device__ __forceinline__ float4 ldg_nt(const float* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// merged attention output for 4 * NF consecutive channels k.. of row `row` (all inside one head since 8 | hd):
+// o = sum_s f_s o_s / sum_s f_s l_s with f_s = exp(m_s - max_s m_s); partial record = [o (hd) | m | l | pad2]
+template <int NF>
+__device__ __forceinline__ void att_merge(const GemvArgs& a, int row, int k, float4* out) {
+    const int h = k / a.hd, i = k - h * a.hd, rec = a.hd + 4;
+    const float* base = a.att_part + ((long long)(row * a.H + h) * a.S) * rec;
+    float m = -INFINITY;
+    for (int s = 0; s < a.S; ++s) m = fmaxf(m, base[s * rec + a.hd]);
+    float L = 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) out[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < a.S; ++s) {
+        const float ms = base[s * rec + a.hd];
+        const float w = (ms == -INFINITY) ? 0.f : expf(ms - m);
+        L = fmaf(base[s * rec + a.hd + 1], w, L);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const float4 o = *reinterpret_cast<const float4*>(base + s * rec + i + 4 * f);
+            out[f].x = fmaf(w, o.x, out[f].x);
+            out[f].y = fmaf(w, o.y, out[f].y);
+            out[f].z = fmaf(w, o.z, out[f].z);
+            out[f].w = fmaf(w, o.w, out[f].w);
+        }
+    }
+    const float inv = 1.0f / L;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        out[f].x *= inv; out[f].y *= inv; out[f].z *= inv; out[f].w *= inv;
+    }
+}
+
+// RMSNorm statistics of the MT * 16 input rows (LlamaRMSNorm: mean of squares over K in fp32); the norm's weight is folded into W
+template <int MT>
+__device__ __forceinline__ void gemv_rstd(const GemvArgs& a, float* s_rstd, int wave, int lane) {
+    for (int r = wave; r < MT * 16; r += 8) {
+        const int row = min(r, a.M - 1);
+        const float* xr = a.tok ? a.table + a.tok[row] * a.ldx : a.x + (long long)row * a.ldx;
+        float sq = 0.f;
+        for (int c = lane * 4; c < a.K; c += 256) {
+            const float4 t = *reinterpret_cast<const float4*>(xr + c);
+            sq += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+        }
+        sq = wave_sum(sq);
+        if (lane == 0) s_rstd[r] = rsqrtf(sq / a.K + a.rms_eps);
+    }
+}
+
+// Fused epilogues over the K-split partial tiles part[wave][m][row][col] (summed in a fixed order: deterministic, no atomics).
+template <int MT, int NT, int MODE>
+__device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const float (*part)[MT][16][17], const float* s_rstd, int tile,
+                                              int tid) {
+    const int M = a.M;
+    auto total = [&](int row, int col) {
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) v += part[wv][row >> 4][row & 15][col];
+        return v;
+    };
+    if (MODE == GM_QKV || MODE == GM_GATEUP) {
+        constexpr int HP = NT / 2;  // pairs per tile: columns (j, j + HP)
+        for (int i = tid; i < MT * 16 * HP; i += 512) {
+            const int row = i / HP, j = i - row * HP;
+            if (row >= M) continue;
+            const float v1 = total(row, j) * s_rstd[row], v2 = total(row, j + HP) * s_rstd[row];
+            if (MODE == GM_GATEUP) {
+                a.y[(long long)row * a.ldy + tile * HP + j] = silu_f(v1) * v2;  // LlamaMLP: down(silu(gate) * up)
+            } else {
+                const int d = a.d, hd = a.hd, half = hd >> 1, tps = d / NT;
+                const int sec = tile / tps, c0 = (tile - sec * tps) * NT;
+                const int h = c0 / hd, ri = ((c0 - h * hd) / NT) * HP + j;  // rotary index in [0, hd/2)
+                const int pos = a.state[ST_POS];
+                if (sec == 2) {  // V: no rotation
+                    float* dst = a.vc + (long long)row * a.kv_bstride + (long long)pos * d + h * hd;
+                    dst[ri] = v1;
+                    dst[ri + half] = v2;
+                } else {  // rotate-half RoPE (LlamaRotaryEmbedding / apply_rotary_pos_emb)
+                    const float c = a.rope[((long long)pos * half + ri) * 2], sn = a.rope[((long long)pos * half + ri) * 2 + 1];
+                    float* dst = sec == 0 ? a.q + (long long)row * d + h * hd
+                                          : a.kc + (long long)row * a.kv_bstride + (long long)pos * d + h * hd;
+                    dst[ri] = v1 * c - v2 * sn;
+                    dst[ri + half] = v2 * c + v1 * sn;
+                }
+            }
+        }
+    } else if (MODE == GM_RESID) {
+        for (int i = tid; i < MT * 16 * NT; i += 512) {
+            const int row = i / NT, j = i - row * NT;
+            if (row >= M) continue;
+            const int n = tile * NT + j;
+            const float r = a.res_tok ? a.res_table[a.res_tok[row] * a.ldr + n] : a.res[(long long)row * a.ldr + n];
+            a.y[(long long)row * a.ldy + n] = total(row, j) + r;
+        }
+    } else {  // GM_HEAD: logits of this tile's NT vocabulary entries and their per-row maximum (first maximum wins)
+        for (int i = tid; i < MT * 16 * NT; i += 512) {  // MT * 16 * NT <= 512: one pass, whole NT-lane groups stay converged
+            const int row = i / NT, j = i - row * NT;
+            const int n = tile * NT + j;
+            float v = -INFINITY;
+            if (row < M) {
+                v = total(row, j) * s_rstd[row];
+                if (a.logits) a.logits[(long long)row * a.ldl + n] = v;
+            }
+            int bi = n;
+#pragma unroll
+            for (int o = NT >> 1; o > 0; o >>= 1) {
+                const float v2 = __shfl_xor(v, o, 64);
+                const int i2 = __shfl_xor(bi, o, 64);
+                if (v2 > v || (v2 == v && i2 < bi)) {
+                    v = v2;
+                    bi = i2;
+                }
+            }
+            if (j == 0 && row < M) {
+                a.pmax[(long long)row * gridDim.x + tile] = v;
+                a.pidx[(long long)row * gridDim.x + tile] = bi;
+            }
+        }
+    }
+}
+
+// y[M <= 16*MT, tile of NT columns] = epi(A[M, K] W_tile[NT, K]^T): one workgroup per column tile, its 8 waves split K, every
+// lane streams 32-byte pieces of its weight row straight from HBM into v_mfma_f32_16x16x4_f32 (batch rows = M side; with
+// NT < 16 the surplus MFMA columns duplicate real ones and are ignored - the 4x4x1 kernel below is the one used for narrow
+// tiles), partial tiles are summed through LDS, then the mode's fused epilogue runs.
+// NB = 32-wide K chunks per wave that are loaded as one batch (all of a wave's K share when K / 256 <= 8): every weight and
+// activation load of the batch is issued before the first MFMA, so a wave pays one memory round trip per batch instead of one per
+// chunk (hipcc does not software-pipeline the chunk loop by itself).
+template <int MT, int NT, int MODE, bool ATT, int NB>
+__global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a) {
+    __shared__ float part[8][MT][16][17];
+    __shared__ float s_rstd[MT * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int tile = blockIdx.x;
+    const int K = a.K, M = a.M;
+    const int kw = K >> 3, k0 = wave * kw, nchunk = kw >> 5;
+    const float* wp = a.w + ((long long)tile * NT + (li & (NT - 1))) * K + k0 + 8 * kq;
+    // weights do not depend on anything computed here: get the first batch in flight before touching the activations
+    float4 wr[NB][2];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        wr[c][0] = ldg_nt(wp + c * 32);
+        wr[c][1] = ldg_nt(wp + c * 32 + 4);
+    }
+    const float* xrow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int row = min(m * 16 + li, M - 1);
+        xrow[m] = a.tok ? a.table + a.tok[row] * a.ldx : a.x + (long long)row * a.ldx;
+    }
+    if (MODE != GM_RESID) gemv_rstd<MT>(a, s_rstd, wave, lane);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int kbase = k0 + 8 * kq;
+    for (int c0 = 0; c0 < nchunk; c0 += NB) {
+        if (c0 > 0) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                wr[c][0] = ldg_nt(wp + (c0 + c) * 32);
+                wr[c][1] = ldg_nt(wp + (c0 + c) * 32 + 4);
+            }
+        }
+        float4 xa[MT][NB][2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                if (ATT) {
+                    att_merge<2>(a, min(m * 16 + li, M - 1), kbase + (c0 + c) * 32, xa[m][c]);
+                } else {
+                    xa[m][c][0] = *reinterpret_cast<const float4*>(xrow[m] + kbase + (c0 + c) * 32);
+                    xa[m][c][1] = *reinterpret_cast<const float4*>(xrow[m] + kbase + (c0 + c) * 32 + 4);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);  // keep every load of the batch ahead of the first MFMA (hipcc sinks them one by one)
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float4 a0 = xa[m][c][0], a1 = xa[m][c][1], w0 = wr[c][0], w1 = wr[c][1];
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w0.x, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w0.y, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w0.z, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w0.w, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, w1.x, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, w1.y, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, w1.z, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, w1.w, acc[m], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][m][4 * kq + r][li] = acc[m][r];
+    __syncthreads();
+    gemv_epilogue<MT, NT, MODE>(a, part, s_rstd, tile, tid);
+}
+
+// The same GEMV for NARROW column tiles (NT = 4 * C columns, C = 1 or 2) on v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4x1
+// blocks per instruction.  Block (g, p) = lane >> 2 multiplies batch rows 4g..4g+3 (A: lane & 3 selects the row) with the tile's
+// columns (B: lane & 3 selects the column) at K phase p: a lane's float4 holds k = 16 * step + 4p .. + 3, one component per MFMA.
+// Every FMA is useful (the 16x16x4 form wastes 16 / NT of the matrix pipe on duplicated columns: 1.3 us per down_proj
+// workgroup); the four K phases are summed with two shuffles at the end.  NS = 16-wide K steps per wave loaded as one batch.
+template <int MT, int C, int MODE, bool ATT, int NS>
+__global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a) {
+    constexpr int NT = 4 * C;
+    __shared__ float part[8][MT][16][17];
+    __shared__ float s_rstd[MT * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, p = (lane >> 2) & 3, i4 = lane & 3;
+    const int tile = blockIdx.x;
+    const int K = a.K, M = a.M;
+    const int kw = K >> 3, k0 = wave * kw, nstep = kw >> 4;
+    const int kbase = k0 + 4 * p;
+    const float* wp[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) wp[c] = a.w + ((long long)tile * NT + c * 4 + i4) * K + kbase;
+    float4 wr[NS][C];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int c = 0; c < C; ++c) wr[s][c] = ldg_nt(wp[c] + s * 16);
+    const float* xrow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int row = min(m * 16 + 4 * g + i4, M - 1);
+        xrow[m] = a.tok ? a.table + a.tok[row] * a.ldx : a.x + (long long)row * a.ldx;
+    }
+    if (MODE != GM_RESID) gemv_rstd<MT>(a, s_rstd, wave, lane);
+    f32x4 acc[MT][C];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[m][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < nstep; s0 += NS) {
+        if (s0 > 0) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int c = 0; c < C; ++c) wr[s][c] = ldg_nt(wp[c] + (s0 + s) * 16);
+        }
+        float4 xa[MT][NS];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (ATT) att_merge<1>(a, min(m * 16 + 4 * g + i4, M - 1), kbase + (s0 + s) * 16, &xa[m][s]);
+                else xa[m][s] = *reinterpret_cast<const float4*>(xrow[m] + kbase + (s0 + s) * 16);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float4 x4 = xa[m][s], w4 = wr[s][c];
+                    acc[m][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(x4.x, w4.x, acc[m][c], 0, 0, 0);
+                    acc[m][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(x4.y, w4.y, acc[m][c], 0, 0, 0);
+                    acc[m][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(x4.z, w4.z, acc[m][c], 0, 0, 0);
+                    acc[m][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(x4.w, w4.w, acc[m][c], 0, 0, 0);
+                }
+    }
+    // D of block (g, p): VGPR r = batch row 4g + r, lane & 3 = column; sum the 4 K phases (lane bits 2, 3)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[m][c][r];
+                v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 8, 64);
+                if (p == 0) part[wave][m][4 * g + r][c * 4 + i4] = v;
+            }
+    __syncthreads();
+    gemv_epilogue<MT, NT, MODE>(a, part, s_rstd, tile, tid);
+}
+
+// column-tile width: as wide as possible (MFMA efficiency is irrelevant here) while the launch still spreads over >= 160 workgroups
+int lm_pick_nt(int N) {
+    int nt = 16;
+    while (nt > 4 && N / nt < 160) nt >>= 1;
+    return nt;
+}
+
+// QA_LM_MFMA16=1: narrow tiles on the 16x16x4 kernel too (A/B switch for tests and measurements)
+static bool narrow_on_4x4() {
+    static const bool v = std::getenv("QA_LM_MFMA16") == nullptr;
+    return v;
+}
+
+// 32-wide chunks per batch of the 16x16x4 kernel for a given K: the whole per-wave share when it is at most 8 chunks (K <= 2048)
+static int gemv_nb(int K) {
+    const int nchunk = K / 256;
+    if (nchunk == 1 || nchunk == 2 || nchunk == 4 || nchunk == 8) return nchunk;
+    return nchunk % 8 == 0 ? 8 : 0;
+}
+
+template <int MODE, bool ATT, int NB>
+static int launch_gemv_nb(const GemvArgs& a, int nt, hipStream_t s) {
+    const dim3 grid((unsigned)(a.N / nt));
+    const bool m4 = narrow_on_4x4() && nt < 16;
+#define QA_GV(MT, NT) hipLaunchKernelGGL((lm_gemv_kernel<MT, NT, MODE, ATT, NB>), grid, dim3(512), 0, s, a)
+#define QA_G4(MT, C) hipLaunchKernelGGL((lm_gemv4_kernel<MT, C, MODE, ATT, 2 * NB>), grid, dim3(512), 0, s, a)
+    if (a.M <= 16) {
+        if (nt == 16) QA_GV(1, 16);
+        else if (nt == 8) { if (m4) QA_G4(1, 2); else QA_GV(1, 8); }
+        else { if (m4) QA_G4(1, 1); else QA_GV(1, 4); }
+    } else {
+        if (nt == 16) QA_GV(2, 16);
+        else if (nt == 8) { if (m4) QA_G4(2, 2); else QA_GV(2, 8); }
+        else { if (m4) QA_G4(2, 1); else QA_GV(2, 4); }
+    }
+#undef QA_GV
+#undef QA_G4
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+// K = hidden for every mode but the down projection (K = intermediate = 4 * hidden): only the batch sizes those shapes need exist
+template <int MODE, bool ATT>
+static int launch_gemv_mode(const GemvArgs& a, int nt, hipStream_t s) {
+    const int nb = gemv_nb(a.K);
+    constexpr bool wide = MODE == GM_RESID && !ATT;  // down_proj
+    if constexpr (!wide) {
+        if (nb == 1) return launch_gemv_nb<MODE, ATT, 1>(a, nt, s);
+        if (nb == 2) return launch_gemv_nb<MODE, ATT, 2>(a, nt, s);
+        if (nb == 4) return launch_gemv_nb<MODE, ATT, 4>(a, nt, s);
+    } else {
+        if (nb == 4) return launch_gemv_nb<MODE, ATT, 4>(a, nt, s);
+        if (nb == 8) return launch_gemv_nb<MODE, ATT, 8>(a, nt, s);
+    }
+    set_error("lm_gemv: K=%d has no kernel instance (mode %d)", a.K, MODE);
+    return QA_ERR_UNSUPPORTED;
+}
+
+bool lm_gemv_supported(int hidden, int intermediate) {
+    const int nb_d = gemv_nb(hidden), nb_i = gemv_nb(intermediate);
+    return hidden % 256 == 0 && intermediate % 256 == 0 && (nb_d == 1 || nb_d == 2 || nb_d == 4) && (nb_i == 4 || nb_i == 8);
+}
+
+int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s) {
+    QA_REQUIRE(a.M >= 1 && a.M <= 32, "lm_gemv: M=%d must be in [1, 32]", a.M);
+    QA_REQUIRE(a.K % 256 == 0 && (a.ldx % 4) == 0, "lm_gemv: K=%d must be a multiple of 256", a.K);
+    QA_REQUIRE((nt == 16 || nt == 8 || nt == 4) && a.N % nt == 0, "lm_gemv: N=%d not a multiple of the tile width %d", a.N, nt);
+    switch (mode) {
+        case GM_QKV: return launch_gemv_mode<GM_QKV, false>(a, nt, s);
+        case GM_GATEUP: return launch_gemv_mode<GM_GATEUP, false>(a, nt, s);
+        case GM_RESID: return a.att_part ? launch_gemv_mode<GM_RESID, true>(a, nt, s) : launch_gemv_mode<GM_RESID, false>(a, nt, s);
+        case GM_HEAD: return launch_gemv_mode<GM_HEAD, false>(a, nt, s);
+        default: set_error("lm_gemv: bad mode %d", mode); return QA_ERR_INVALID;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Single-query attention over the KV cache, keys split over S workgroups per (batch, head).  A wave covers 16 keys per
+// iteration: lane = (key = lane >> 2, 16-float slice = lane & 3), 64 contiguous bytes per lane and 256 per key; scores are
+// finished with two shuffles, softmax is online per wave, the NW wave states are merged through LDS into one partial record
+// [o (HD, un-normalised, relative to m) | m | l | pad2] that the o_proj GEMV merges across the S splits (att_merge8).
+// The number of keys (pos + 1, the new key included) is read from the device-side loop state.
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void lm_attn_kernel(const float* __restrict__ q, long long ldq,
+                                                          const float* __restrict__ kc, const float* __restrict__ vc,
+                                                          long long kv_bstride, long long ldkv, float* __restrict__ part,
+                                                          const int* __restrict__ state, float scale) {
+    constexpr int SL = HD / 4;  // floats per lane slice
+    __shared__ float s_m[NW], s_l[NW];
+    __shared__ float s_o[NW][HD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, h = blockIdx.x, sp = blockIdx.z, S = gridDim.z, H = gridDim.x;
+    const int n_keys = state[ST_POS] + 1;
+    const int per = (((n_keys + S - 1) / S) + 15) & ~15;
+    const int k_begin = sp * per, k_end = min(n_keys, k_begin + per);
+    const int kl = lane >> 2, sl = lane & 3;
+    const float* qp = q + (long long)b * ldq + h * HD + sl * SL;
+    float qv[SL];
+#pragma unroll
+    for (int i = 0; i < SL; i += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(qp + i);
+        qv[i] = t.x * scale; qv[i + 1] = t.y * scale; qv[i + 2] = t.z * scale; qv[i + 3] = t.w * scale;
+    }
+    const float* kb = kc + (long long)b * kv_bstride + h * HD + sl * SL;
+    const float* vb = vc + (long long)b * kv_bstride + h * HD + sl * SL;
+    float m_run = -INFINITY, l_run = 0.f;
+    float o[SL];
+#pragma unroll
+    for (int i = 0; i < SL; ++i) o[i] = 0.f;
+    for (int k0 = k_begin + wave * 16; k0 < k_end; k0 += NW * 16) {
+        const int key = k0 + kl;
+        const bool ok = key < k_end;
+        const int kk = ok ? key : k_end - 1;
+        float sdot = 0.f;
+        const float* kp = kb + (long long)kk * ldkv;
+        const float* vp = vb + (long long)kk * ldkv;
+        float4 kt[SL / 4], vt[SL / 4];
+#pragma unroll
+        for (int i = 0; i < SL / 4; ++i) kt[i] = ldg_nt(kp + 4 * i);
+#pragma unroll
+        for (int i = 0; i < SL / 4; ++i) vt[i] = ldg_nt(vp + 4 * i);
+#pragma unroll
+        for (int i = 0; i < SL / 4; ++i) {
+            sdot = fmaf(qv[4 * i], kt[i].x, sdot);
+            sdot = fmaf(qv[4 * i + 1], kt[i].y, sdot);
+            sdot = fmaf(qv[4 * i + 2], kt[i].z, sdot);
+            sdot = fmaf(qv[4 * i + 3], kt[i].w, sdot);
+        }
+        sdot += __shfl_xor(sdot, 1, 64);
+        sdot += __shfl_xor(sdot, 2, 64);
+        const float sc = ok ? sdot : -INFINITY;
+        float tmax = sc;
+#pragma unroll
+        for (int of = 4; of < 64; of <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, of, 64));
+        const float m_new = fmaxf(m_run, tmax);  // every executed tile has at least one valid key
+        const float alpha = expf(m_run - m_new);
+        const float p = ok ? expf(sc - m_new) : 0.f;
+        float psum = p;
+#pragma unroll
+        for (int of = 4; of < 64; of <<= 1) psum += __shfl_xor(psum, of, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < SL / 4; ++i) {
+            o[4 * i] = fmaf(p, vt[i].x, o[4 * i] * alpha);
+            o[4 * i + 1] = fmaf(p, vt[i].y, o[4 * i + 1] * alpha);
+            o[4 * i + 2] = fmaf(p, vt[i].z, o[4 * i + 2] * alpha);
+            o[4 * i + 3] = fmaf(p, vt[i].w, o[4 * i + 3] * alpha);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {  // sum the 16 key-lanes that share a slice
+#pragma unroll
+        for (int of = 4; of < 64; of <<= 1) o[i] += __shfl_xor(o[i], of, 64);
+    }
+    if (lane < 4) {
+#pragma unroll
+        for (int i = 0; i < SL; ++i) s_o[wave][lane * SL + i] = o[i];
+        if (lane == 0) {
+            s_m[wave] = m_run;
+            s_l[wave] = l_run;
+        }
+    }
+    __syncthreads();
+    if (tid < HD + 2) {
+        float m = s_m[0];
+        for (int w = 1; w < NW; ++w) m = fmaxf(m, s_m[w]);
+        float l = 0.f, accv = 0.f;
+        for (int w = 0; w < NW; ++w) {
+            const float f = (s_m[w] == -INFINITY) ? 0.f : expf(s_m[w] - m);
+            l += s_l[w] * f;
+            if (tid < HD) accv += s_o[w][tid] * f;
+        }
+        float* rec = part + ((long long)(b * H + h) * S + sp) * (HD + 4);
+        if (tid < HD) rec[tid] = accv;
+        else if (tid == HD) rec[HD] = m;
+        else rec[HD + 1] = l;
+    }
+}
+
+int launch_lm_attn(const float* q, long long ldq, const float* kc, const float* vc, long long kv_bstride, long long ldkv,
+                   float* part, int B, int H, int hd, int S, const int* state, float scale, hipStream_t s) {
+    QA_REQUIRE(S >= 1 && S <= 8, "lm_attn: bad split count %d", S);
+    const dim3 grid(H, B, S);
+    switch (hd) {
+        case 64:
+            hipLaunchKernelGGL((lm_attn_kernel<64, 16>), grid, dim3(1024), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale);
+            break;
+        case 128:
+            hipLaunchKernelGGL((lm_attn_kernel<128, 16>), grid, dim3(1024), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale);
+            break;
+        case 32:
+            hipLaunchKernelGGL((lm_attn_kernel<32, 16>), grid, dim3(1024), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale);
+            break;
+        default: set_error("lm_attn: head_dim=%d unsupported", hd); return QA_ERR_UNSUPPORTED;
+    }
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Greedy pick (llm.py:286 with the range mask of llm_sft.py:150-153 / :180-182 already applied by restricting output_head to the
+// slice): arg-max over the head kernel's per-tile maxima, first maximum wins.  One workgroup (so it can advance the loop state
+// without a race): tok[b] = lo + argmax; ids[b, col] = argmax for col < keep; pos++, col++, step++.
+__global__ __launch_bounds__(1024) void lm_pick_kernel(const float* __restrict__ pmax, const int* __restrict__ pidx, int n_tiles,
+                                                       int B, int lo, long long* __restrict__ tok, long long* __restrict__ ids,
+                                                       long long ids_ld, int keep, int* __restrict__ state) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = state[ST_COL];
+    for (int b = wave; b < B; b += 16) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int t = lane; t < n_tiles; t += 64) {
+            const float v = pmax[(long long)b * n_tiles + t];
+            const int i = pidx[(long long)b * n_tiles + t];
+            if (v > best || (v == best && i < bi)) {
+                best = v;
+                bi = i;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(best, o, 64);
+            const int i2 = __shfl_xor(bi, o, 64);
+            if (v2 > best || (v2 == best && i2 < bi)) {
+                best = v2;
+                bi = i2;
+            }
+        }
+        if (lane == 0) {
+            if (bi == 0x7fffffff) bi = 0;  // all-NaN row: stay inside the table
+            tok[b] = lo + bi;
+            if (col < keep) ids[(long long)b * ids_ld + col] = bi;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        state[ST_POS] += 1;
+        state[ST_COL] = col + 1;
+        state[ST_STEP] += 1;
+    }
+}
+
+int launch_lm_pick(const float* pmax, const int* pidx, int n_tiles, int B, int lo, long long* tok, long long* ids, long long ids_ld,
+                   int keep, int* state, hipStream_t s) {
+    hipLaunchKernelGGL(lm_pick_kernel, dim3(1), dim3(1024), 0, s, pmax, pidx, n_tiles, B, lo, tok, ids, ids_ld, keep, state);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+// phase start: tok[:] = first_id, pos, col = 0 (the RNG step counter keeps running across the two phases of a call)
+__global__ void lm_phase_init_kernel(long long* tok, long long first_id, int B, int* state, int pos, int reset_step, unsigned seed_lo,
+                                     unsigned seed_hi) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) tok[i] = first_id;
+    if (i == 0) {
+        state[ST_POS] = pos;
+        state[ST_COL] = 0;
+        if (reset_step) {
+            state[ST_STEP] = 0;
+            state[ST_SEED_LO] = (int)seed_lo;
+            state[ST_SEED_HI] = (int)seed_hi;
+        }
+    }
+}
+int launch_lm_phase_init(long long* tok, long long first_id, int B, int* state, int pos, int reset_step, unsigned long long seed,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(lm_phase_init_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, s, tok, first_id, B, state, pos, reset_step,
+                       (unsigned)(seed & 0xffffffffull), (unsigned)(seed >> 32));
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+__global__ void lm_advance_kernel(int* state) {
+    if (threadIdx.x == 0) {
+        state[ST_POS] += 1;
+        state[ST_COL] += 1;
+        state[ST_STEP] += 1;
+    }
+}
+int launch_lm_advance(int* state, hipStream_t s) {
+    hipLaunchKernelGGL(lm_advance_kernel, dim3(1), dim3(64), 0, s, state);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CustomLlamaModel.sample_logits (llm.py:253-288) on the active vocabulary slice, one workgroup per sequence:
+//   1. sort the slice descending (value, then lower index first) - bitonic sort of 64-bit keys in LDS;
+//   2. top-k: keep everything >= the k-th largest value (the reference removes `logits < kth`, so ties with it survive);
+//   3. top-p on the UN-tempered logits: softmax over the survivors, inclusive cumsum, shift right by one: sorted position
+//      j >= 1 is removed iff cumsum[j-1] > top_p (the token that crosses top_p is kept);
+//   4. / temperature, softmax, one categorical draw (inverse CDF with a Philox4x32-10 uniform keyed by (seed, sequence, step));
+//      do_sample = 0 returns the first sorted element instead (arg-max; the filters cannot remove it).
+// The reference draws from torch's global RNG; the streams necessarily differ, the distribution is the same (tested).
+__device__ __forceinline__ unsigned f2ord(float v) {
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ float philox_uniform(unsigned seed_lo, unsigned seed_hi, unsigned seq, unsigned step) {
+    unsigned c[4] = {step, 0u, seq, 0u};
+    unsigned k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return (float)(c[0] >> 8) * (1.0f / 16777216.0f);  // [0, 1) with 24 random bits
+}
+
+// block-wide inclusive scan of one float per thread (1024 threads), returns this thread's inclusive prefix; *total = sum
+__device__ __forceinline__ float block_scan_1024(float v, float* s_wave, float* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    __syncthreads();  // s_wave may still be read from a previous call
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    float off = 0.f, tot = 0.f;
+    for (int w = 0; w < 16; ++w) {
+        const float t = s_wave[w];
+        if (w < wave) off += t;
+        tot += t;
+    }
+    *total = tot;
+    return x + off;
+}
+
+__global__ __launch_bounds__(1024) void lm_sample_kernel(const float* __restrict__ logits, long long ldl, int width, int n_pow2, int lo,
+                                                         int top_k, float top_p, float temperature, int do_sample,
+                                                         long long* __restrict__ tok, long long* __restrict__ ids, long long ids_ld,
+                                                         int keep, const int* __restrict__ state) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // n_pow2 entries
+    __shared__ float s_wave[16];
+    __shared__ int s_cnt, s_pick;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const float* row = logits + (long long)b * ldl;
+    for (int i = tid; i < n_pow2; i += 1024)
+        keys[i] = i < width ? (((unsigned long long)f2ord(row[i])) << 32) | (unsigned)(~(unsigned)i) : 0ull;
+    __syncthreads();
+    for (int k = 2; k <= n_pow2; k <<= 1) {  // bitonic sort, descending
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n_pow2; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long x = keys[i], y = keys[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) {
+                        keys[i] = y;
+                        keys[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const float top = ord2f((unsigned)(keys[0] >> 32));
+    // ---- top-k: survivors are a prefix [0, n1)
+    int n1 = width;
+    if (top_k > 0 && top_k < width) {
+        const unsigned kth = (unsigned)(keys[top_k - 1] >> 32);
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        int c = 0;
+        for (int i = tid; i < width; i += 1024) c += ((unsigned)(keys[i] >> 32) >= kth) ? 1 : 0;
+        atomicAdd(&s_cnt, c);
+        __syncthreads();
+        n1 = s_cnt;
+        __syncthreads();
+    }
+    // -inf entries (nothing below the range mask survives a finite maximum anyway) never carry probability
+    // ---- top-p: thread t owns the contiguous sorted positions [t*per, (t+1)*per)
+    const int per = n_pow2 / 1024 > 0 ? n_pow2 / 1024 : 1;
+    int n2 = n1;
+    if (top_p < 1.0f) {
+        float loc = 0.f;
+        for (int u = 0; u < per; ++u) {
+            const int i = tid * per + u;
+            if (i < n1) loc += expf(ord2f((unsigned)(keys[i] >> 32)) - top);
+        }
+        float Z;
+        const float incl = block_scan_1024(loc, s_wave, &Z);
+        // position j >= 1 is removed iff cumsum[j-1] / Z > top_p  <=>  kept count = 1 + #{j >= 1 : cumsum[j-1] <= top_p * Z}
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        float run = incl - loc;  // exclusive prefix at this thread's first position = cumsum[first - 1]
+        int c = 0;
+        for (int u = 0; u < per; ++u) {
+            const int i = tid * per + u;
+            if (i < n1) {
+                if (i == 0 || run / Z <= top_p) ++c;
+                run += expf(ord2f((unsigned)(keys[i] >> 32)) - top);
+            }
+        }
+        atomicAdd(&s_cnt, c);
+        __syncthreads();
+        n2 = s_cnt;  // monotone cumsum => the kept positions are exactly the prefix [0, n2)
+        __syncthreads();
+    }
+    // ---- temperature + categorical draw over [0, n2)
+    int pick = 0;
+    if (do_sample) {
+        const float invT = 1.0f / temperature;
+        float loc = 0.f;
+        for (int u = 0; u < per; ++u) {
+            const int i = tid * per + u;
+            if (i < n2) loc += expf((ord2f((unsigned)(keys[i] >> 32)) - top) * invT);
+        }
+        float Z;
+        const float incl = block_scan_1024(loc, s_wave, &Z);
+        const float uu = philox_uniform((unsigned)state[ST_SEED_LO], (unsigned)state[ST_SEED_HI], (unsigned)b, (unsigned)state[ST_STEP]) * Z;
+        if (tid == 0) s_pick = n2 - 1;  // rounding guard: u * Z may land on the total
+        __syncthreads();
+        float run = incl - loc;
+        for (int u = 0; u < per; ++u) {
+            const int i = tid * per + u;
+            if (i < n2) {
+                const float nxt = run + expf((ord2f((unsigned)(keys[i] >> 32)) - top) * invT);
+                if (uu >= run && uu < nxt) atomicMin(&s_pick, i);  // first position whose cumulative mass exceeds u
+                run = nxt;
+            }
+        }
+        __syncthreads();
+        pick = s_pick;
+    }
+    if (tid == 0) {
+        const int idx = (int)(~(unsigned)(keys[pick] & 0xffffffffull));
+        tok[b] = lo + idx;
+        const int col = state[ST_COL];
+        if (col < keep) ids[(long long)b * ids_ld + col] = idx;
+    }
+}
+
+int launch_lm_sample(const float* logits, long long ldl, int width, int B, int lo, int top_k, float top_p, float temperature,
+                     int do_sample, long long* tok, long long* ids, long long ids_ld, int keep, const int* state, hipStream_t s) {
+    int n_pow2 = 1024;
+    while (n_pow2 < width) n_pow2 <<= 1;
+    QA_REQUIRE(n_pow2 <= 16384, "lm_sample: vocabulary slice of %d entries exceeds the 16384 the sampler sorts in LDS", width);
+    const size_t lds = (size_t)n_pow2 * sizeof(unsigned long long);
+    static bool attr_set = false;
+    if (!attr_set) {
+        QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lm_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lm_sample_kernel, dim3(B), dim3(1024), lds, s, logits, ldl, width, n_pow2, lo, top_k, top_p, temperature,
+                       do_sample, tok, ids, ids_ld, keep, state);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+}  // namespace qa

@@ -65,12 +65,13 @@ class LLM_SFT:
                  global_length: int = 32, temperature: float = 0.8, top_k: int = 50, top_p: float = 0.95,
                  do_sample: bool = True):
         """Returns (global_ids [B, global_length], semantic_ids [B, mix_mel.size(1)]) int64, offsets subtracted.
-        Only `mix_mel.size(1)` is consumed from the mel inputs, exactly like the reference (llm_sft.py:108)."""
+        Only `mix_mel.size(1)` is consumed from the mel inputs, exactly like the reference (llm_sft.py:108).
+        do_sample=True (the reference's signature default, llm_sft.py:106) samples every token on the device with
+        CustomLlamaModel.sample_logits' filters (llm.py:253-288); the draws come from a Philox stream seeded from torch's
+        global generator (torch.manual_seed controls reproducibility, as in the reference), so the distribution - not
+        the individual stream - matches the reference."""
         if not self._handle.value:
             raise _lib.QuarkAudioError(-3, "LLM_SFT has no weights: call load_state_dict first")
-        if do_sample:
-            raise _lib.QuarkAudioError(-4, "do_sample=True (multinomial sampling) is not implemented; the reference's "
-                                           "inference path runs with do_sample=False (model/model.py:173)")
         task = self.task_map[task_name]  # KeyError like the reference
         mix = mix_feats.to(device=self.device, dtype=torch.float32).contiguous()
         B, n_mix, _ = mix.shape
@@ -81,7 +82,29 @@ class LLM_SFT:
         S = int(mix_mel.size(1))
         gids = torch.empty((B, global_length), dtype=torch.int64, device=self.device)
         sids = torch.empty((B, S), dtype=torch.int64, device=self.device)
-        _lib.check(self._lib.qa_lm_generate(self._handle, task, enr.data_ptr() if enr is not None else None, n_enr,
-                                            mix.data_ptr(), n_mix, B, global_length, S, temperature, top_k, top_p,
-                                            gids.data_ptr(), sids.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream))
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        enr_ptr = enr.data_ptr() if enr is not None else None
+        if do_sample:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())  # advances torch's CPU generator: new draws per call
+            _lib.check(self._lib.qa_lm_generate_sampled(self._handle, task, enr_ptr, n_enr, mix.data_ptr(), n_mix, B, global_length,
+                                                        S, temperature, top_k, top_p, seed, gids.data_ptr(), sids.data_ptr(), stream))
+        else:
+            _lib.check(self._lib.qa_lm_generate(self._handle, task, enr_ptr, n_enr, mix.data_ptr(), n_mix, B, global_length, S,
+                                                temperature, top_k, top_p, gids.data_ptr(), sids.data_ptr(), stream))
         return gids, sids
+
+
+def sample_logits(logits: torch.Tensor, temperature: float = 0.8, top_k: int = 50, top_p: float = 0.95,
+                  do_sample: bool = True, seed: Optional[int] = None) -> torch.Tensor:
+    """CustomLlamaModel.sample_logits (llm.py:253-288) on the device: logits [B, V] float32 cuda -> [B, 1] int64.
+    Unlike the reference it does not filter `logits` in place."""
+    lib = _lib.load_library()
+    x = logits.to(dtype=torch.float32).contiguous()
+    if not x.is_cuda:
+        raise _lib.QuarkAudioError(-1, "sample_logits: logits must live on the HIP device (there is no CPU path)")
+    out = torch.empty((x.shape[0],), dtype=torch.int64, device=x.device)
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    _lib.check(lib.qa_sample_logits(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), top_k, top_p, temperature,
+                                    1 if do_sample else 0, seed, out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream))
+    return out[:, None]
