@@ -121,11 +121,12 @@ int qa_rvq_search(const float* x, int64_t n_vec, const float* codebooks, int32_t
     }
     QA_REQUIRE(n_vec >= 0 && Q > 0 && K > 0 && D > 0, "qa_rvq_search: bad shape");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    float* e2 = nullptr;
-    QA_HIP(hipMallocAsync(reinterpret_cast<void**>(&e2), sizeof(float) * (size_t)Q * K, s));
+    float* e2 = nullptr;  // [Q*K] code norms followed by the search workspace
+    const size_t e2n = (size_t)round_up((int64_t)Q * K, 64);
+    QA_HIP(hipMallocAsync(reinterpret_cast<void**>(&e2), sizeof(float) * (e2n + rvq_scratch_floats(n_vec, K, D)), s));
     int st = launch_rvq_norms(codebooks, e2, Q * K, D, s);
     if (st == QA_OK)
-        st = launch_rvq_search(x, n_vec, codebooks, e2, Q, K, D, reinterpret_cast<long long*>(indices), quantized_out, D, s);
+        st = launch_rvq_search(x, n_vec, codebooks, e2, Q, K, D, reinterpret_cast<long long*>(indices), quantized_out, D, e2 + e2n, s);
     (void)hipFreeAsync(e2, s);
     return st;
 }

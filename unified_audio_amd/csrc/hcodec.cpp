@@ -606,11 +606,12 @@ int encode_graph(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const flo
     const int Q = sp.num_quantizers;
     long long* ia = c.arena.alloc<long long>((size_t)B * N25 * Q);
     long long* is = c.arena.alloc<long long>((size_t)B * N25 * Q);
+    float* rvq_ws = c.arena.alloc<float>(rvq_scratch_floats((long long)B * N25, sp.codebook_size, sp.code_dim));
     if (!c.dry) {
         QA_TRY(launch_rvq_search(emb, (long long)B * N25, h->cb_a, h->e2_a, Q, sp.codebook_size, sp.code_dim, ia, nullptr, 0,
-                                 c.stream));
+                                 rvq_ws, c.stream));
         QA_TRY(launch_rvq_search(sem, (long long)B * N25, h->cb_s, h->e2_s, Q, sp.codebook_size, sp.code_dim, is, nullptr, 0,
-                                 c.stream));
+                                 rvq_ws, c.stream));
         QA_TRY(launch_codes_to_bqn(ia, ac_out, B, N25, Q, c.stream));
         QA_TRY(launch_codes_to_bqn(is, sc_out, B, N25, Q, c.stream));
     }
@@ -740,9 +741,10 @@ int encode_adaptive_graph(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, 
     c.tap("enc.sem_agg", agg_s, (int64_t)B * G * D);
     long long* ia = c.arena.alloc<long long>((size_t)B * G * Q);
     long long* is = c.arena.alloc<long long>((size_t)B * G * Q);
+    float* rvq_ws = c.arena.alloc<float>(rvq_scratch_floats((long long)B * G, sp.codebook_size, D));
     if (!c.dry) {
-        QA_TRY(launch_rvq_search(agg_a, (long long)B * G, h->cb_a, h->e2_a, Q, sp.codebook_size, D, ia, nullptr, 0, c.stream));
-        QA_TRY(launch_rvq_search(agg_s, (long long)B * G, h->cb_s, h->e2_s, Q, sp.codebook_size, D, is, nullptr, 0, c.stream));
+        QA_TRY(launch_rvq_search(agg_a, (long long)B * G, h->cb_a, h->e2_a, Q, sp.codebook_size, D, ia, nullptr, 0, rvq_ws, c.stream));
+        QA_TRY(launch_rvq_search(agg_s, (long long)B * G, h->cb_s, h->e2_s, Q, sp.codebook_size, D, is, nullptr, 0, rvq_ws, c.stream));
         QA_TRY(launch_codes_inject(ia, len, ac_out, B, N, G, Q, sp.codebook_size, c.stream));
         QA_TRY(launch_codes_inject(is, len, sc_out, B, N, G, Q, sp.codebook_size, c.stream));
     }

@@ -54,8 +54,10 @@ int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_st
                 hipStream_t s);
 
 // rvq.hip
+// scratch: rvq_scratch_floats(n_vec, K, D) floats of device workspace (residuals, distance products, norms of one chunk)
+size_t rvq_scratch_floats(long long n_vec, int K, int D);
 int launch_rvq_search(const float* x, long long n_vec, const float* codebooks, const float* e2, int Q, int K, int D,
-                      long long* indices, float* quantized, long long ldq, hipStream_t s);
+                      long long* indices, float* quantized, long long ldq, float* scratch, hipStream_t s);
 int launch_rvq_norms(const float* codebooks, float* e2, int QK, int D, hipStream_t s);
 int launch_rvq_lookup(const long long* indices, long long n_vec, const float* codebooks, int Q, int K, int D, float* out,
                       long long ldo, hipStream_t s);

@@ -539,6 +539,7 @@ static int lm_generate_impl(qa_lm* lm, int32_t task, const float* enroll_feats, 
     QA_REQUIRE(sc.temperature > 0.f && sc.temperature <= 1.0f, "qa_lm_generate: temperature must be in (0, 1] (llm.py:278)");
     QA_REQUIRE(sc.top_k >= 0 && sc.top_p > 0.f, "qa_lm_generate: bad top_k / top_p");
     QA_HIP(hipSetDevice(lm->device));
+    if (sc.do_sample) QA_TRY(lm_sample_prepare());
     Ctx& c = lm->ctx;
     c.stream = static_cast<hipStream_t>(stream);
     c.dry = true;
@@ -578,6 +579,7 @@ int qa_sample_logits(const float* logits, int64_t B, int64_t width, int64_t ld, 
     QA_REQUIRE(temperature > 0.f && temperature <= 1.0f, "qa_sample_logits: temperature must be in (0, 1] (llm.py:278)");
     QA_REQUIRE(top_k >= 0 && top_p > 0.f, "qa_sample_logits: bad top_k / top_p");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    QA_TRY(lm_sample_prepare());
     char* scratch = nullptr;
     QA_HIP(hipMalloc(reinterpret_cast<void**>(&scratch), 256 + sizeof(long long) * (size_t)B));
     int* state = reinterpret_cast<int*>(scratch);

@@ -53,6 +53,7 @@ int launch_lm_pick(const float* pmax, const int* pidx, int n_tiles, int B, int l
 int launch_lm_phase_init(long long* tok, long long first_id, int B, int* state, int pos, int reset_step, unsigned long long seed,
                          hipStream_t s);
 int launch_lm_advance(int* state, hipStream_t s);
+int lm_sample_prepare();
 int launch_lm_sample(const float* logits, long long ldl, int width, int B, int lo, int top_k, float top_p, float temperature,
                      int do_sample, long long* tok, long long* ids, long long ids_ld, int keep, const int* state, hipStream_t s);
 

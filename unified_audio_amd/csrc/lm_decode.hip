@@ -742,7 +742,7 @@ __global__ __launch_bounds__(1024) void lm_sample_kernel(const float* __restrict
             const int i = tid * per + u;
             if (i < n2) {
                 const float nxt = run + expf((ord2f((unsigned)(keys[i] >> 32)) - top) * invT);
-                if (uu >= run && uu < nxt) atomicMin(&s_pick, i);  // first position whose cumulative mass exceeds u
+                if (uu < nxt) atomicMin(&s_pick, i);  // first position whose cumulative mass exceeds u (robust to scan rounding)
                 run = nxt;
             }
         }
@@ -757,17 +757,23 @@ __global__ __launch_bounds__(1024) void lm_sample_kernel(const float* __restrict
     }
 }
 
+// the sampler sorts up to 16384 64-bit keys in LDS (128 KiB): raise the kernel's dynamic-LDS limit once per process, outside
+// any stream capture
+int lm_sample_prepare() {
+    static bool done = false;
+    if (!done) {
+        QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lm_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+        done = true;
+    }
+    return QA_OK;
+}
+
 int launch_lm_sample(const float* logits, long long ldl, int width, int B, int lo, int top_k, float top_p, float temperature,
                      int do_sample, long long* tok, long long* ids, long long ids_ld, int keep, const int* state, hipStream_t s) {
     int n_pow2 = 1024;
     while (n_pow2 < width) n_pow2 <<= 1;
     QA_REQUIRE(n_pow2 <= 16384, "lm_sample: vocabulary slice of %d entries exceeds the 16384 the sampler sorts in LDS", width);
     const size_t lds = (size_t)n_pow2 * sizeof(unsigned long long);
-    static bool attr_set = false;
-    if (!attr_set) {
-        QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lm_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
-        attr_set = true;
-    }
     hipLaunchKernelGGL(lm_sample_kernel, dim3(B), dim3(1024), lds, s, logits, ldl, width, n_pow2, lo, top_k, top_p, temperature,
                        do_sample, tok, ids, ids_ld, keep, state);
     QA_LAUNCH_CHECK();

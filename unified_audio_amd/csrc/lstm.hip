@@ -2,20 +2,28 @@
 // projection (reference: QuarkAudio-HCodec/HCodec-1.0/vq/encoder_modules/transformer.py:115,133).
 //
 // The input half (x W_ih^T + b_ih + b_hh) is one big batched GEMM done by conv_gemm; what remains is the strictly
-// sequential recurrence  gates_t = xw_t + h_{t-1} W_hh^T.  Round-1 structure: one launch per time step (the kernel
-// boundary is the cross-CU synchronisation; MI355X_MICROARCH "boundary" row: ~1.5-1.9 us, cheaper than a software
-// grid barrier), d/4 workgroups per step.  A workgroup owns 4 hidden units x 4 gates = 16 rows of W_hh (rows
+// sequential recurrence  gates_t = xw_t + h_{t-1} W_hh^T.  Structure: one launch per time step - every step is an all-to-all
+// seam (each gate needs the whole h_{t-1} of its batch row), the kernel boundary IS the cross-CU synchronisation and at
+// ~1.2-1.9 us (MI355X_MICROARCH price list, "boundary") it is cheaper than any in-launch exchange of a 64-128 KB state across
+// 256 CUs ("barrier-xcd" 4.1 us, "allgather" 2.9-4.2 us for 32 KB), so a persistent weights-in-LDS kernel would lose per step
+// what it saves in L2 weight reads.  What the step must not do is serialise its memory round trips: every load of a wave's K
+// share is issued before its first MFMA (NI template), and the T launches of a call are replayed from a cached hipGraph so the
+// host never limits the 3-4 us step.  d/4 workgroups per step.  A workgroup owns 4 hidden units x 4 gates = 16 rows of W_hh (rows
 // pre-permuted to (unit, gate) order at load time) for ALL batch rows, splits K = d over its 8 waves, runs
 // v_mfma_f32_16x16x4_f32 with batch as the M dimension, reduces the 8 partial tiles through LDS and applies the
 // cell update in the same kernel, so gates never touch HBM.
+#include <cstdlib>
+#include <mutex>
+#include <vector>
+
 #include "kernels.h"
 
 namespace qa {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// MT = number of 16-row batch tiles (B <= 16*MT)
-template <int MT>
+// MT = number of 16-row batch tiles (B <= 16*MT); NI = 16-wide K steps per wave (d / 128) when known at compile time, 0 = loop
+template <int MT, int NI>
 __global__ __launch_bounds__(512) void lstm_step_kernel(const float* __restrict__ xw, const float* __restrict__ w_hh,
                                                         float* __restrict__ h_out, float* __restrict__ c_state, int B,
                                                         int T, int d, int t) {
@@ -50,15 +58,35 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const float* __restrict_
             if (b >= B) b = B - 1;  // rows past B are computed on a valid row and discarded
             hrow[m] = h_out + ((long long)b * T + (t - 1)) * d + k0 + 4 * kq;
         }
-        for (int g = 0; g < kw; g += 16) {
-            const float4 wv = *reinterpret_cast<const float4*>(wrow + g);
+        if (NI > 0) {  // all of this wave's W_hh and h loads in flight before the first MFMA: one L2 round trip per step
+            float4 wv[NI > 0 ? NI : 1], hv[MT][NI > 0 ? NI : 1];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const float4 hv = *reinterpret_cast<const float4*>(hrow[m] + g);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.x, wv.x, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.y, wv.y, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.z, wv.z, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.w, wv.w, acc[m], 0, 0, 0);
+            for (int i = 0; i < NI; ++i) wv[i] = *reinterpret_cast<const float4*>(wrow + i * 16);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) hv[m][i] = *reinterpret_cast<const float4*>(hrow[m] + i * 16);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[m][i].x, wv[i].x, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[m][i].y, wv[i].y, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[m][i].z, wv[i].z, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[m][i].w, wv[i].w, acc[m], 0, 0, 0);
+                }
+        } else {
+            for (int g = 0; g < kw; g += 16) {
+                const float4 wv = *reinterpret_cast<const float4*>(wrow + g);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float4 hv = *reinterpret_cast<const float4*>(hrow[m] + g);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.x, wv.x, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.y, wv.y, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.z, wv.z, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.w, wv.w, acc[m], 0, 0, 0);
+                }
             }
         }
     }
@@ -87,25 +115,102 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const float* __restrict_
     }
 }
 
-int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d,
-                hipStream_t s) {
-    QA_REQUIRE(d % 128 == 0, "lstm: hidden size %d must be a multiple of 128", d);
+template <int MT>
+static void launch_step(int ni, dim3 grid, hipStream_t s, const float* xw, const float* w, float* h, float* c, int bn, int T, int d, int t) {
+#define QA_LS(NI) hipLaunchKernelGGL((lstm_step_kernel<MT, NI>), grid, dim3(512), 0, s, xw, w, h, c, bn, T, d, t)
+    switch (ni) {
+        case 1: QA_LS(1); break;
+        case 2: QA_LS(2); break;
+        case 4: QA_LS(4); break;    // d = 512  (H-Codec encoder)
+        case 6: QA_LS(6); break;    // d = 768  (H-Codec 1.0 decoder)
+        case 8: QA_LS(8); break;    // d = 1024 (H-Codec 1.5 decoder)
+        case 12: QA_LS(12); break;  // d = 1536 (H-Codec 2.0)
+        default: QA_LS(0); break;
+    }
+#undef QA_LS
+}
+
+static int lstm_launch_steps(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d, hipStream_t s) {
+    const int ni = (d % 128 == 0) ? d / 128 : 0;
     for (int b0 = 0; b0 < B; b0 += 64) {
         const int bn = std::min(64, B - b0);
         const float* xw_b = xw + (long long)b0 * T * 4 * d;
         float* h_b = h_out + (long long)b0 * T * d;
         float* c_b = c_state + (long long)b0 * d;
         const int mt = (int)ceil_div(bn, 16);
+        const dim3 grid(d / 4);
         for (int t = 0; t < T; ++t) {
             switch (mt) {
-                case 1: hipLaunchKernelGGL(lstm_step_kernel<1>, dim3(d / 4), dim3(512), 0, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
-                case 2: hipLaunchKernelGGL(lstm_step_kernel<2>, dim3(d / 4), dim3(512), 0, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
-                case 3: hipLaunchKernelGGL(lstm_step_kernel<3>, dim3(d / 4), dim3(512), 0, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
-                default: hipLaunchKernelGGL(lstm_step_kernel<4>, dim3(d / 4), dim3(512), 0, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
+                case 1: launch_step<1>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
+                case 2: launch_step<2>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
+                case 3: launch_step<3>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
+                default: launch_step<4>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
             }
         }
         QA_LAUNCH_CHECK();
     }
+    return QA_OK;
+}
+
+// The T step launches of one call as a hipGraph: captured once per (buffers, shape) - the model graphs re-use the same arena
+// addresses call after call - and replayed, so the host issues one graph launch instead of T kernel launches (eager launches go
+// host-bound below ~3.5 us per kernel).  QA_LSTM_GRAPH=0 keeps the eager launches.
+namespace {
+struct LstmGraph {
+    const void *xw, *w, *h, *c;
+    int B, T, d, device;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    unsigned long long stamp;
+};
+std::mutex g_lstm_mu;
+std::vector<LstmGraph> g_lstm_graphs;
+hipStream_t g_lstm_cap[16] = {};
+unsigned long long g_lstm_clock = 0;
+constexpr size_t LSTM_GRAPH_CACHE = 24;
+}  // namespace
+
+int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d,
+                hipStream_t s) {
+    QA_REQUIRE(d % 128 == 0, "lstm: hidden size %d must be a multiple of 128", d);
+    static const bool use_graph = [] {
+        const char* e = std::getenv("QA_LSTM_GRAPH");
+        return !(e && e[0] == '0');
+    }();
+    if (!use_graph || T < 8) return lstm_launch_steps(xw, w_hh_ug, h_out, c_state, B, T, d, s);
+    int dev = 0;
+    QA_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_lstm_mu);
+    LstmGraph* hit = nullptr;
+    for (LstmGraph& g : g_lstm_graphs)
+        if (g.xw == xw && g.w == w_hh_ug && g.h == h_out && g.c == c_state && g.B == B && g.T == T && g.d == d && g.device == dev) hit = &g;
+    if (!hit) {
+        QA_REQUIRE(dev >= 0 && dev < 16, "lstm: device index %d out of range", dev);
+        if (!g_lstm_cap[dev]) QA_HIP(hipStreamCreateWithFlags(&g_lstm_cap[dev], hipStreamNonBlocking));
+        QA_HIP(hipStreamBeginCapture(g_lstm_cap[dev], hipStreamCaptureModeThreadLocal));
+        const int st = lstm_launch_steps(xw, w_hh_ug, h_out, c_state, B, T, d, g_lstm_cap[dev]);
+        hipGraph_t graph = nullptr;
+        const hipError_t e = hipStreamEndCapture(g_lstm_cap[dev], &graph);
+        if (st != QA_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return st;
+        }
+        QA_HIP(e);
+        hipGraphExec_t exec = nullptr;
+        QA_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        if (g_lstm_graphs.size() >= LSTM_GRAPH_CACHE) {  // evict the least recently used entry
+            size_t lru = 0;
+            for (size_t i = 1; i < g_lstm_graphs.size(); ++i)
+                if (g_lstm_graphs[i].stamp < g_lstm_graphs[lru].stamp) lru = i;
+            (void)hipGraphExecDestroy(g_lstm_graphs[lru].exec);
+            (void)hipGraphDestroy(g_lstm_graphs[lru].graph);
+            g_lstm_graphs.erase(g_lstm_graphs.begin() + (long)lru);
+        }
+        g_lstm_graphs.push_back(LstmGraph{xw, w_hh_ug, h_out, c_state, B, T, d, dev, graph, exec, 0});
+        hit = &g_lstm_graphs.back();
+    }
+    hit->stamp = ++g_lstm_clock;
+    QA_HIP(hipGraphLaunch(hit->exec, s));
     return QA_OK;
 }
 

@@ -4,10 +4,19 @@
 // and :183-184; arithmetic as stated in-tree by vq/core_vq.py:223-231 (dist = |x|^2 - 2 x.e + |e|^2, arg-max of the negative,
 // first maximum wins), :394-404 (r <- r - e_idx per stage) and :406-412 (decode = sum of look-ups).
 //
-// All Q stages run in ONE launch: a workgroup keeps the residuals of 32 vectors in LDS (fp32), each of its 4 waves sweeps
-// a quarter of the codebook 32 codes at a time with v_mfma_f32_32x32x2_f32 (A = residual tile from LDS, B = code rows straight
-// from L2: the 2 MB stage codebook is shared by every workgroup), keeps a per-lane running arg-min, then the winners are
-// reduced with wave shuffles and one LDS exchange, ties resolving to the lowest index, and the residual update is fused.
+// Main path (D a multiple of 32): per stage the distance products  S = R E_q^T  ([n_vec, K], K = 1024 codes x D = 512) are a
+// plain contraction and run on the library's implicit-GEMM kernel (conv_gemm.hip: code rows and residual rows staged through
+// LDS, fp32 MFMA, >= 256 workgroups even for ~1000 vectors because the tile grid covers vectors x codes), then ONE wave per
+// vector (rvq_pick_kernel) forms dist = (|r|^2 - 2 s) + |e|^2 with the reference's association, reduces the arg-min over the K
+// codes with wave shuffles (lowest index on ties), writes the index, subtracts the chosen code from the residual and leaves
+// the new |r|^2 for the next stage.  The stages are sequential by definition (core_vq.py:394-404), so a stage = 2 launches;
+// vectors are processed in chunks of 16384 so S (64 MB) stays inside the Infinity Cache between the two.
+// Fallback (other D): all Q stages in ONE launch - a workgroup keeps the residuals of 32 vectors in LDS (fp32), each of its 4
+// waves sweeps a quarter of the codebook 32 codes at a time with v_mfma_f32_32x32x2_f32 (A = residual tile from LDS, B = code
+// rows straight from L2), keeps a per-lane running arg-min, then the winners are reduced with wave shuffles and one LDS
+// exchange, ties resolving to the lowest index, and the residual update is fused.  It only uses n_vec / 32 workgroups.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace qa {
@@ -134,6 +143,66 @@ __global__ __launch_bounds__(256) void rvq_search_kernel(const float* __restrict
     }
 }
 
+// residual workspace of a chunk: R = x, x2 = |x|^2 (one wave per vector)
+__global__ __launch_bounds__(256) void rvq_prep_kernel(const float* __restrict__ x, long long n, int D, float* __restrict__ R,
+                                                       float* __restrict__ x2) {
+    const int lane = threadIdx.x & 63;
+    const long long v = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n) return;
+    float s = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 t = *reinterpret_cast<const float4*>(x + v * D + c);
+        *reinterpret_cast<float4*>(R + v * D + c) = t;
+        s += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+    }
+    s = wave_sum(s);
+    if (lane == 0) x2[v] = s;
+}
+
+// One wave per vector: arg-min over the K codes of dist = (|r|^2 - 2 r.e) + |e|^2 (core_vq.py:225-229 association), lowest
+// index on ties (torch.max returns the first maximum of the negated distance); then r <- r - e[idx], |r|^2 refreshed.
+__global__ __launch_bounds__(256) void rvq_pick_kernel(const float* __restrict__ S, long long ldS, float* __restrict__ x2,
+                                                       const float* __restrict__ e2q, const float* __restrict__ cbq,
+                                                       float* __restrict__ R, long long n, int K, int D,
+                                                       long long* __restrict__ indices, int Q, int q) {
+    const int lane = threadIdx.x & 63;
+    const long long v = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n) return;
+    const float xx = x2[v];
+    const float* row = S + v * ldS;
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane * 4; c < K; c += 256) {  // codes ascend per lane: strict '<' keeps the first minimum
+        const float4 s4 = *reinterpret_cast<const float4*>(row + c);
+        const float4 e4 = *reinterpret_cast<const float4*>(e2q + c);
+        const float d0 = (xx - 2.f * s4.x) + e4.x, d1 = (xx - 2.f * s4.y) + e4.y, d2 = (xx - 2.f * s4.z) + e4.z,
+                    d3 = (xx - 2.f * s4.w) + e4.w;
+        if (d0 < best) { best = d0; bi = c; }
+        if (d1 < best) { best = d1; bi = c + 1; }
+        if (d2 < best) { best = d2; bi = c + 2; }
+        if (d3 < best) { best = d3; bi = c + 3; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float d2 = __shfl_xor(best, o, 64);
+        const int i2 = __shfl_xor(bi, o, 64);
+        argmin_merge(best, bi, d2, i2);
+    }
+    if (bi == 0x7fffffff) bi = 0;  // all-NaN row: stay inside the codebook
+    if (lane == 0) indices[v * Q + q] = bi;
+    const float* e = cbq + (long long)bi * D;
+    float s = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        float4 t = *reinterpret_cast<float4*>(R + v * D + c);
+        const float4 ev = *reinterpret_cast<const float4*>(e + c);
+        t.x -= ev.x; t.y -= ev.y; t.z -= ev.z; t.w -= ev.w;
+        *reinterpret_cast<float4*>(R + v * D + c) = t;
+        s += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+    }
+    s = wave_sum(s);
+    if (lane == 0) x2[v] = s;
+}
+
 // |e|^2 of every code vector: one wave per code
 __global__ __launch_bounds__(256) void rvq_norms_kernel(const float* __restrict__ cb, float* __restrict__ e2, int QK,
                                                         int D) {
@@ -175,22 +244,60 @@ int launch_rvq_norms(const float* codebooks, float* e2, int QK, int D, hipStream
     return QA_OK;
 }
 
+constexpr long long RVQ_CHUNK = 16384;
+
+static bool rvq_gemm_ok(int K, int D) { return D % 32 == 0 && K % 4 == 0 && K >= 32; }
+
+size_t rvq_scratch_floats(long long n_vec, int K, int D) {
+    if (!rvq_gemm_ok(K, D) || n_vec <= 0) return 0;
+    const long long ch = std::min(n_vec, RVQ_CHUNK);
+    return (size_t)ch * ((size_t)K + D + 1) + 64;
+}
+
 int launch_rvq_search(const float* x, long long n_vec, const float* codebooks, const float* e2, int Q, int K, int D,
-                      long long* indices, float* quantized, long long ldq, hipStream_t s) {
+                      long long* indices, float* quantized, long long ldq, float* scratch, hipStream_t s) {
     QA_REQUIRE(D % 8 == 0 && D >= 8, "rvq_search: D=%d must be a multiple of 8", D);
     QA_REQUIRE(Q >= 1 && K >= 1, "rvq_search: Q=%d K=%d", Q, K);
     if (n_vec <= 0) return QA_OK;
-    const size_t lds = (size_t)(32 * (D + 4) + 32 + 4 * 32) * sizeof(float) + (4 * 32 + 32) * sizeof(int);
-    QA_REQUIRE(lds <= 160 * 1024, "rvq_search: D=%d needs %zu B of LDS", D, lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_search_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    if (rvq_gemm_ok(K, D) && std::getenv("QA_RVQ_LEGACY") == nullptr) {
+        QA_REQUIRE(scratch != nullptr, "rvq_search: the GEMM path needs rvq_scratch_floats() floats of workspace");
+        const long long ch = std::min(n_vec, RVQ_CHUNK);
+        float* R = scratch;                  // [ch, D] residuals
+        float* S = R + (size_t)ch * D;       // [ch, K] residual . code products
+        float* x2 = S + (size_t)ch * K;      // [ch]
+        for (long long v0 = 0; v0 < n_vec; v0 += ch) {
+            const long long n = std::min(ch, n_vec - v0);
+            const unsigned grid = (unsigned)ceil_div(n, 4);
+            hipLaunchKernelGGL(rvq_prep_kernel, dim3(grid), dim3(256), 0, s, x + v0 * D, n, D, R, x2);
+            QA_LAUNCH_CHECK();
+            for (int q = 0; q < Q; ++q) {
+                const float* cbq = codebooks + (long long)q * K * D;
+                qa_conv_args a{};
+                a.x = R; a.w = cbq; a.y = S;
+                a.B = 1; a.T_in = n; a.C_in = D; a.T_out = n; a.N = K;
+                a.ldx = D; a.ldy = K; a.ldr = K; a.ldg = K;
+                a.ksize = 1; a.stride = 1;
+                ConvParams p;
+                QA_TRY(conv_params_from_args(a, &p));
+                QA_TRY(launch_conv_gemm(p, s));
+                hipLaunchKernelGGL(rvq_pick_kernel, dim3(grid), dim3(256), 0, s, S, (long long)K, x2, e2 + (long long)q * K, cbq, R, n, K, D,
+                                   indices + v0 * Q, Q, q);
+                QA_LAUNCH_CHECK();
+            }
+        }
+    } else {
+        const size_t lds = (size_t)(32 * (D + 4) + 32 + 4 * 32) * sizeof(float) + (4 * 32 + 32) * sizeof(int);
+        QA_REQUIRE(lds <= 160 * 1024, "rvq_search: D=%d needs %zu B of LDS", D, lds);
+        static bool attr_set = false;
+        if (!attr_set) {
+            QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_search_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(rvq_search_kernel, dim3((unsigned)ceil_div(n_vec, 32)), dim3(256), lds, s, x, n_vec, codebooks,
+                           e2, Q, K, D, indices);
+        QA_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(rvq_search_kernel, dim3((unsigned)ceil_div(n_vec, 32)), dim3(256), lds, s, x, n_vec, codebooks,
-                       e2, Q, K, D, indices);
-    QA_LAUNCH_CHECK();
     if (quantized) return launch_rvq_lookup(indices, n_vec, codebooks, Q, K, D, quantized, ldq, s);
     return QA_OK;
 }
