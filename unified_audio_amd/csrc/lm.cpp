@@ -329,7 +329,7 @@ int fused_step(qa_lm* lm, const LMBuffers& b, int B, int lo, int width, long lon
         q.rope = lm->rope; q.q = b.q; q.kc = kc; q.vc = vc; q.kv_bstride = kv_bstride;
         QA_TRY(launch_lm_gemv(q, GM_QKV, lm->nt_qkv, s));
         // 2. attention over the cache (pos + 1 keys), split over S_att workgroups per (sequence, head)
-        QA_TRY(launch_lm_attn(b.q, d, kc, vc, kv_bstride, d, b.att_part, B, H, hd, b.S_att, b.state, scale, s));
+        QA_TRY(launch_lm_attn(b.q, d, kc, vc, kv_bstride, d, b.att_part, B, H, hd, b.S_att, b.state, scale, b.cap, s));
         // 3. merge of the partials + o_proj + residual
         GemvArgs o = a;
         o.att_part = b.att_part; o.S = b.S_att;
@@ -386,7 +386,7 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
     const int64_t prow = (int64_t)B * L;
     LMBuffers b{};
     b.cap = cap;
-    b.S_att = std::max(1, std::min(4, 256 / std::max(1, H * B)));
+    b.S_att = std::max(1, std::min(4, (int)ceil_div(cap, 256)));  // one round of 2 tiles x 8 waves covers 256 keys per workgroup
     b.x = c.arena.alloc<float>(prow * d);
     b.hn = c.arena.alloc<float>(prow * d);
     b.qkv = c.arena.alloc<float>(prow * 3 * d);

@@ -47,7 +47,7 @@ int lm_pick_nt(int N);
 bool lm_gemv_supported(int hidden, int intermediate);  // kernel instances exist for these K
 int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s);
 int launch_lm_attn(const float* q, long long ldq, const float* kc, const float* vc, long long kv_bstride, long long ldkv,
-                   float* part, int B, int H, int hd, int S, const int* state, float scale, hipStream_t s);
+                   float* part, int B, int H, int hd, int S, const int* state, float scale, int cap, hipStream_t s);
 int launch_lm_pick(const float* pmax, const int* pidx, int n_tiles, int B, int lo, long long* tok, long long* ids, long long ids_ld,
                    int keep, int* state, hipStream_t s);
 int launch_lm_phase_init(long long* tok, long long first_id, int B, int* state, int pos, int reset_step, unsigned long long seed,

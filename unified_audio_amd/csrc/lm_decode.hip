@@ -36,24 +36,36 @@ __device__ __forceinline__ float4 ldg_nt(const float* p) {
 // o = sum_s f_s o_s / sum_s f_s l_s with f_s = exp(m_s - max_s m_s); partial record = [o (hd) | m | l | pad2]
 template <int NF>
 __device__ __forceinline__ void att_merge(const GemvArgs& a, int row, int k, float4* out) {
+    constexpr int SMAX = 4;  // launch_lm_attn caps the split count
     const int h = k / a.hd, i = k - h * a.hd, rec = a.hd + 4;
     const float* base = a.att_part + ((long long)(row * a.H + h) * a.S) * rec;
-    float m = -INFINITY;
-    for (int s = 0; s < a.S; ++s) m = fmaxf(m, base[s * rec + a.hd]);
+    float ms[SMAX], ls[SMAX];
+    float4 o[SMAX][NF];
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {  // every load first (one round trip), then the arithmetic
+        const bool on = s < a.S;
+        ms[s] = on ? base[s * rec + a.hd] : -INFINITY;
+        ls[s] = on ? base[s * rec + a.hd + 1] : 0.f;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+            o[s][f] = on ? *reinterpret_cast<const float4*>(base + s * rec + i + 4 * f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float m = ms[0];
+#pragma unroll
+    for (int s = 1; s < SMAX; ++s) m = fmaxf(m, ms[s]);
     float L = 0.f;
 #pragma unroll
     for (int f = 0; f < NF; ++f) out[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < a.S; ++s) {
-        const float ms = base[s * rec + a.hd];
-        const float w = (ms == -INFINITY) ? 0.f : expf(ms - m);
-        L = fmaf(base[s * rec + a.hd + 1], w, L);
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {
+        const float w = (ms[s] == -INFINITY) ? 0.f : expf(ms[s] - m);
+        L = fmaf(ls[s], w, L);
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            const float4 o = *reinterpret_cast<const float4*>(base + s * rec + i + 4 * f);
-            out[f].x = fmaf(w, o.x, out[f].x);
-            out[f].y = fmaf(w, o.y, out[f].y);
-            out[f].z = fmaf(w, o.z, out[f].z);
-            out[f].w = fmaf(w, o.w, out[f].w);
+            out[f].x = fmaf(w, o[s][f].x, out[f].x);
+            out[f].y = fmaf(w, o[s][f].y, out[f].y);
+            out[f].z = fmaf(w, o[s][f].z, out[f].z);
+            out[f].w = fmaf(w, o[s][f].w, out[f].w);
         }
     }
     const float inv = 1.0f / L;
@@ -63,26 +75,54 @@ __device__ __forceinline__ void att_merge(const GemvArgs& a, int row, int k, flo
     }
 }
 
-// RMSNorm statistics of the MT * 16 input rows (LlamaRMSNorm: mean of squares over K in fp32); the norm's weight is folded into W
-template <int MT>
-__device__ __forceinline__ void gemv_rstd(const GemvArgs& a, float* s_rstd, int wave, int lane) {
-    for (int r = wave; r < MT * 16; r += 8) {
-        const int row = min(r, a.M - 1);
-        const float* xr = a.tok ? a.table + a.tok[row] * a.ldx : a.x + (long long)row * a.ldx;
-        float sq = 0.f;
-        for (int c = lane * 4; c < a.K; c += 256) {
-            const float4 t = *reinterpret_cast<const float4*>(xr + c);
-            sq += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+// RMSNorm statistics (LlamaRMSNorm: mean of squares over K in fp32; the norm's weight is folded into W) come for free from the
+// A-operand registers: every wave adds the squares of its K share per row into s_sq[wave][row] and the epilogue sums the 8 shares.
+// Epilogue inputs that do not depend on the GEMV (residual rows, loop state, RoPE table entry) are loaded into registers at kernel
+// entry: a dependent load of data another kernel just wrote costs ~2 us on this chip, so a kernel must not chain them.
+struct EpiPre {
+    float res[4];   // GM_RESID: residual values of this thread's outputs
+    int pos;        // GM_QKV: position
+    float c[4], s[4];  // GM_QKV: cos / sin of this thread's rotary pairs
+};
+
+template <int MT, int NT, int MODE>
+__device__ __forceinline__ void epi_prefetch(const GemvArgs& a, int tile, int tid, EpiPre& e) {
+    if (MODE == GM_RESID) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + u * 512;
+            e.res[u] = 0.f;
+            if (i < MT * 16 * NT) {
+                const int row = i / NT, j = i - row * NT, n = tile * NT + j;
+                if (row < a.M)
+                    e.res[u] = a.res_tok ? a.res_table[a.res_tok[row] * a.ldr + n] : a.res[(long long)row * a.ldr + n];
+            }
         }
-        sq = wave_sum(sq);
-        if (lane == 0) s_rstd[r] = rsqrtf(sq / a.K + a.rms_eps);
+    } else if (MODE == GM_QKV) {
+        constexpr int HP = NT / 2;
+        e.pos = a.state[ST_POS];
+        const int hd = a.hd, half = hd >> 1, tps = a.d / NT;
+        const int sec = tile / tps, c0 = (tile - sec * tps) * NT, h = c0 / hd;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + u * 512;
+            e.c[u] = 1.f;
+            e.s[u] = 0.f;
+            if (i < MT * 16 * HP && sec != 2) {
+                const int row = i / HP, j = i - row * HP;
+                const int ri = ((c0 - h * hd) / NT) * HP + j;
+                e.c[u] = a.rope[((long long)e.pos * half + ri) * 2];
+                e.s[u] = a.rope[((long long)e.pos * half + ri) * 2 + 1];
+                (void)row;
+            }
+        }
     }
 }
 
 // Fused epilogues over the K-split partial tiles part[wave][m][row][col] (summed in a fixed order: deterministic, no atomics).
 template <int MT, int NT, int MODE>
-__device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const float (*part)[MT][16][17], const float* s_rstd, int tile,
-                                              int tid) {
+__device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const float (*part)[MT][16][17], const float (*s_sq)[MT * 16], int tile,
+                                              int tid, const EpiPre& e) {
     const int M = a.M;
     auto total = [&](int row, int col) {
         float v = 0.f;
@@ -90,25 +130,35 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const float (*p
         for (int wv = 0; wv < 8; ++wv) v += part[wv][row >> 4][row & 15][col];
         return v;
     };
+    auto rstd = [&](int row) {
+        float sq = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) sq += s_sq[wv][row];
+        return rsqrtf(sq / a.K + a.rms_eps);
+    };
     if (MODE == GM_QKV || MODE == GM_GATEUP) {
         constexpr int HP = NT / 2;  // pairs per tile: columns (j, j + HP)
-        for (int i = tid; i < MT * 16 * HP; i += 512) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + u * 512;
+            if (i >= MT * 16 * HP) break;
             const int row = i / HP, j = i - row * HP;
             if (row >= M) continue;
-            const float v1 = total(row, j) * s_rstd[row], v2 = total(row, j + HP) * s_rstd[row];
+            const float rs = rstd(row);
+            const float v1 = total(row, j) * rs, v2 = total(row, j + HP) * rs;
             if (MODE == GM_GATEUP) {
                 a.y[(long long)row * a.ldy + tile * HP + j] = silu_f(v1) * v2;  // LlamaMLP: down(silu(gate) * up)
             } else {
                 const int d = a.d, hd = a.hd, half = hd >> 1, tps = d / NT;
                 const int sec = tile / tps, c0 = (tile - sec * tps) * NT;
                 const int h = c0 / hd, ri = ((c0 - h * hd) / NT) * HP + j;  // rotary index in [0, hd/2)
-                const int pos = a.state[ST_POS];
+                const int pos = e.pos;
                 if (sec == 2) {  // V: no rotation
                     float* dst = a.vc + (long long)row * a.kv_bstride + (long long)pos * d + h * hd;
                     dst[ri] = v1;
                     dst[ri + half] = v2;
                 } else {  // rotate-half RoPE (LlamaRotaryEmbedding / apply_rotary_pos_emb)
-                    const float c = a.rope[((long long)pos * half + ri) * 2], sn = a.rope[((long long)pos * half + ri) * 2 + 1];
+                    const float c = e.c[u], sn = e.s[u];
                     float* dst = sec == 0 ? a.q + (long long)row * d + h * hd
                                           : a.kc + (long long)row * a.kv_bstride + (long long)pos * d + h * hd;
                     dst[ri] = v1 * c - v2 * sn;
@@ -117,12 +167,13 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const float (*p
             }
         }
     } else if (MODE == GM_RESID) {
-        for (int i = tid; i < MT * 16 * NT; i += 512) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + u * 512;
+            if (i >= MT * 16 * NT) break;
             const int row = i / NT, j = i - row * NT;
             if (row >= M) continue;
-            const int n = tile * NT + j;
-            const float r = a.res_tok ? a.res_table[a.res_tok[row] * a.ldr + n] : a.res[(long long)row * a.ldr + n];
-            a.y[(long long)row * a.ldy + n] = total(row, j) + r;
+            a.y[(long long)row * a.ldy + tile * NT + j] = total(row, j) + e.res[u];
         }
     } else {  // GM_HEAD: logits of this tile's NT vocabulary entries and their per-row maximum (first maximum wins)
         for (int i = tid; i < MT * 16 * NT; i += 512) {  // MT * 16 * NT <= 512: one pass, whole NT-lane groups stay converged
@@ -130,7 +181,7 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const float (*p
             const int n = tile * NT + j;
             float v = -INFINITY;
             if (row < M) {
-                v = total(row, j) * s_rstd[row];
+                v = total(row, j) * rstd(row);
                 if (a.logits) a.logits[(long long)row * a.ldl + n] = v;
             }
             int bi = n;
@@ -161,7 +212,7 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const float (*p
 template <int MT, int NT, int MODE, bool ATT, int NB>
 __global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a) {
     __shared__ float part[8][MT][16][17];
-    __shared__ float s_rstd[MT * 16];
+    __shared__ float s_sq[8][MT * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int tile = blockIdx.x;
@@ -181,10 +232,15 @@ __global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a) {
         const int row = min(m * 16 + li, M - 1);
         xrow[m] = a.tok ? a.table + a.tok[row] * a.ldx : a.x + (long long)row * a.ldx;
     }
-    if (MODE != GM_RESID) gemv_rstd<MT>(a, s_rstd, wave, lane);
+    EpiPre epi;
+    epi_prefetch<MT, NT, MODE>(a, tile, tid, epi);
     f32x4 acc[MT];
+    float sq[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m) {
+        acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        sq[m] = 0.f;
+    }
     const int kbase = k0 + 8 * kq;
     for (int c0 = 0; c0 < nchunk; c0 += NB) {
         if (c0 > 0) {
@@ -212,6 +268,8 @@ __global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const float4 a0 = xa[m][c][0], a1 = xa[m][c][1], w0 = wr[c][0], w1 = wr[c][1];
+                if (MODE != GM_RESID)
+                    sq[m] += (a0.x * a0.x + a0.y * a0.y + a0.z * a0.z + a0.w * a0.w) + (a1.x * a1.x + a1.y * a1.y + a1.z * a1.z + a1.w * a1.w);
                 acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w0.x, acc[m], 0, 0, 0);
                 acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w0.y, acc[m], 0, 0, 0);
                 acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w0.z, acc[m], 0, 0, 0);
@@ -226,8 +284,17 @@ __global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[wave][m][4 * kq + r][li] = acc[m][r];
+    if (MODE != GM_RESID) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float v = sq[m];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (kq == 0) s_sq[wave][m * 16 + li] = v;
+        }
+    }
     __syncthreads();
-    gemv_epilogue<MT, NT, MODE>(a, part, s_rstd, tile, tid);
+    gemv_epilogue<MT, NT, MODE>(a, part, s_sq, tile, tid, epi);
 }
 
 // The same GEMV for NARROW column tiles (NT = 4 * C columns, C = 1 or 2) on v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4x1
@@ -239,7 +306,7 @@ template <int MT, int C, int MODE, bool ATT, int NS>
 __global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a) {
     constexpr int NT = 4 * C;
     __shared__ float part[8][MT][16][17];
-    __shared__ float s_rstd[MT * 16];
+    __shared__ float s_sq[8][MT * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, p = (lane >> 2) & 3, i4 = lane & 3;
     const int tile = blockIdx.x;
@@ -260,12 +327,16 @@ __global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a) {
         const int row = min(m * 16 + 4 * g + i4, M - 1);
         xrow[m] = a.tok ? a.table + a.tok[row] * a.ldx : a.x + (long long)row * a.ldx;
     }
-    if (MODE != GM_RESID) gemv_rstd<MT>(a, s_rstd, wave, lane);
+    EpiPre epi;
+    epi_prefetch<MT, NT, MODE>(a, tile, tid, epi);
     f32x4 acc[MT][C];
+    float sq[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m) {
+        sq[m] = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[m][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     for (int s0 = 0; s0 < nstep; s0 += NS) {
         if (s0 > 0) {
 #pragma unroll
@@ -285,7 +356,11 @@ __global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m) {
+                if (MODE != GM_RESID) {
+                    const float4 x4 = xa[m][s];
+                    sq[m] += x4.x * x4.x + x4.y * x4.y + x4.z * x4.z + x4.w * x4.w;
+                }
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const float4 x4 = xa[m][s], w4 = wr[s][c];
@@ -294,6 +369,7 @@ __global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a) {
                     acc[m][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(x4.z, w4.z, acc[m][c], 0, 0, 0);
                     acc[m][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(x4.w, w4.w, acc[m][c], 0, 0, 0);
                 }
+            }
     }
     // D of block (g, p): VGPR r = batch row 4g + r, lane & 3 = column; sum the 4 K phases (lane bits 2, 3)
 #pragma unroll
@@ -307,8 +383,17 @@ __global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a) {
                 v += __shfl_xor(v, 8, 64);
                 if (p == 0) part[wave][m][4 * g + r][c * 4 + i4] = v;
             }
+    if (MODE != GM_RESID) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float v = sq[m];
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 8, 64);
+            if (p == 0) s_sq[wave][m * 16 + 4 * g + i4] = v;
+        }
+    }
     __syncthreads();
-    gemv_epilogue<MT, NT, MODE>(a, part, s_rstd, tile, tid);
+    gemv_epilogue<MT, NT, MODE>(a, part, s_sq, tile, tid, epi);
 }
 
 // column-tile width: as wide as possible (MFMA efficiency is irrelevant here) while the launch still spreads over >= 160 workgroups
@@ -388,77 +473,93 @@ int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Single-query attention over the KV cache, keys split over S workgroups per (batch, head).  A wave covers 16 keys per
-// iteration: lane = (key = lane >> 2, 16-float slice = lane & 3), 64 contiguous bytes per lane and 256 per key; scores are
-// finished with two shuffles, softmax is online per wave, the NW wave states are merged through LDS into one partial record
-// [o (HD, un-normalised, relative to m) | m | l | pad2] that the o_proj GEMV merges across the S splits (att_merge8).
-// The number of keys (pos + 1, the new key included) is read from the device-side loop state.
+// Single-query attention over the KV cache, keys dealt in 16-key tiles round-robin to S workgroups per (batch, head) and their
+// NW waves.  A wave covers 16 keys per tile: lane = (key = lane >> 2, 16-float slice = lane & 3), 64 contiguous bytes per lane
+// and 256 per key; scores are finished with two shuffles, softmax is online per wave, the NW wave states are merged through LDS
+// into one partial record [o (HD, un-normalised, relative to m) | m | l | pad2] that the o_proj GEMV merges across the S splits
+// (att_merge).  The number of keys (pos + 1, the new key included) lives in the device-side loop state; because a dependent load
+// costs ~2 us here, the K / V loads of a wave's first TWO tiles are issued before that number is known (the tile -> key mapping
+// does not depend on it and rows below the cache capacity are always readable), and masked once it arrives.
 template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64) void lm_attn_kernel(const float* __restrict__ q, long long ldq,
                                                           const float* __restrict__ kc, const float* __restrict__ vc,
                                                           long long kv_bstride, long long ldkv, float* __restrict__ part,
-                                                          const int* __restrict__ state, float scale) {
+                                                          const int* __restrict__ state, float scale, int cap) {
     constexpr int SL = HD / 4;  // floats per lane slice
+    constexpr int NF = SL / 4;  // float4 per lane slice
     __shared__ float s_m[NW], s_l[NW];
     __shared__ float s_o[NW][HD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, h = blockIdx.x, sp = blockIdx.z, S = gridDim.z, H = gridDim.x;
-    const int n_keys = state[ST_POS] + 1;
-    const int per = (((n_keys + S - 1) / S) + 15) & ~15;
-    const int k_begin = sp * per, k_end = min(n_keys, k_begin + per);
     const int kl = lane >> 2, sl = lane & 3;
-    const float* qp = q + (long long)b * ldq + h * HD + sl * SL;
-    float qv[SL];
-#pragma unroll
-    for (int i = 0; i < SL; i += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(qp + i);
-        qv[i] = t.x * scale; qv[i + 1] = t.y * scale; qv[i + 2] = t.z * scale; qv[i + 3] = t.w * scale;
-    }
     const float* kb = kc + (long long)b * kv_bstride + h * HD + sl * SL;
     const float* vb = vc + (long long)b * kv_bstride + h * HD + sl * SL;
+    const float* qp = q + (long long)b * ldq + h * HD + sl * SL;
     float m_run = -INFINITY, l_run = 0.f;
     float o[SL];
 #pragma unroll
     for (int i = 0; i < SL; ++i) o[i] = 0.f;
-    for (int k0 = k_begin + wave * 16; k0 < k_end; k0 += NW * 16) {
-        const int key = k0 + kl;
-        const bool ok = key < k_end;
-        const int kk = ok ? key : k_end - 1;
-        float sdot = 0.f;
-        const float* kp = kb + (long long)kk * ldkv;
-        const float* vp = vb + (long long)kk * ldkv;
-        float4 kt[SL / 4], vt[SL / 4];
+    float qv[SL];
+    int n_keys = 0;
+    for (int it = 0;; it += 2) {
+        const int ka = ((it * NW + wave) * S + sp) * 16, kb2 = (((it + 1) * NW + wave) * S + sp) * 16;
+        if (ka >= cap) break;
+        float4 kt[2][NF], vt[2][NF];
+        {
+            const int r0 = min(ka + kl, cap - 1), r1 = min(kb2 + kl, cap - 1);
 #pragma unroll
-        for (int i = 0; i < SL / 4; ++i) kt[i] = ldg_nt(kp + 4 * i);
+            for (int i = 0; i < NF; ++i) kt[0][i] = ldg_nt(kb + (long long)r0 * ldkv + 4 * i);
 #pragma unroll
-        for (int i = 0; i < SL / 4; ++i) vt[i] = ldg_nt(vp + 4 * i);
+            for (int i = 0; i < NF; ++i) vt[0][i] = ldg_nt(vb + (long long)r0 * ldkv + 4 * i);
 #pragma unroll
-        for (int i = 0; i < SL / 4; ++i) {
-            sdot = fmaf(qv[4 * i], kt[i].x, sdot);
-            sdot = fmaf(qv[4 * i + 1], kt[i].y, sdot);
-            sdot = fmaf(qv[4 * i + 2], kt[i].z, sdot);
-            sdot = fmaf(qv[4 * i + 3], kt[i].w, sdot);
+            for (int i = 0; i < NF; ++i) kt[1][i] = ldg_nt(kb + (long long)r1 * ldkv + 4 * i);
+#pragma unroll
+            for (int i = 0; i < NF; ++i) vt[1][i] = ldg_nt(vb + (long long)r1 * ldkv + 4 * i);
         }
-        sdot += __shfl_xor(sdot, 1, 64);
-        sdot += __shfl_xor(sdot, 2, 64);
-        const float sc = ok ? sdot : -INFINITY;
-        float tmax = sc;
+        if (it == 0) {
 #pragma unroll
-        for (int of = 4; of < 64; of <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, of, 64));
-        const float m_new = fmaxf(m_run, tmax);  // every executed tile has at least one valid key
-        const float alpha = expf(m_run - m_new);
-        const float p = ok ? expf(sc - m_new) : 0.f;
-        float psum = p;
+            for (int i = 0; i < SL; i += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(qp + i);
+                qv[i] = t.x * scale; qv[i + 1] = t.y * scale; qv[i + 2] = t.z * scale; qv[i + 3] = t.w * scale;
+            }
+            n_keys = state[ST_POS] + 1;
+        }
+        if (ka >= n_keys) break;
 #pragma unroll
-        for (int of = 4; of < 64; of <<= 1) psum += __shfl_xor(psum, of, 64);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
+        for (int u = 0; u < 2; ++u) {
+            const int k0 = u == 0 ? ka : kb2;
+            if (k0 >= n_keys) break;
+            const bool ok = k0 + kl < n_keys;
+            float sdot = 0.f;
 #pragma unroll
-        for (int i = 0; i < SL / 4; ++i) {
-            o[4 * i] = fmaf(p, vt[i].x, o[4 * i] * alpha);
-            o[4 * i + 1] = fmaf(p, vt[i].y, o[4 * i + 1] * alpha);
-            o[4 * i + 2] = fmaf(p, vt[i].z, o[4 * i + 2] * alpha);
-            o[4 * i + 3] = fmaf(p, vt[i].w, o[4 * i + 3] * alpha);
+            for (int i = 0; i < NF; ++i) {
+                sdot = fmaf(qv[4 * i], kt[u][i].x, sdot);
+                sdot = fmaf(qv[4 * i + 1], kt[u][i].y, sdot);
+                sdot = fmaf(qv[4 * i + 2], kt[u][i].z, sdot);
+                sdot = fmaf(qv[4 * i + 3], kt[u][i].w, sdot);
+            }
+            sdot += __shfl_xor(sdot, 1, 64);
+            sdot += __shfl_xor(sdot, 2, 64);
+            const float sc = ok ? sdot : -INFINITY;
+            float tmax = sc;
+#pragma unroll
+            for (int of = 4; of < 64; of <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, of, 64));
+            const float m_new = fmaxf(m_run, tmax);  // every processed tile has at least one valid key
+            const float alpha = expf(m_run - m_new);
+            const float p = ok ? expf(sc - m_new) : 0.f;
+            float psum = p;
+#pragma unroll
+            for (int of = 4; of < 64; of <<= 1) psum += __shfl_xor(psum, of, 64);
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                if (!ok) vt[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);  // rows past n_keys are uninitialised cache memory: 0 * NaN must not leak in
+                o[4 * i] = fmaf(p, vt[u][i].x, o[4 * i] * alpha);
+                o[4 * i + 1] = fmaf(p, vt[u][i].y, o[4 * i + 1] * alpha);
+                o[4 * i + 2] = fmaf(p, vt[u][i].z, o[4 * i + 2] * alpha);
+                o[4 * i + 3] = fmaf(p, vt[u][i].w, o[4 * i + 3] * alpha);
+            }
         }
     }
 #pragma unroll
@@ -492,18 +593,19 @@ __global__ __launch_bounds__(NW * 64) void lm_attn_kernel(const float* __restric
 }
 
 int launch_lm_attn(const float* q, long long ldq, const float* kc, const float* vc, long long kv_bstride, long long ldkv,
-                   float* part, int B, int H, int hd, int S, const int* state, float scale, hipStream_t s) {
-    QA_REQUIRE(S >= 1 && S <= 8, "lm_attn: bad split count %d", S);
+                   float* part, int B, int H, int hd, int S, const int* state, float scale, int cap, hipStream_t s) {
+    QA_REQUIRE(S >= 1 && S <= 4, "lm_attn: bad split count %d", S);
+    QA_REQUIRE(cap >= 1, "lm_attn: empty cache");
     const dim3 grid(H, B, S);
     switch (hd) {
         case 64:
-            hipLaunchKernelGGL((lm_attn_kernel<64, 16>), grid, dim3(1024), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale);
+            hipLaunchKernelGGL((lm_attn_kernel<64, 8>), grid, dim3(512), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale, cap);
             break;
         case 128:
-            hipLaunchKernelGGL((lm_attn_kernel<128, 16>), grid, dim3(1024), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale);
+            hipLaunchKernelGGL((lm_attn_kernel<128, 8>), grid, dim3(512), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale, cap);
             break;
         case 32:
-            hipLaunchKernelGGL((lm_attn_kernel<32, 16>), grid, dim3(1024), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale);
+            hipLaunchKernelGGL((lm_attn_kernel<32, 8>), grid, dim3(512), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale, cap);
             break;
         default: set_error("lm_attn: head_dim=%d unsupported", hd); return QA_ERR_UNSUPPORTED;
     }
