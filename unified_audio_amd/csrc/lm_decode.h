@@ -22,6 +22,7 @@ struct GemvArgs {
     int M, N, K;
     float rms_eps;
     const int* state;
+    int pos;  // >= 0: position of the step (host-driven loop); < 0: read it from state (captured step)
     // GM_QKV
     const float* rope;  // [pos][hd/2][2] cos, sin
     float* q;           // [M, d]
@@ -47,9 +48,9 @@ int lm_pick_nt(int N);
 bool lm_gemv_supported(int hidden, int intermediate);  // kernel instances exist for these K
 int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s);
 int launch_lm_attn(const float* q, long long ldq, const float* kc, const float* vc, long long kv_bstride, long long ldkv,
-                   float* part, int B, int H, int hd, int S, const int* state, float scale, int cap, hipStream_t s);
+                   float* part, int B, int H, int hd, int S, const int* state, float scale, int pos, hipStream_t s);
 int launch_lm_pick(const float* pmax, const int* pidx, int n_tiles, int B, int lo, long long* tok, long long* ids, long long ids_ld,
-                   int keep, int* state, hipStream_t s);
+                   int keep, int* state, int col, hipStream_t s);
 int launch_lm_phase_init(long long* tok, long long first_id, int B, int* state, int pos, int reset_step, unsigned long long seed,
                          hipStream_t s);
 int launch_lm_advance(int* state, hipStream_t s);

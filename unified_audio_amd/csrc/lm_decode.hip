@@ -100,7 +100,7 @@ __device__ __forceinline__ void epi_prefetch(const GemvArgs& a, int tile, int ti
         }
     } else if (MODE == GM_QKV) {
         constexpr int HP = NT / 2;
-        e.pos = a.state[ST_POS];
+        e.pos = a.pos >= 0 ? a.pos : a.state[ST_POS];
         const int hd = a.hd, half = hd >> 1, tps = a.d / NT;
         const int sec = tile / tps, c0 = (tile - sec * tps) * NT, h = c0 / hd;
 #pragma unroll
@@ -396,10 +396,11 @@ __global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a) {
     gemv_epilogue<MT, NT, MODE>(a, part, s_sq, tile, tid, epi);
 }
 
-// column-tile width: as wide as possible (MFMA efficiency is irrelevant here) while the launch still spreads over >= 160 workgroups
+// column-tile width: as wide as possible while the launch still spreads over >= 96 workgroups (measured on MI355X at B = 16:
+// qkv 96 x 16 columns beats 192 x 8 by 3 %, o_proj / down_proj 128 x 4 beat 64 x 8 by 3-9 %, gate/up 256 x 16 beats 512 x 8 by 9 %)
 int lm_pick_nt(int N) {
     int nt = 16;
-    while (nt > 4 && N / nt < 160) nt >>= 1;
+    while (nt > 4 && N / nt < 96) nt >>= 1;
     return nt;
 }
 
@@ -473,103 +474,96 @@ int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Single-query attention over the KV cache, keys dealt in 16-key tiles round-robin to S workgroups per (batch, head) and their
-// NW waves.  A wave covers 16 keys per tile: lane = (key = lane >> 2, 16-float slice = lane & 3), 64 contiguous bytes per lane
-// and 256 per key; scores are finished with two shuffles, softmax is online per wave, the NW wave states are merged through LDS
-// into one partial record [o (HD, un-normalised, relative to m) | m | l | pad2] that the o_proj GEMV merges across the S splits
-// (att_merge).  The number of keys (pos + 1, the new key included) lives in the device-side loop state; because a dependent load
-// costs ~2 us here, the K / V loads of a wave's first TWO tiles are issued before that number is known (the tile -> key mapping
-// does not depend on it and rows below the cache capacity are always readable), and masked once it arrives.
+// Single-query attention over the KV cache.  The 16-key tiles of a (sequence, head) are dealt round-robin to the S workgroups of
+// its split and their NW waves; a wave keeps two tiles (its K and V rows) in flight.  Lane map: LPK = HD / 4 lanes cover one key
+// row with one float4 each, so a load instruction reads 64 / LPK whole rows of 4 * HD contiguous bytes (full cache lines; the
+// first version gave each lane 64 contiguous bytes and touched 32 lines per instruction for 1 KB of payload).  Scores are
+// reduced over the LPK lanes of a key with shuffles, softmax is online per wave, the NW wave states are merged through LDS into
+// one partial record [o (HD, un-normalised, relative to m) | m | l | pad2] that the o_proj GEMV merges across the S splits
+// (att_merge).  n_keys = pos + 1 (the new key included): `pos` is a launch argument when the host drives the loop, or read from the
+// device-side loop state (pos < 0) when a captured step is replayed.
 template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64) void lm_attn_kernel(const float* __restrict__ q, long long ldq,
                                                           const float* __restrict__ kc, const float* __restrict__ vc,
                                                           long long kv_bstride, long long ldkv, float* __restrict__ part,
-                                                          const int* __restrict__ state, float scale, int cap) {
-    constexpr int SL = HD / 4;  // floats per lane slice
-    constexpr int NF = SL / 4;  // float4 per lane slice
+                                                          const int* __restrict__ state, float scale, int pos) {
+    constexpr int LPK = HD / 4;    // lanes per key row
+    constexpr int KPI = 64 / LPK;  // key rows per load instruction
+    constexpr int NI = 16 / KPI;   // load instructions per 16-key tile (per operand)
     __shared__ float s_m[NW], s_l[NW];
-    __shared__ float s_o[NW][HD];
+    __shared__ __attribute__((aligned(16))) float s_o[NW][HD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, h = blockIdx.x, sp = blockIdx.z, S = gridDim.z, H = gridDim.x;
-    const int kl = lane >> 2, sl = lane & 3;
-    const float* kb = kc + (long long)b * kv_bstride + h * HD + sl * SL;
-    const float* vb = vc + (long long)b * kv_bstride + h * HD + sl * SL;
-    const float* qp = q + (long long)b * ldq + h * HD + sl * SL;
+    const int kq = lane / LPK, c4 = (lane % LPK) * 4;
+    const int n_keys = (pos >= 0 ? pos : state[ST_POS]) + 1;
+    const int n_tiles = (n_keys + 15) >> 4;
+    const float* kb = kc + (long long)b * kv_bstride + h * HD + c4;
+    const float* vb = vc + (long long)b * kv_bstride + h * HD + c4;
+    float4 qv = *reinterpret_cast<const float4*>(q + (long long)b * ldq + h * HD + c4);
+    qv.x *= scale; qv.y *= scale; qv.z *= scale; qv.w *= scale;
     float m_run = -INFINITY, l_run = 0.f;
-    float o[SL];
-#pragma unroll
-    for (int i = 0; i < SL; ++i) o[i] = 0.f;
-    float qv[SL];
-    int n_keys = 0;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int it = 0;; it += 2) {
-        const int ka = ((it * NW + wave) * S + sp) * 16, kb2 = (((it + 1) * NW + wave) * S + sp) * 16;
-        if (ka >= cap) break;
-        float4 kt[2][NF], vt[2][NF];
-        {
-            const int r0 = min(ka + kl, cap - 1), r1 = min(kb2 + kl, cap - 1);
-#pragma unroll
-            for (int i = 0; i < NF; ++i) kt[0][i] = ldg_nt(kb + (long long)r0 * ldkv + 4 * i);
-#pragma unroll
-            for (int i = 0; i < NF; ++i) vt[0][i] = ldg_nt(vb + (long long)r0 * ldkv + 4 * i);
-#pragma unroll
-            for (int i = 0; i < NF; ++i) kt[1][i] = ldg_nt(kb + (long long)r1 * ldkv + 4 * i);
-#pragma unroll
-            for (int i = 0; i < NF; ++i) vt[1][i] = ldg_nt(vb + (long long)r1 * ldkv + 4 * i);
-        }
-        if (it == 0) {
-#pragma unroll
-            for (int i = 0; i < SL; i += 4) {
-                const float4 t = *reinterpret_cast<const float4*>(qp + i);
-                qv[i] = t.x * scale; qv[i + 1] = t.y * scale; qv[i + 2] = t.z * scale; qv[i + 3] = t.w * scale;
-            }
-            n_keys = state[ST_POS] + 1;
-        }
-        if (ka >= n_keys) break;
+        const int ta = (it * NW + wave) * S + sp, tb = ((it + 1) * NW + wave) * S + sp;
+        if (ta >= n_tiles) break;
+        float4 kt[2][NI], vt[2][NI];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int k0 = u == 0 ? ka : kb2;
-            if (k0 >= n_keys) break;
-            const bool ok = k0 + kl < n_keys;
-            float sdot = 0.f;
+            const int t = u == 0 ? ta : min(tb, n_tiles - 1);  // a missing second tile re-reads a valid one and is skipped below
 #pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                sdot = fmaf(qv[4 * i], kt[u][i].x, sdot);
-                sdot = fmaf(qv[4 * i + 1], kt[u][i].y, sdot);
-                sdot = fmaf(qv[4 * i + 2], kt[u][i].z, sdot);
-                sdot = fmaf(qv[4 * i + 3], kt[u][i].w, sdot);
+            for (int j = 0; j < NI; ++j) {
+                const int row = min(t * 16 + j * KPI + kq, n_keys - 1);  // clamp: rows past n_keys are uninitialised cache memory
+                kt[u][j] = ldg_nt(kb + (long long)row * ldkv);
+                vt[u][j] = ldg_nt(vb + (long long)row * ldkv);
             }
-            sdot += __shfl_xor(sdot, 1, 64);
-            sdot += __shfl_xor(sdot, 2, 64);
-            const float sc = ok ? sdot : -INFINITY;
-            float tmax = sc;
+        }
 #pragma unroll
-            for (int of = 4; of < 64; of <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, of, 64));
+        for (int u = 0; u < 2; ++u) {
+            const int t = u == 0 ? ta : tb;
+            if (t >= n_tiles) break;
+            float sc[NI];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                float d = qv.x * kt[u][j].x;
+                d = fmaf(qv.y, kt[u][j].y, d);
+                d = fmaf(qv.z, kt[u][j].z, d);
+                d = fmaf(qv.w, kt[u][j].w, d);
+#pragma unroll
+                for (int of = 1; of < LPK; of <<= 1) d += __shfl_xor(d, of, 64);
+                sc[j] = (t * 16 + j * KPI + kq < n_keys) ? d : -INFINITY;
+                tmax = fmaxf(tmax, sc[j]);
+            }
+#pragma unroll
+            for (int of = LPK; of < 64; of <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, of, 64));
             const float m_new = fmaxf(m_run, tmax);  // every processed tile has at least one valid key
             const float alpha = expf(m_run - m_new);
-            const float p = ok ? expf(sc - m_new) : 0.f;
-            float psum = p;
+            float psum = 0.f;
+            o.x *= alpha; o.y *= alpha; o.z *= alpha; o.w *= alpha;
 #pragma unroll
-            for (int of = 4; of < 64; of <<= 1) psum += __shfl_xor(psum, of, 64);
+            for (int j = 0; j < NI; ++j) {
+                const float p = expf(sc[j] - m_new);  // exp(-inf) = 0 for masked keys (their V row is a clamped, valid row)
+                psum += p;
+                o.x = fmaf(p, vt[u][j].x, o.x);
+                o.y = fmaf(p, vt[u][j].y, o.y);
+                o.z = fmaf(p, vt[u][j].z, o.z);
+                o.w = fmaf(p, vt[u][j].w, o.w);
+            }
+#pragma unroll
+            for (int of = LPK; of < 64; of <<= 1) psum += __shfl_xor(psum, of, 64);
             l_run = l_run * alpha + psum;
             m_run = m_new;
-#pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                if (!ok) vt[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);  // rows past n_keys are uninitialised cache memory: 0 * NaN must not leak in
-                o[4 * i] = fmaf(p, vt[u][i].x, o[4 * i] * alpha);
-                o[4 * i + 1] = fmaf(p, vt[u][i].y, o[4 * i + 1] * alpha);
-                o[4 * i + 2] = fmaf(p, vt[u][i].z, o[4 * i + 2] * alpha);
-                o[4 * i + 3] = fmaf(p, vt[u][i].w, o[4 * i + 3] * alpha);
-            }
         }
     }
 #pragma unroll
-    for (int i = 0; i < SL; ++i) {  // sum the 16 key-lanes that share a slice
-#pragma unroll
-        for (int of = 4; of < 64; of <<= 1) o[i] += __shfl_xor(o[i], of, 64);
+    for (int of = LPK; of < 64; of <<= 1) {  // sum the key groups that share a column slice
+        o.x += __shfl_xor(o.x, of, 64);
+        o.y += __shfl_xor(o.y, of, 64);
+        o.z += __shfl_xor(o.z, of, 64);
+        o.w += __shfl_xor(o.w, of, 64);
     }
-    if (lane < 4) {
-#pragma unroll
-        for (int i = 0; i < SL; ++i) s_o[wave][lane * SL + i] = o[i];
+    if (lane < LPK) {
+        *reinterpret_cast<float4*>(&s_o[wave][c4]) = o;
         if (lane == 0) {
             s_m[wave] = m_run;
             s_l[wave] = l_run;
@@ -593,19 +587,18 @@ __global__ __launch_bounds__(NW * 64) void lm_attn_kernel(const float* __restric
 }
 
 int launch_lm_attn(const float* q, long long ldq, const float* kc, const float* vc, long long kv_bstride, long long ldkv,
-                   float* part, int B, int H, int hd, int S, const int* state, float scale, int cap, hipStream_t s) {
+                   float* part, int B, int H, int hd, int S, const int* state, float scale, int pos, hipStream_t s) {
     QA_REQUIRE(S >= 1 && S <= 4, "lm_attn: bad split count %d", S);
-    QA_REQUIRE(cap >= 1, "lm_attn: empty cache");
     const dim3 grid(H, B, S);
     switch (hd) {
         case 64:
-            hipLaunchKernelGGL((lm_attn_kernel<64, 8>), grid, dim3(512), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale, cap);
+            hipLaunchKernelGGL((lm_attn_kernel<64, 8>), grid, dim3(512), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale, pos);
             break;
         case 128:
-            hipLaunchKernelGGL((lm_attn_kernel<128, 8>), grid, dim3(512), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale, cap);
+            hipLaunchKernelGGL((lm_attn_kernel<128, 8>), grid, dim3(512), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale, pos);
             break;
         case 32:
-            hipLaunchKernelGGL((lm_attn_kernel<32, 8>), grid, dim3(512), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale, cap);
+            hipLaunchKernelGGL((lm_attn_kernel<32, 8>), grid, dim3(512), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale, pos);
             break;
         default: set_error("lm_attn: head_dim=%d unsupported", hd); return QA_ERR_UNSUPPORTED;
     }
@@ -619,9 +612,9 @@ int launch_lm_attn(const float* q, long long ldq, const float* kc, const float* 
 // without a race): tok[b] = lo + argmax; ids[b, col] = argmax for col < keep; pos++, col++, step++.
 __global__ __launch_bounds__(1024) void lm_pick_kernel(const float* __restrict__ pmax, const int* __restrict__ pidx, int n_tiles,
                                                        int B, int lo, long long* __restrict__ tok, long long* __restrict__ ids,
-                                                       long long ids_ld, int keep, int* __restrict__ state) {
+                                                       long long ids_ld, int keep, int* __restrict__ state, int col_arg) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int col = state[ST_COL];
+    const int col = col_arg >= 0 ? col_arg : state[ST_COL];
     for (int b = wave; b < B; b += 16) {
         float best = -INFINITY;
         int bi = 0x7fffffff;
@@ -657,8 +650,8 @@ __global__ __launch_bounds__(1024) void lm_pick_kernel(const float* __restrict__
 }
 
 int launch_lm_pick(const float* pmax, const int* pidx, int n_tiles, int B, int lo, long long* tok, long long* ids, long long ids_ld,
-                   int keep, int* state, hipStream_t s) {
-    hipLaunchKernelGGL(lm_pick_kernel, dim3(1), dim3(1024), 0, s, pmax, pidx, n_tiles, B, lo, tok, ids, ids_ld, keep, state);
+                   int keep, int* state, int col, hipStream_t s) {
+    hipLaunchKernelGGL(lm_pick_kernel, dim3(1), dim3(1024), 0, s, pmax, pidx, n_tiles, B, lo, tok, ids, ids_ld, keep, state, col);
     QA_LAUNCH_CHECK();
     return QA_OK;
 }
