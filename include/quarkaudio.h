@@ -122,11 +122,13 @@ int qa_hcodec_decode(qa_hcodec* h, const int64_t* acoustic_codes, const int64_t*
  *   - encode writes int64 [B, nq, G] length-injected codes (code' = (len-1)*codebook_size + code) compactly into buffers of
  *     capacity B*nq*N25 elements and returns G through *n_groups (the call synchronises `stream` once);
  *   - qa_hcodec_adaptive_frames returns max_b sum_g len[b,g] (= N25 of the clip) for a batch of codes, so the caller can size
- *     wav_out = [B, frames * 2 * hop] before qa_hcodec_decode_adaptive. */
+ *     wav_out = [B, frames * 2 * hop] before qa_hcodec_decode_adaptive.
+ * threshold: the per-call similarity threshold of Codec.encode(..., threshold=t) (codec_adaptive.py:150-158): 0 = the model's
+ *   manual_threshold (spec.threshold), otherwise in (0, 1]. */
 int qa_hcodec_encode_adaptive(qa_hcodec* h, const float* wav, int64_t B, int64_t T,
                               const float* feat, int64_t feat_stride_b, int64_t feat_stride_c, int64_t feat_stride_t,
                               int64_t n_feat_frames, int64_t* acoustic_codes, int64_t* semantic_codes, int64_t* n_groups,
-                              void* stream);
+                              float threshold, void* stream);
 int qa_hcodec_adaptive_frames(qa_hcodec* h, const int64_t* semantic_codes, int64_t B, int64_t G, int64_t* frames, void* stream);
 int qa_hcodec_decode_adaptive(qa_hcodec* h, const int64_t* acoustic_codes, const int64_t* semantic_codes, int64_t B,
                               int64_t G, int64_t frames, float* wav_out, void* stream);
@@ -148,6 +150,17 @@ int qa_rvq_search(const float* x, int64_t n_vec, const float* codebooks, int32_t
  * NOT detected on device; the caller guarantees 0 <= idx < K (the reference would raise IndexError). */
 int qa_rvq_lookup(const int64_t* indices, int64_t n_vec, const float* codebooks, int32_t Q, int32_t K, int32_t D,
                   float* out, void* stream);
+
+/* Range check of integer codes before a decode (the reference's F.embedding raises IndexError on the host, or trips a device-side
+ * assert on a GPU): *bad = number of entries of codes[0..n) outside [0, limit).  One tiny kernel + one 4-byte copy; synchronises
+ * `stream`.  The decode entry points themselves never synchronise and clamp indices for memory safety. */
+int qa_codes_check(const int64_t* codes, int64_t n, int64_t limit, int64_t* bad, void* stream);
+
+/* torchaudio.transforms.Resample(orig_freq, new_freq) with its defaults (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99),
+ * the 48 kHz -> 16 kHz step in front of HuBERT in H-Codec 2.0 (HCodec-2.0/audio_tokenizer.py:44,51).
+ * qa_resample_length = ceil(new * T / orig) samples per clip; wav [B, T] -> out [B, qa_resample_length] (device). */
+int64_t qa_resample_length(int64_t T, int32_t orig_freq, int32_t new_freq);
+int qa_resample(const float* wav, int64_t B, int64_t T, int32_t orig_freq, int32_t new_freq, float* out, void* stream);
 
 /* Implicit-GEMM Conv1d over channel-last activations (covers nn.Linear with ksize = 1):
  *   y[b, t, n] = post( res[b,t,n] + gamma[n] * act( bias[n] + sum_{j,c} pro(x[b, src(t,j), c]) * w[n, j, c] ) )

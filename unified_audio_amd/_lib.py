@@ -80,7 +80,11 @@ SYMBOLS = {
                                    C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qa_hcodec_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "qa_hcodec_encode_adaptive": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
-                                            C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
+                                            C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_float,
+                                            C.c_void_p]),
+    "qa_codes_check": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
+    "qa_resample_length": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "qa_resample": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "qa_hcodec_adaptive_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
     "qa_hcodec_decode_adaptive": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                             C.c_void_p]),
@@ -147,14 +151,16 @@ def require_device() -> None:
 
 
 def tensor_table(state_dict):
-    """state_dict (name -> torch CPU tensor) -> (qa_tensor array, keep-alive list).  fp32 tensors only."""
+    """state_dict (name -> torch tensor) -> (qa_tensor array, keep-alive list).  Floating-point tensors of any precision
+    (fp16 / bf16 / fp64 checkpoints) are converted to fp32 on the host - the path computes in fp32 like the reference;
+    integer / bool buffers (e.g. `initted`, `num_batches_tracked`) are not weights and are skipped."""
     import torch
 
     keep, names = [], []
-    items = [(k, v) for k, v in state_dict.items() if torch.is_tensor(v) and v.dtype == torch.float32]
+    items = [(k, v) for k, v in state_dict.items() if torch.is_tensor(v) and v.is_floating_point()]
     arr = (qa_tensor * len(items))()
     for i, (k, v) in enumerate(items):
-        t = v.detach().to("cpu").contiguous()
+        t = v.detach().to(device="cpu", dtype=torch.float32).contiguous()
         nm = k.encode()
         keep.append(t)
         names.append(nm)

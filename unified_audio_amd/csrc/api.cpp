@@ -1,6 +1,8 @@
 // api.cpp - error channel and the kernel-level C-ABI entry points.
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -22,6 +24,7 @@ struct ProfRec {
     hipEvent_t a, b;
     int cfg;
     double flops, bytes;
+    int M, N, K, ksize, flags;  // shape of the launch (QA_GEMM_SHAPES report)
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
@@ -42,8 +45,12 @@ static bool g_serial = [] {
     return e && *e && *e != '0';
 }();
 bool serial_mode() { return g_serial; }
-void profile_record_begin(int cfg, double flops, double bytes, hipStream_t s) {
-    ProfRec r{prof_event(), prof_event(), cfg, flops, bytes};
+void profile_record_begin(int cfg, double flops, double bytes, hipStream_t s, const ConvParams* p) {
+    ProfRec r{prof_event(), prof_event(), cfg, flops, bytes, 0, 0, 0, 0, 0};
+    if (p) {
+        r.M = p->M; r.N = p->N; r.K = p->K; r.ksize = p->ksize;
+        r.flags = (p->res ? 1 : 0) | (p->gate ? 2 : 0) | (p->prologue ? 4 : 0) | (p->act ? 8 : 0);
+    }
     (void)hipEventRecord(r.a, s);
     g_prof.push_back(r);
 }
@@ -85,6 +92,34 @@ int qa_profile_end(double* out, int32_t n_out) {
         out[r.cfg * 4 + 1] += ms;
         out[r.cfg * 4 + 2] += 1.0;
         out[r.cfg * 4 + 3] += r.bytes;
+    }
+    // QA_GEMM_SHAPES=<path>: per-shape table of the profiled launches (tuning aid; summaries go to profiles/)
+    if (const char* path = g_prof.empty() ? nullptr : getenv("QA_GEMM_SHAPES")) {
+        struct Agg { int M, N, K, ksize, flags, cfg; double ms, flops; long n; };
+        std::vector<Agg> agg;
+        for (auto& r : g_prof) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, r.a, r.b);
+            Agg* hit = nullptr;
+            for (auto& a : agg)
+                if (a.M == r.M && a.N == r.N && a.K == r.K && a.ksize == r.ksize && a.flags == r.flags && a.cfg == r.cfg) hit = &a;
+            if (!hit) {
+                agg.push_back(Agg{r.M, r.N, r.K, r.ksize, r.flags, r.cfg, 0.0, 0.0, 0});
+                hit = &agg.back();
+            }
+            hit->ms += ms;
+            hit->flops += r.flops;
+            hit->n += 1;
+        }
+        if (FILE* f = fopen(path, "w")) {
+            double tot = 0.0;
+            for (auto& a : agg) tot += a.ms;
+            fprintf(f, "| M | N | K | ksize | flags(res1 gate2 pro4 act8) | cfg(0=128x32 1=128x64 2=128x128) | launches | total ms | share | avg us | TFLOP/s |\n|---|---|---|---|---|---|---|---|---|---|---|\n");
+            for (auto& a : agg)
+                fprintf(f, "| %d | %d | %d | %d | %d | %d | %ld | %.3f | %.3f | %.1f | %.1f |\n", a.M, a.N, a.K, a.ksize, a.flags, a.cfg, a.n, a.ms,
+                        a.ms / tot, 1e3 * a.ms / a.n, a.flops / (a.ms * 1e-3) / 1e12);
+            fclose(f);
+        }
     }
     return QA_OK;
 }
@@ -150,6 +185,85 @@ int qa_conv1d_cl(const qa_conv_args* args, void* stream) {
     ConvParams p;
     QA_TRY(conv_params_from_args(*args, &p));
     return launch_conv_gemm(p, static_cast<hipStream_t>(stream));
+}
+
+int qa_codes_check(const int64_t* codes, int64_t n, int64_t limit, int64_t* bad, void* stream) {
+    if (!codes || !bad) {
+        set_error("qa_codes_check: null argument");
+        return QA_ERR_INVALID;
+    }
+    QA_REQUIRE(n >= 0 && limit > 0, "qa_codes_check: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned long long* dev = nullptr;
+    QA_HIP(hipMallocAsync(reinterpret_cast<void**>(&dev), sizeof(unsigned long long), s));
+    int st = launch_codes_check(reinterpret_cast<const long long*>(codes), n, limit, dev, s);
+    unsigned long long host = 0;
+    hipError_t e = hipSuccess;
+    if (st == QA_OK) e = hipMemcpyAsync(&host, dev, sizeof(host), hipMemcpyDeviceToHost, s);
+    if (st == QA_OK && e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFreeAsync(dev, s);
+    if (st != QA_OK) return st;
+    QA_HIP(e);
+    *bad = (int64_t)host;
+    return QA_OK;
+}
+
+// torchaudio.functional._get_sinc_resample_kernel (sinc_interp_hann, lowpass_filter_width = 6, rolloff = 0.99; index arithmetic in
+// double, kernel stored as fp32 - what transforms.Resample precomputes) for the reduced ratio orig / new
+static void resample_taps(int orig, int nw, std::vector<float>* taps, int* width_out) {
+    const double lpw = 6.0, rolloff = 0.99, pi = 3.14159265358979323846;
+    const double base = std::min(orig, nw) * rolloff;
+    const int width = (int)std::ceil(lpw * orig / base);
+    const int kt = 2 * width + orig;
+    taps->assign((size_t)nw * kt, 0.f);
+    const double scale = base / orig;
+    for (int i = 0; i < nw; ++i)
+        for (int j = 0; j < kt; ++j) {
+            double t = ((double)(-i) / nw + (double)(j - width) / orig) * base;
+            t = std::max(-lpw, std::min(lpw, t));
+            const double c = std::cos(t * pi / lpw / 2.0);
+            const double window = c * c;
+            const double tp = t * pi;
+            const double sinc = tp == 0.0 ? 1.0 : std::sin(tp) / tp;
+            (*taps)[(size_t)i * kt + j] = (float)(sinc * window * scale);
+        }
+    *width_out = width;
+}
+static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
+
+int64_t qa_resample_length(int64_t T, int32_t orig_freq, int32_t new_freq) {
+    if (T < 0 || orig_freq <= 0 || new_freq <= 0) return QA_ERR_INVALID;
+    const int g = gcd_i(orig_freq, new_freq);
+    const int64_t o = orig_freq / g, n = new_freq / g;
+    return (n * T + o - 1) / o;
+}
+
+int qa_resample(const float* wav, int64_t B, int64_t T, int32_t orig_freq, int32_t new_freq, float* out, void* stream) {
+    if (!wav || !out) {
+        set_error("qa_resample: null argument");
+        return QA_ERR_INVALID;
+    }
+    QA_REQUIRE(B > 0 && T > 0 && orig_freq > 0 && new_freq > 0, "qa_resample: bad argument");
+    const int g = gcd_i(orig_freq, new_freq);
+    const int orig = orig_freq / g, nw = new_freq / g;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (orig == nw) {
+        QA_HIP(hipMemcpyAsync(out, wav, sizeof(float) * (size_t)B * T, hipMemcpyDeviceToDevice, s));
+        return QA_OK;
+    }
+    std::vector<float> taps;
+    int width = 0;
+    resample_taps(orig, nw, &taps, &width);
+    float* dev = nullptr;
+    QA_HIP(hipMallocAsync(reinterpret_cast<void**>(&dev), taps.size() * sizeof(float), s));
+    hipError_t e = hipMemcpyAsync(dev, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice, s);
+    int st = QA_OK;
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // `taps` is a stack-lifetime host buffer
+    if (e == hipSuccess)
+        st = launch_resample(wav, dev, out, (int)B, T, qa_resample_length(T, orig_freq, new_freq), orig, nw, width, 2 * width + orig, s);
+    (void)hipFreeAsync(dev, s);
+    QA_HIP(e);
+    return st;
 }
 
 }  // extern "C"

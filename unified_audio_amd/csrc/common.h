@@ -110,7 +110,7 @@ struct ConvParams {
 enum { PROF_CFG_128x32 = 0, PROF_CFG_128x64 = 1, PROF_CFG_128x128 = 2, PROF_NCFG = 3 };
 bool profile_enabled();
 bool serial_mode();  // qa_set_serial / QA_SERIAL=1: no internal stream concurrency (every kernel alone on the device)
-void profile_record_begin(int cfg, double flops, double bytes, hipStream_t s);
+void profile_record_begin(int cfg, double flops, double bytes, hipStream_t s, const ConvParams* p = nullptr);
 void profile_record_end(hipStream_t s);
 
 int launch_conv_gemm(const ConvParams& p, hipStream_t stream);

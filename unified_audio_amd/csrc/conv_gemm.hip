@@ -327,7 +327,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
         const double n = p.algo_n ? p.algo_n : p.N, k = p.algo_k ? p.algo_k : p.K;
         // algorithmic bytes: every input frame, weight and output element once (+ fused residual / gate reads)
         const double elems = (double)p.B * p.T_in * p.C_in + n * k + (double)p.M * n * (1.0 + (p.res ? 1.0 : 0.0) + (p.gate ? 1.0 : 0.0));
-        profile_record_begin(cfg, 2.0 * (double)p.M * n * k, 4.0 * elems, stream);
+        profile_record_begin(cfg, 2.0 * (double)p.M * n * k, 4.0 * elems, stream, &p);
     }
     // BK = 16 chunks need 45 KB / 35 KB of LDS, so 3-4 workgroups are co-resident per CU (BK = 32: 2) and cover each
     // other's barriers, prologues and epilogues: +10..25 % on the K = 512 layers of the aggregator stacks, +3..5 % on

@@ -706,4 +706,64 @@ int launch_deaggregate(const long long* codes, const long long* len_codes, long 
     return QA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// number of codes outside [0, limit): what F.embedding would refuse (Codec.decode, vq/codec.py:183-184)
+__global__ __launch_bounds__(256) void codes_check_kernel(const long long* __restrict__ codes, long long n, long long limit,
+                                                          unsigned long long* __restrict__ bad) {
+    unsigned long long local = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long c = codes[i];
+        local += (c < 0 || c >= limit) ? 1ull : 0ull;
+    }
+    local += __shfl_xor(local, 32, 64);
+    local += __shfl_xor(local, 16, 64);
+    local += __shfl_xor(local, 8, 64);
+    local += __shfl_xor(local, 4, 64);
+    local += __shfl_xor(local, 2, 64);
+    local += __shfl_xor(local, 1, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(bad, local);  // integer count: order-independent
+}
+int launch_codes_check(const long long* codes, long long n, long long limit, unsigned long long* bad, hipStream_t s) {
+    QA_HIP(hipMemsetAsync(bad, 0, sizeof(unsigned long long), s));
+    if (n <= 0) return QA_OK;
+    const unsigned grid = (unsigned)std::min<long long>(ceil_div(n, 256), 1024);
+    hipLaunchKernelGGL(codes_check_kernel, dim3(grid), dim3(256), 0, s, codes, n, limit, bad);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+// torchaudio.functional.resample's polyphase FIR (transforms.Resample, HCodec-2.0/audio_tokenizer.py:44,51):
+//   out[b, q * new + i] = sum_j kernel[i][j] * padded[b, q * orig + j],  padded = wav with `width` zeros in front and
+//   width + orig behind, kernel [new][2 * width + orig]; the output is cut to ceil(new * T / orig) samples.
+// HBM-bound (one read of the waveform, 1/3 of it written for 48 -> 16 kHz): one thread per output sample, taps from LDS.
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ wav, const float* __restrict__ taps, float* __restrict__ out,
+                                                       long long T, long long T_out, int orig, int nw, int width, int ktaps) {
+    extern __shared__ float s_taps[];
+    for (int i = threadIdx.x; i < nw * ktaps; i += 256) s_taps[i] = taps[i];
+    __syncthreads();
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= T_out) return;
+    const int b = blockIdx.y;
+    const long long q = o / nw;
+    const int ph = (int)(o - q * nw);
+    const float* x = wav + (long long)b * T;
+    const float* k = s_taps + ph * ktaps;
+    const long long base = q * orig - width;
+    float acc = 0.f;
+    for (int j = 0; j < ktaps; ++j) {
+        const long long t = base + j;
+        const float v = (t >= 0 && t < T) ? x[t] : 0.f;
+        acc = fmaf(k[j], v, acc);
+    }
+    out[(long long)b * T_out + o] = acc;
+}
+int launch_resample(const float* wav, const float* taps, float* out, int B, long long T, long long T_out, int orig, int nw, int width,
+                    int ktaps, hipStream_t s) {
+    QA_REQUIRE((size_t)nw * ktaps * sizeof(float) <= 64 * 1024, "resample: %d x %d taps do not fit in LDS", nw, ktaps);
+    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)ceil_div(T_out, 256), (unsigned)B), dim3(256), (size_t)nw * ktaps * sizeof(float), s, wav,
+                       taps, out, T, T_out, orig, nw, width, ktaps);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
 }  // namespace qa

@@ -697,7 +697,7 @@ int read_scalar(Ctx& c, qa_hcodec* h, const int* dev, int* out) {
 }
 
 int encode_adaptive_graph(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const float* feat, int64_t fsb, int64_t fsc,
-                          int64_t fst, int n_feat, long long* ac_out, long long* sc_out, int* G_out) {
+                          int64_t fst, int n_feat, long long* ac_out, long long* sc_out, int* G_out, float threshold) {
     const qa_hcodec_spec& sp = h->spec;
     const int D = sp.code_dim, Q = sp.num_quantizers;
     float *emb = nullptr, *sem = nullptr;
@@ -710,7 +710,7 @@ int encode_adaptive_graph(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, 
     int* gmax = c.arena.alloc<int>(1);
     int G = N;  // planning pass: worst case, every frame its own group
     if (!c.dry) {
-        QA_TRY(launch_align(sem, B, N, D, sp.threshold, sp.max_tokens_per_group, seg, start, len, nseg, gmax, c.stream));
+        QA_TRY(launch_align(sem, B, N, D, threshold, sp.max_tokens_per_group, seg, start, len, nseg, gmax, c.stream));
         QA_TRY(read_scalar(c, h, gmax, &G));
         QA_REQUIRE(G >= 1 && G <= N, "encode: alignment produced %d groups for %d frames", G, N);
     }
@@ -1084,7 +1084,7 @@ int qa_hcodec_decode(qa_hcodec* h, const int64_t* ac, const int64_t* sc, int64_t
 }
 
 int qa_hcodec_encode_adaptive(qa_hcodec* h, const float* wav, int64_t B, int64_t T, const float* feat, int64_t fsb, int64_t fsc,
-                              int64_t fst, int64_t n_feat, int64_t* ac, int64_t* sc, int64_t* n_groups, void* stream) {
+                              int64_t fst, int64_t n_feat, int64_t* ac, int64_t* sc, int64_t* n_groups, float threshold, void* stream) {
     if (!h || !wav || !feat || !ac || !sc || !n_groups) {
         set_error("qa_hcodec_encode_adaptive: null argument");
         return QA_ERR_INVALID;
@@ -1095,18 +1095,20 @@ int qa_hcodec_encode_adaptive(qa_hcodec* h, const float* wav, int64_t B, int64_t
     QA_REQUIRE(B > 0 && T > 0 && T % hop == 0, "qa_hcodec_encode_adaptive: wav is [%lld, %lld]; T must be a positive multiple of %d",
                (long long)B, (long long)T, hop);
     QA_REQUIRE(B * T < (1LL << 31), "qa_hcodec_encode_adaptive: batch too large");
+    QA_REQUIRE(threshold >= 0.f && threshold <= 1.f, "qa_hcodec_encode_adaptive: threshold %g outside [0, 1] (codec_adaptive.py:151)", threshold);
+    const float thr = threshold <= 0.f ? h->spec.threshold : threshold;  // codec_adaptive.py:158
     QA_HIP(hipSetDevice(h->device));
     Ctx& c = h->ctx;
     c.stream = static_cast<hipStream_t>(stream);
     c.dry = true;
     c.arena.begin(nullptr, 0);
     int G = 0;
-    QA_TRY(encode_adaptive_graph(h, c, wav, (int)B, (int)T, feat, fsb, fsc, fst, (int)n_feat, (long long*)ac, (long long*)sc, &G));
+    QA_TRY(encode_adaptive_graph(h, c, wav, (int)B, (int)T, feat, fsb, fsc, fst, (int)n_feat, (long long*)ac, (long long*)sc, &G, thr));
     QA_TRY(ensure_workspace(h, c.arena.peak()));
     c.dry = false;
     c.taps.clear();
     c.arena.begin(h->ws, h->ws_cap);
-    QA_TRY(encode_adaptive_graph(h, c, wav, (int)B, (int)T, feat, fsb, fsc, fst, (int)n_feat, (long long*)ac, (long long*)sc, &G));
+    QA_TRY(encode_adaptive_graph(h, c, wav, (int)B, (int)T, feat, fsb, fsc, fst, (int)n_feat, (long long*)ac, (long long*)sc, &G, thr));
     *n_groups = G;
     return QA_OK;
 }

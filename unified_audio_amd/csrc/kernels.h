@@ -38,6 +38,10 @@ int launch_stft_post(const float* ri, float* out, long long rows, int nb, int ld
 int launch_istft_spec(const float* y, float* S, long long rows, int nb, int ldy, int ldS, hipStream_t s);
 int launch_istft_ola(const float* frames, const float* win, float* out, int B, int T, int n_fft, int hop, hipStream_t s);
 
+int launch_codes_check(const long long* codes, long long n, long long limit, unsigned long long* bad, hipStream_t s);
+int launch_resample(const float* wav, const float* taps, float* out, int B, long long T, long long T_out, int orig, int nw, int width,
+                    int ktaps, hipStream_t s);
+
 // attention.hip : softmax(Q K^T * scale) V over a fused [B*N, 3*H*hd] QKV buffer (RoPE already applied)
 //   causal = 0: full attention over the N keys of the same batch item (codec transformers)
 //   causal = 1: key j visible to query i iff j <= i + (n_keys - n_q) (LM prefill / decode over a KV cache)

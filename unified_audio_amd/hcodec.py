@@ -102,23 +102,68 @@ def _stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-class Codec:
+def _spec_from_config(config: dict, device=None) -> HCodecSpec:
+    """HCodecSpec from the reference's YAML dictionaries: HCodec-1.5/conf/config_adaptive_v3.yaml (keys encoder_config /
+    decoder_config / quantizer_config / adaptive_config) or HCodec-2.0/conf/large_12.5hz_config.yaml (encoder_config with
+    n_fft / target_frame_rate, semantic_encoder_config)."""
+    enc, dec, qz = config["encoder_config"], config["decoder_config"], config["quantizer_config"]
+    if "adaptive_config" in config:  # H-Codec 1.5
+        e, se, d, q, ad = enc["encoder"], enc["semantic_encoder"], dec["decoder"], qz["quantizer"], config["adaptive_config"]
+        agg, tk = ad["aggregators"]["semantic_aggregator"], ad["transformer_kwargs"]
+        thr = ad.get("manual_threshold")
+        return HCodecSpec(n_filters=e["n_filters"], ratios=tuple(reversed(e["ratios"])), dimension=e["dimension"],
+                          sem_in=se["input_channels"], sem_ch=se["encode_channels"], sem_strides=tuple(se["strides"]),
+                          code_dim=q["dim"], codebook_size=q["codebook_size"], num_quantizers=q["num_quantizers"],
+                          dec_dim=d["dim"], dec_inter=d["intermediate_dim"], adaptive=True, agg_layers=agg["num_layers"],
+                          agg_heads=agg["num_heads"], agg_ff=agg["dim_feedforward"], bt_layers=tk["num_layers"],
+                          bt_heads=tk["num_heads"], bt_ff=tk["dim_feedforward"],
+                          threshold=float(thr if thr is not None else ad["similarity_threshold"]),
+                          max_tokens_per_group=ad["max_tokens_per_group"])
+    se = config["semantic_encoder_config"]  # H-Codec 2.0
+    stride = int(50 / enc["target_frame_rate"])
+    return HCodecSpec(version=20, enc_dim=enc["dim"], enc_inter=enc["intermediate_dim"], enc_convnext_layers=enc["convnext_layers"],
+                      enc_layers=enc["transformer_layers"], frame_stride=stride, tr_inter_cap=4096, dimension=enc["dimension"],
+                      sem_in=se["input_channels"], sem_ch=se["encode_channels"], sem_strides=tuple(se["strides"]),
+                      code_dim=qz["dim"], codebook_size=qz["codebook_size"], num_quantizers=qz["num_quantizers"],
+                      dec_dim=dec["dim"], dec_inter=dec["intermediate_dim"], dec_heads=dec["dim"] // 64,
+                      dec_layers=dec["transformer_layers"], convnext_layers=dec["convnext_layers"], n_fft=enc["n_fft"],
+                      hop=enc["hop_length"])
+
+
+class Codec(torch.nn.Module):
     """Drop-in for `vq.Codec` on the inference path: `encode(x, feat)` / `decode(acoustic_codes, semantic_codes)`.
 
-    The constructor signature keeps the reference's three (ignored) kwargs dicts (codec.py:22-27); weights come
-    through `load_state_dict` in the reference's own key layout (weight_g / weight_v, `layers.{q}._codebook.embed`).
+    The constructor keeps the reference's positional kwargs dicts (1.0: codec.py:22-27, ignored - the architecture is hard-coded
+    there; 1.5: encoder / decoder / quantizer / adaptive configs; 2.0: + semantic encoder / decoder configs): when the YAML
+    dictionaries are given the architecture is read from them, otherwise from `spec`.  Weights come through `load_state_dict`
+    in the reference's own key layout (weight_g / weight_v, `layers.{q}._codebook.embed`).  It is an `nn.Module` without
+    parameters of its own (the folded weights live in the library's device blob): `.eval()`, `.requires_grad_()`,
+    `.to(device)` / `.cuda()` work as for the reference module - moving to another GPU re-creates the handle there from the
+    state_dict it was loaded with - and `.train()` / `.half()` raise: this is the fp32 inference path.
     """
 
     def __init__(self, encoder_kwargs=None, decoder_kwargs=None, quantizer_kwargs=None, adaptive_kwargs=None,
-                 semantic_decoder_kwargs=None, *, spec: HCodecSpec = SPEC_10,
-                 device: str | torch.device = "cuda:0"):
+                 semantic_decoder_kwargs=None, *, spec: Optional[HCodecSpec] = None,
+                 device: str | torch.device = "cuda:0", check_codes: bool = True):
+        super().__init__()
+        if spec is None:
+            if isinstance(encoder_kwargs, dict) and isinstance(adaptive_kwargs, dict) and "aggregators" in adaptive_kwargs:
+                spec = _spec_from_config({"encoder_config": encoder_kwargs, "decoder_config": decoder_kwargs,
+                                          "quantizer_config": quantizer_kwargs, "adaptive_config": adaptive_kwargs})
+            elif isinstance(encoder_kwargs, dict) and "n_fft" in encoder_kwargs:  # 2.0: Codec(enc, dec, quant, sem_enc, sem_dec)
+                spec = _spec_from_config({"encoder_config": encoder_kwargs, "decoder_config": decoder_kwargs,
+                                          "quantizer_config": quantizer_kwargs, "semantic_encoder_config": adaptive_kwargs})
+            else:
+                spec = SPEC_10
         self.spec = spec
         self.device = torch.device(device)
+        self.check_codes = check_codes  # decode(): refuse out-of-range codes like F.embedding (one tiny kernel + one sync)
         self._handle = C.c_void_p()
         self._lib = _lib.load_library()
+        self._state = None
 
     # -- weights -------------------------------------------------------------------------------------
-    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True, assign: bool = False):
         _lib.require_device()
         if self.device.type != "cuda":
             raise _lib.QuarkAudioError(-1, f"Codec lives on a HIP device, got {self.device}")
@@ -129,15 +174,58 @@ class Codec:
         _lib.check(self._lib.qa_hcodec_create(C.byref(handle), C.byref(spec_c), table, n, self.device.index or 0))
         del keep
         self._handle = handle
+        self._state = state_dict  # a reference, not a copy: lets .to(other_gpu) rebuild the handle there
         return self
 
-    def eval(self):
+    def state_dict(self, *args, destination=None, prefix: str = "", keep_vars: bool = False):
+        """The state_dict this handle was loaded with (reference key layout)."""
+        out = destination if destination is not None else {}
+        for k, v in (self._state or {}).items():
+            out[prefix + k] = v
+        return out
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise _lib.QuarkAudioError(-4, "unified_audio_amd.Codec is the inference path (the reference calls .eval(), audio_tokenizer.py:26)")
         return self
 
-    def to(self, device):
-        if torch.device(device) != self.device:
-            raise _lib.QuarkAudioError(-4, "move the handle by constructing Codec(device=...) and reloading the weights")
+    def to(self, *args, **kwargs):
+        device = kwargs.get("device")
+        dtype = kwargs.get("dtype")
+        for a in args:
+            if isinstance(a, (str, torch.device, int)):
+                device = a
+            elif isinstance(a, torch.dtype):
+                dtype = a
+        if dtype is not None and dtype != torch.float32:
+            raise _lib.QuarkAudioError(-4, f"the path computes in fp32 like the reference; {dtype} is not supported")
+        if device is None:
+            return self
+        device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        if device.type != "cuda":
+            raise _lib.QuarkAudioError(-1, f"there is no CPU path: Codec cannot move to {device}")
+        if device != self.device:
+            self.device = device
+            if self._state is not None:
+                self.load_state_dict(self._state)
         return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", device if device is not None else (self.device.index or 0)))
+
+    def cpu(self):
+        raise _lib.QuarkAudioError(-1, "there is no CPU path")
+
+    def half(self):
+        return self.to(torch.float16)
+
+    def float(self):
+        return self
+
+    def forward(self, *args, **kwargs):
+        raise _lib.QuarkAudioError(-4, "Codec.forward is the training forward of the reference; use encode() / decode()")
 
     def _free(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
@@ -153,6 +241,17 @@ class Codec:
     def _require_loaded(self):
         if not self._handle.value:
             raise _lib.QuarkAudioError(-3, "Codec has no weights: call load_state_dict first")
+
+    def _check_range(self, tensors, limit: int):
+        """F.embedding's range check (reference: IndexError on the host, device-side assert on a GPU) with ONE host sync for all
+        code tensors of a decode call; `check_codes=False` skips it (the kernels clamp indices for memory safety)."""
+        if not self.check_codes:
+            return
+        flat = torch.cat([t.reshape(-1) for t in tensors]) if len(tensors) > 1 else tensors[0].reshape(-1)
+        bad = C.c_int64(0)
+        _lib.check(self._lib.qa_codes_check(flat.data_ptr(), flat.numel(), limit, C.byref(bad), _stream_ptr(self.device)))
+        if bad.value:
+            raise IndexError(f"{bad.value} code indices out of range [0, {limit})")
 
     # -- hot path ------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -176,12 +275,11 @@ class Codec:
         if self.spec.adaptive:
             # codec_adaptive.py:150-178: dict of length-injected codes [B, nq, G]; G is data dependent (host sync, as in the
             # reference: modeling_flexicodec_new.py:910)
-            if threshold != 0.0:
-                raise _lib.QuarkAudioError(-4, "per-call threshold is fixed at load time: set HCodecSpec.threshold")
+            assert 0 <= threshold <= 1.0  # codec_adaptive.py:151; 0 = the model's manual_threshold (:158)
             g = C.c_int64(0)
             _lib.check(self._lib.qa_hcodec_encode_adaptive(self._handle, x.data_ptr(), B, T, feat.data_ptr(), sb, sch, st,
                                                            feat.shape[2], ac.data_ptr(), sc.data_ptr(), C.byref(g),
-                                                           _stream_ptr(self.device)))
+                                                           float(threshold), _stream_ptr(self.device)))
             G = int(g.value)
             return {"acoustic_codes": ac.view(-1)[: B * q * G].view(B, q, G), "semantic_codes": sc.view(-1)[: B * q * G].view(B, q, G)}
         _lib.check(self._lib.qa_hcodec_encode(self._handle, x.data_ptr(), B, T, feat.data_ptr(), sb, sch, st,
@@ -201,9 +299,7 @@ class Codec:
                                            f"{tuple(acoustic_codes.shape)} / {tuple(semantic_codes.shape)}")
         ac = acoustic_codes.to(device=self.device, dtype=torch.int64).contiguous()
         sc = semantic_codes.to(device=self.device, dtype=torch.int64).contiguous()
-        for name, c in (("acoustic_codes", ac), ("semantic_codes", sc)):
-            if c.numel() and (int(c.min()) < 0 or int(c.max()) >= self.spec.codebook_size):
-                raise IndexError(f"{name} out of range [0, {self.spec.codebook_size})")  # reference: F.embedding raises
+        self._check_range((ac, sc), self.spec.codebook_size)
         B, _, N = ac.shape
         wav = torch.empty((B, N * self.spec.dec_upsample * self.spec.hop), dtype=torch.float32, device=self.device)
         _lib.check(self._lib.qa_hcodec_decode(self._handle, ac.data_ptr(), sc.data_ptr(), B, N, wav.data_ptr(),
@@ -226,6 +322,7 @@ class Codec:
             tl = token_lengths.to(device=self.device, dtype=torch.int64).unsqueeze(1)
             ac, sc = (tl - 1) * K + ac, (tl - 1) * K + sc
         B, _, G = ac.shape
+        self._check_range((ac, sc), K * self.spec.max_tokens_per_group)  # length-injected: code + (len - 1) * K
         frames = C.c_int64(0)
         _lib.check(self._lib.qa_hcodec_adaptive_frames(self._handle, sc.data_ptr(), B, G, C.byref(frames), _stream_ptr(self.device)))
         n = int(frames.value)
@@ -246,51 +343,119 @@ class Codec:
         return out
 
 
-class HCodecTokenizer:
-    """Drop-in for the reference's HCodecTokenizer (audio_tokenizer.py:18-66).
+class HCodecTokenizer(torch.nn.Module):
+    """Drop-in for the reference's three HCodecTokenizer classes, with their constructor signatures:
 
-    `feature_extractor`: either a `unified_audio_amd.SSLFeatureExtractor` (the HuBERT / XLSR front-end on the same HIP
-    library: `tokenize(wav)` then never leaves the device path), or the reference's PyTorch module
-    (`feature_extractor(wav[B,T+320], output_hidden_states=True).hidden_states`); or pass precomputed features to
-    `tokenize(wav, feats=...)`.
+        HCodecTokenizer(pt_path)                                   H-Codec 1.0   HCodec-1.0/audio_tokenizer.py:18-33
+        HCodecTokenizer(config=dict)   (config['ckpt_path'], ...)  H-Codec 1.5   HCodec-1.5/audio_tokenizer.py:38-51
+        HCodecTokenizer(pt_path, config_path, device)              H-Codec 2.0   HCodec-2.0/audio_tokenizer.py:19-46
+
+    plus keyword-only extras: `state_dict=` (instead of a checkpoint path), `spec=` (instead of a YAML config),
+    `feature_extractor=`.  The reference downloads its SSL model (`AutoModel.from_pretrained`: hubert_base / XLSR-53); there is
+    no network here, so the front-end is passed in: a `unified_audio_amd.SSLFeatureExtractor` (HuBERT / XLSR on the same HIP
+    library - `tokenize(wav)` then never leaves the device path), or the reference's own PyTorch module
+    (`feature_extractor(wav, output_hidden_states=True).hidden_states`), or precomputed features via `tokenize(wav, feats=...)`.
+    Per version the tokenizer applies what the reference applies around it: mean of all hidden states (1.0, 2.0) or of states
+    11 / 14 / 16 (1.5), |x|^0.3 compression, and for 2.0 the 48 kHz -> 16 kHz `Resample` in front (qa_resample).
     """
 
-    def __init__(self, pt_path=None, *, state_dict=None, feature_extractor: Optional[Callable] = None,
-                 device: str | torch.device = "cuda:0", spec: HCodecSpec = SPEC_10, **kwargs):
+    def __init__(self, pt_path=None, config_path=None, device: str | torch.device = "cuda:0", *, config: Optional[dict] = None,
+                 state_dict=None, feature_extractor: Optional[Callable] = None, spec: Optional[HCodecSpec] = None, **kwargs):
+        super().__init__()
+        self.config = config
+        sampling_rate = 16000
+        if config is None and config_path is not None:  # 2.0: YAML path
+            import yaml
+
+            with open(config_path, "r") as f:
+                config = yaml.safe_load(f)
+        if spec is None and config is not None:
+            spec = _spec_from_config(config)
+        if config is not None:
+            sampling_rate = int(config.get("sampling_rate", 16000))
+            if pt_path is None:
+                pt_path = config.get("ckpt_path")  # 1.5: load_sub_weights(config['ckpt_path'], prefix=None)
+        spec = spec or SPEC_10
+        if spec.version == 20 and sampling_rate == 16000:
+            sampling_rate = 48000  # large_12.5hz_config.yaml:1
         if state_dict is None:
             if pt_path is None:
-                raise ValueError("HCodecTokenizer needs pt_path or state_dict")
+                raise ValueError("HCodecTokenizer needs pt_path, config['ckpt_path'] or state_dict")
             state_dict = torch.load(pt_path, map_location="cpu")  # audio_tokenizer.py:24
-        self.model = Codec(None, None, None, spec=spec, device=device).load_state_dict(state_dict)
+            if isinstance(state_dict, dict) and "state_dict" in state_dict:  # HCodec-1.5/audio_tokenizer.py:20-25
+                state_dict = state_dict["state_dict"]
+        self.device = torch.device(device) if str(device) != "cpu" else torch.device("cuda:0")  # 2.0's default device='cpu': no CPU path
+        self.model = Codec(None, None, None, spec=spec, device=self.device).load_state_dict(state_dict)
         self.feature_extractor = feature_extractor
-        self.hop_length = spec.enc_hop  # 640 = 25 Hz (audio_tokenizer.py:31)
-        self.device = torch.device(device)
+        self.sampling_rate = sampling_rate
+        self.hop_length = spec.enc_hop  # 640 = 25 Hz (audio_tokenizer.py:31); 3840 = 12.5 Hz at 48 kHz (2.0 :46)
+        # hidden states averaged by extract_wav2vec2_features when the extractor is the reference's own PyTorch module
+        self.select_layers = (11, 14, 16) if spec.adaptive else None  # HCodec-1.5/audio_tokenizer.py:58-61
+
+    def to(self, *args, **kwargs):
+        self.model.to(*args, **kwargs)
+        self.device = self.model.device
+        fx = self.feature_extractor
+        if fx is not None and hasattr(fx, "to"):
+            self.feature_extractor = fx.to(self.device) or fx
+        return self
+
+    def train(self, mode: bool = True):
+        self.model.train(mode)
+        return self
+
+    def resample(self, wavs: torch.Tensor) -> torch.Tensor:
+        """torchaudio.transforms.Resample(sampling_rate, 16000) (HCodec-2.0/audio_tokenizer.py:44,51) on the device."""
+        if self.sampling_rate == 16000:
+            return wavs
+        x = wavs.to(device=self.device, dtype=torch.float32).contiguous()
+        B, T = x.shape
+        n = int(self.model._lib.qa_resample_length(T, self.sampling_rate, 16000))
+        out = torch.empty((B, n), dtype=torch.float32, device=self.device)
+        _lib.check(self.model._lib.qa_resample(x.data_ptr(), B, T, self.sampling_rate, 16000, out.data_ptr(), _stream_ptr(self.device)))
+        return out
 
     @torch.no_grad()
     def extract_wav2vec2_features(self, wavs: torch.Tensor) -> torch.Tensor:
-        """audio_tokenizer.py:35-48: pad (160,160), mean of all hidden states, sign*|x|^0.3 compression."""
+        """1.0: audio_tokenizer.py:35-48 (pad (160,160), mean of all hidden states, sign*|x|^0.3); 1.5: hidden states 11 / 14 / 16
+        (HCodec-1.5/audio_tokenizer.py:53-67); 2.0 (`extract_ssl_features`): Resample first (HCodec-2.0/audio_tokenizer.py:48-64)."""
         if self.feature_extractor is None:
             raise _lib.QuarkAudioError(-3, "no feature_extractor was given; pass feats= to tokenize()")
         from .ssl import SSLFeatureExtractor
 
+        wavs = self.resample(wavs)
         if isinstance(self.feature_extractor, SSLFeatureExtractor):  # padding, averaging and compression happen in the library
-            return self.feature_extractor(wavs)
+            fx = self.feature_extractor
+            want = tuple(self.select_layers or ())
+            have = tuple(fx.spec.select or ())
+            if want != have:
+                raise _lib.QuarkAudioError(-1, f"this tokenizer averages hidden states {want or 'all'} but the SSLFeatureExtractor was built "
+                                               f"with select={have or 'all'} (H-Codec 1.5 needs SPEC_XLSR53, 1.0 / 2.0 SPEC_HUBERT_BASE)")
+            return fx(wavs)
         wavs = torch.nn.functional.pad(wavs, (160, 160))
         feats = self.feature_extractor(wavs, output_hidden_states=True)
-        feats_mix = torch.stack(feats.hidden_states, dim=1).mean(1)
+        hs = feats.hidden_states
+        if self.select_layers is not None:
+            feats_mix = sum(hs[i] for i in self.select_layers) / len(self.select_layers)
+        else:
+            feats_mix = torch.stack(hs, dim=1).mean(1)
         symbol = (feats_mix > 0).float() * 2 - 1
         return symbol * feats_mix.abs() ** 0.3
+
+    extract_ssl_features = extract_wav2vec2_features  # the 2.0 tokenizer's name for it
 
     def pad_wav(self, wav: torch.Tensor) -> torch.Tensor:
         pad = math.ceil(wav.size(-1) / self.hop_length) * self.hop_length - wav.size(-1)
         return torch.nn.functional.pad(wav, (0, pad))
 
     @torch.no_grad()
-    def tokenize(self, wav: torch.Tensor, feats: Optional[torch.Tensor] = None):
+    def tokenize(self, wav: torch.Tensor, feats: Optional[torch.Tensor] = None, threshold: float = 0.0):
         wav = self.pad_wav(wav.to(self.device))
         if feats is None:
             feats = self.extract_wav2vec2_features(wav)  # (b, t, d)
         feats = feats.to(self.device).transpose(-2, -1)  # (b, d, t) view; the library reads it through its strides
+        if self.model.spec.adaptive:
+            return self.model.encode(wav.unsqueeze(1), feats, threshold=threshold)
         return self.model.encode(wav.unsqueeze(1), feats)
 
     @torch.no_grad()
