@@ -100,13 +100,13 @@ def test_tokenizer_feature_path_is_the_same_for_both_extractor_kinds(qa_lib, gpu
     import unified_audio_amd as qa
 
     if version == "1.5":
-        ospec = S.SSLSpec(conv_dim=(32,) * 7, hidden_size=64, num_hidden_layers=17, num_attention_heads=2, intermediate_size=128,
+        ospec = S.SSLSpec(conv_dim=(32,) * 7, hidden_size=96, num_hidden_layers=17, num_attention_heads=3, intermediate_size=128,
                           num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=2, conv_bias=True, feat_extract_norm="layer",
                           do_stable_layer_norm=True, select=(11, 14, 16))
         kind, cspec = "wav2vec2", dataclasses.replace(R.HCodecSpec(**{**MINI, "sem_in": 64}), adaptive=True, agg_layers=1, bt_layers=1,
                                                      agg_heads=2, bt_heads=2, agg_ff=128, bt_ff=128)
     else:
-        ospec = S.SSLSpec(conv_dim=(32,) * 7, hidden_size=64, num_hidden_layers=3, num_attention_heads=2, intermediate_size=128,
+        ospec = S.SSLSpec(conv_dim=(32,) * 7, hidden_size=96, num_hidden_layers=3, num_attention_heads=3, intermediate_size=128,
                           num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=2)
         kind, cspec = "hubert", R.HCodecSpec(**MINI)
     ssl_sd = S.synth_state_dict(5, ospec, kind)
@@ -145,8 +145,9 @@ def test_hcodec20_tokenizer_resamples_before_the_ssl_model(qa_lib, gpu_device):
                           code_dim=o.dimension, sem_in=o.sem_in, sem_ch=o.sem_ch, sem_strides=o.sem_strides, codebook_size=o.codebook_size,
                           num_quantizers=o.num_quantizers, dec_dim=o.dec_dim, dec_inter=o.dec_inter, dec_heads=o.dec_dim // 64,
                           dec_layers=o.dec_transformer_layers, convnext_layers=o.dec_convnext_layers, n_fft=o.n_fft, hop=o.hop)
+    assert o.sem_in == 64  # one positional-conv group of 64 channels (the library supports 48- and 64-channel groups)
     ospec = S.SSLSpec(conv_dim=(32,) * 7, hidden_size=o.sem_in, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
-                      num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=2)
+                      num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=1)
     ssl_sd = S.synth_state_dict(5, ospec, "hubert")
     kw = {f: getattr(ospec, f) for f in ospec.__dataclass_fields__}
     fx = qa.SSLFeatureExtractor(qa.SSLSpec(**kw), device=gpu_device).load_state_dict(ssl_sd)

@@ -737,17 +737,20 @@ int launch_codes_check(const long long* codes, long long n, long long limit, uns
 //   width + orig behind, kernel [new][2 * width + orig]; the output is cut to ceil(new * T / orig) samples.
 // HBM-bound (one read of the waveform, 1/3 of it written for 48 -> 16 kHz): one thread per output sample, taps from LDS.
 __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ wav, const float* __restrict__ taps, float* __restrict__ out,
-                                                       long long T, long long T_out, int orig, int nw, int width, int ktaps) {
+                                                       long long T, long long T_out, int orig, int nw, int width, int ktaps,
+                                                       int use_lds) {
     extern __shared__ float s_taps[];
-    for (int i = threadIdx.x; i < nw * ktaps; i += 256) s_taps[i] = taps[i];
-    __syncthreads();
+    if (use_lds) {  // small filter banks (48 -> 16 kHz: 1 x 41 taps) live in LDS; large ones (44.1 -> 16 kHz: 160 x 475) stay in L2
+        for (int i = threadIdx.x; i < nw * ktaps; i += 256) s_taps[i] = taps[i];
+        __syncthreads();
+    }
     const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
     if (o >= T_out) return;
     const int b = blockIdx.y;
     const long long q = o / nw;
     const int ph = (int)(o - q * nw);
     const float* x = wav + (long long)b * T;
-    const float* k = s_taps + ph * ktaps;
+    const float* k = (use_lds ? s_taps : taps) + ph * ktaps;
     const long long base = q * orig - width;
     float acc = 0.f;
     for (int j = 0; j < ktaps; ++j) {
@@ -759,9 +762,10 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
 }
 int launch_resample(const float* wav, const float* taps, float* out, int B, long long T, long long T_out, int orig, int nw, int width,
                     int ktaps, hipStream_t s) {
-    QA_REQUIRE((size_t)nw * ktaps * sizeof(float) <= 64 * 1024, "resample: %d x %d taps do not fit in LDS", nw, ktaps);
-    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)ceil_div(T_out, 256), (unsigned)B), dim3(256), (size_t)nw * ktaps * sizeof(float), s, wav,
-                       taps, out, T, T_out, orig, nw, width, ktaps);
+    const size_t bytes = (size_t)nw * ktaps * sizeof(float);
+    const int use_lds = bytes <= 48 * 1024;
+    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)ceil_div(T_out, 256), (unsigned)B), dim3(256), use_lds ? bytes : 0, s, wav, taps, out, T,
+                       T_out, orig, nw, width, ktaps, use_lds);
     QA_LAUNCH_CHECK();
     return QA_OK;
 }

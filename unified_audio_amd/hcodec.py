@@ -242,16 +242,18 @@ class Codec(torch.nn.Module):
         if not self._handle.value:
             raise _lib.QuarkAudioError(-3, "Codec has no weights: call load_state_dict first")
 
-    def _check_range(self, tensors, limit: int):
+    def _check_range(self, tensors, limit: int, offset: int = 0):
         """F.embedding's range check (reference: IndexError on the host, device-side assert on a GPU) with ONE host sync for all
         code tensors of a decode call; `check_codes=False` skips it (the kernels clamp indices for memory safety)."""
         if not self.check_codes:
             return
         flat = torch.cat([t.reshape(-1) for t in tensors]) if len(tensors) > 1 else tensors[0].reshape(-1)
+        if offset:
+            flat = flat + offset
         bad = C.c_int64(0)
         _lib.check(self._lib.qa_codes_check(flat.data_ptr(), flat.numel(), limit, C.byref(bad), _stream_ptr(self.device)))
         if bad.value:
-            raise IndexError(f"{bad.value} code indices out of range [0, {limit})")
+            raise IndexError(f"{bad.value} code indices out of range [{-offset}, {limit - offset})")
 
     # -- hot path ------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -322,7 +324,8 @@ class Codec(torch.nn.Module):
             tl = token_lengths.to(device=self.device, dtype=torch.int64).unsqueeze(1)
             ac, sc = (tl - 1) * K + ac, (tl - 1) * K + sc
         B, _, G = ac.shape
-        self._check_range((ac, sc), K * self.spec.max_tokens_per_group)  # length-injected: code + (len - 1) * K
+        # length-injected: code + (len - 1) * K with len in 0..max_tokens (len 0 = the padding groups of shorter clips: [-K, 0))
+        self._check_range((ac, sc), K * (self.spec.max_tokens_per_group + 1), offset=K)
         frames = C.c_int64(0)
         _lib.check(self._lib.qa_hcodec_adaptive_frames(self._handle, sc.data_ptr(), B, G, C.byref(frames), _stream_ptr(self.device)))
         n = int(frames.value)
