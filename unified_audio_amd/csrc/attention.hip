@@ -74,21 +74,36 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const int n_tiles = last_key / 32 + 1;
     const int wave_last_key = causal ? min(n_keys - 1, min(q_blk0 + wave * 32 + 31, n_q - 1) + off) : n_keys - 1;
 
-    for (int kt = 0; kt < n_tiles; ++kt) {
-        __syncthreads();
-        // stage K / V tile (32 keys x HD), zero-filled past n_keys
-        for (int i = tid; i < 32 * (HD / 4); i += 256) {
+    // K / V tiles go global -> registers -> LDS; the loads of tile kt + 1 are issued right after tile kt is in LDS and stay in
+    // flight under its 64 MFMAs (the first version loaded synchronously: one exposed L2 / HBM round trip per 32 keys)
+    constexpr int NLD = HD / 32;  // float4 per thread per operand: 32 keys x HD floats over 256 threads
+    float4 kreg[NLD], vreg[NLD];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + 256 * j;
             const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
             const int key = kt * 32 + row;
-            float4 kk4 = make_float4(0.f, 0.f, 0.f, 0.f), vv4 = kk4;
-            if (key < n_keys) {
-                kk4 = *reinterpret_cast<const float4*>(kb + (long long)key * ldkv + c4);
-                vv4 = *reinterpret_cast<const float4*>(vb + (long long)key * ldkv + c4);
+            kreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vreg[j] = kreg[j];
+            if (key < n_keys) {  // zero-filled past n_keys
+                kreg[j] = *reinterpret_cast<const float4*>(kb + (long long)key * ldkv + c4);
+                vreg[j] = *reinterpret_cast<const float4*>(vb + (long long)key * ldkv + c4);
             }
-            *reinterpret_cast<float4*>(sK + row * LD + c4) = kk4;
-            *reinterpret_cast<float4*>(sV + row * LD + c4) = vv4;
+        }
+    };
+    fetch(0);
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        __syncthreads();  // the previous tile is no longer read
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + 256 * j;
+            const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
+            *reinterpret_cast<float4*>(sK + row * LD + c4) = kreg[j];
+            *reinterpret_cast<float4*>(sV + row * LD + c4) = vreg[j];
         }
         __syncthreads();
+        if (kt + 1 < n_tiles) fetch(kt + 1);
         if (kt * 32 > wave_last_key) continue;  // wave-uniform: whole tile masked for this wave
 
         // S^T = K Q^T

@@ -104,6 +104,10 @@ struct ConvParams {
     int in_rep;  // >1: the input is read as if every frame were repeated in_rep times (x.repeat_interleave, H-Codec 2.0 decoder)
     int vec_epi;  // epilogue may move float4 (set by launch_conv_gemm from N, leading dimensions and pointer alignment)
     unsigned rep_magic, rep_one;  // r / in_rep == __umulhi(r, rep_magic) + r * rep_one  (branch-free; set by launch_conv_gemm)
+    // fused interleaved-pair RoPE on output channels n < rope_n (the q and k parts of a fused QKV projection; mimi module/rope.py:13-69):
+    // (y[2i], y[2i+1]) <- (y[2i] c - y[2i+1] s, y[2i+1] c + y[2i] s) with (c, s) = rope[(t * rope_hd/2 + i) * 2 + {0,1}], t = m % rope_T, i = (n % rope_hd) / 2
+    const float* rope;
+    int rope_n, rope_hd, rope_T;
 };
 
 // Live measurement hook (bench.py): when enabled every conv_gemm launch is bracketed by HIP events on its own stream.

@@ -64,6 +64,12 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const ConvParams& p, long lo
         v.x = apply_act(v.x, p.post_act); v.y = apply_act(v.y, p.post_act); v.z = apply_act(v.z, p.post_act);
         v.w = apply_act(v.w, p.post_act);
     }
+    if (p.rope && n < p.rope_n) {  // interleaved pairs (2i, 2i+1): both members of a pair sit in this float4 (n % 4 == 0)
+        const int t = (int)(m % p.rope_T), i = (n % p.rope_hd) >> 1;
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope + ((long long)t * (p.rope_hd >> 1) + i) * 2);  // c_i, s_i, c_i+1, s_i+1
+        const f32x4 r = {v.x * cs.x - v.y * cs.y, v.y * cs.x + v.x * cs.y, v.z * cs.z - v.w * cs.w, v.w * cs.z + v.z * cs.w};
+        v = r;
+    }
     return v;
 }
 
@@ -377,6 +383,8 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
     q.rep_one = p.in_rep > 1 ? 0u : 1u;
     q.rep_magic = p.in_rep > 1 ? (unsigned)(((1ULL << 32) + p.in_rep - 1) / p.in_rep) : 0u;
     QA_REQUIRE(p.in_rep <= 1 || p.pad_mode == PAD_ZERO, "conv_gemm: in_rep needs zero padding");
+    QA_REQUIRE(!p.rope || (q.vec_epi && p.rope_hd % 4 == 0 && p.rope_n % 4 == 0 && p.rope_T > 0 && al16(p.rope)),
+               "conv_gemm: fused RoPE needs the float4 epilogue (N, strides, pointers multiples of 4 / 16 B)");
     int cfg;
     if (forced >= 0) cfg = forced;
     else if (p.N <= 32) cfg = PROF_CFG_128x32;

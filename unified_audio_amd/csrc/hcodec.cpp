@@ -306,7 +306,8 @@ void build_mimi(Builder& b, MimiW* mw, const std::string& p, int d, int n_layers
 
 int conv_op(Ctx& c, const float* x, int64_t ldx, int B, int T_in, const ConvW& w, float* y, int64_t ldy, int T_out,
             int stride, int pad_left, int pad_right, int pad_mode, int prologue, int act, const float* gamma,
-            const float* res, int64_t ldr, const float* gate, int post_act, int in_rep = 1) {
+            const float* res, int64_t ldr, const float* gate, int post_act, int in_rep = 1, const float* rope = nullptr,
+            int rope_n = 0, int rope_hd = 0, int rope_T = 0) {
     if (c.dry) return QA_OK;
     qa_conv_args a{};
     a.x = x; a.w = w.w; a.bias = w.b; a.gamma = gamma; a.residual = res; a.gate = gate; a.y = y;
@@ -319,6 +320,7 @@ int conv_op(Ctx& c, const float* x, int64_t ldx, int B, int T_in, const ConvW& w
     QA_TRY(conv_params_from_args(a, &p));
     p.algo_n = w.algo_n;
     p.algo_k = w.algo_cin ? w.algo_cin * w.ksize : 0;
+    p.rope = rope; p.rope_n = rope_n; p.rope_hd = rope_hd; p.rope_T = rope_T;
     return launch_conv_gemm(p, c.stream);
 }
 
@@ -399,8 +401,9 @@ int mimi_layer(Ctx& c, const MimiW& mw, const MimiLayerW& L, float* x, const Mim
     const int d = mw.d, H = mw.heads, hd = d / H;
     const int64_t rows = (int64_t)B * N;
     QA_TRY(launch_layernorm(x, L.n1w, L.n1b, t.hn, rows, d, 1e-5f, c.stream));
-    QA_TRY(linear_op(c, t.hn, rows, L.in_proj, t.qkv));
-    QA_TRY(launch_rope(t.qkv, mw.rope, B, N, H, hd, 3 * d, 0, c.stream, 1));
+    // fused QKV projection with the interleaved-pair RoPE of q and k applied in the GEMM epilogue (one launch less per layer)
+    QA_TRY(conv_op(c, t.hn, d, 1, (int)rows, L.in_proj, t.qkv, 3 * d, (int)rows, 1, 0, 0, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, nullptr,
+                   3 * d, nullptr, ACT_NONE, 1, mw.rope, 2 * d, hd, N));
     QA_TRY(launch_attention(t.qkv, 3 * d, t.qkv + d, t.qkv + 2 * d, 3 * d, t.att, d, B, N, N, (long long)N * 3 * d, H, hd,
                             1.0f / std::sqrt((float)hd), 0, c.stream));
     QA_TRY(linear_op(c, t.att, rows, L.out_proj, x, ACT_NONE, x, nullptr, L.ls1));

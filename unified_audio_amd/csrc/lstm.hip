@@ -130,22 +130,49 @@ static void launch_step(int ni, dim3 grid, hipStream_t s, const float* xw, const
 #undef QA_LS
 }
 
-static int lstm_launch_steps(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d, hipStream_t s) {
+// One chain of T dependent step launches for batch rows [0, bn) of the given buffers.
+static void lstm_chain(const float* xw_b, const float* w_hh_ug, float* h_b, float* c_b, int bn, int T, int d, int t, hipStream_t s) {
     const int ni = (d % 128 == 0) ? d / 128 : 0;
+    const int mt = (int)ceil_div(bn, 16);
+    const dim3 grid(d / 4);
+    switch (mt) {
+        case 1: launch_step<1>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
+        case 2: launch_step<2>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
+        case 3: launch_step<3>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
+        default: launch_step<4>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
+    }
+}
+
+// A step is latency-bound (kernel floor + one dependent round trip for h_{t-1}), not throughput-bound, and the batch rows are
+// independent recurrences: with QA_LSTM_SPLIT=1 the batch is cut in two halves whose step chains run concurrently on two streams
+// (fork / join with events), each step kernel carrying half the rows (MT = 1 instead of 2).  Measured on MI355X (H-Codec 1.5,
+// 32 x 10 s): the half-row kernels take 7.3 / 4.7 us (d = 1024 / 512) against 9.8 / 6.0 us for the whole batch - the two chains
+// overlap too little to pay for that (147.4 vs 144.9 ms per step), so one chain stays the default.
+static int lstm_launch_steps(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d, hipStream_t s,
+                             hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
+    static const bool split_ok = [] {
+        const char* e = std::getenv("QA_LSTM_SPLIT");
+        return e && e[0] == '1';
+    }();
     for (int b0 = 0; b0 < B; b0 += 64) {
         const int bn = std::min(64, B - b0);
         const float* xw_b = xw + (long long)b0 * T * 4 * d;
         float* h_b = h_out + (long long)b0 * T * d;
         float* c_b = c_state + (long long)b0 * d;
-        const int mt = (int)ceil_div(bn, 16);
-        const dim3 grid(d / 4);
+        const bool split = split_ok && side && bn >= 32;
+        const int h0 = split ? (bn / 2 + 15) / 16 * 16 : bn;  // first half, a whole number of 16-row tiles
+        if (split) {
+            QA_HIP(hipEventRecord(ev_fork, s));
+            QA_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+        }
         for (int t = 0; t < T; ++t) {
-            switch (mt) {
-                case 1: launch_step<1>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
-                case 2: launch_step<2>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
-                case 3: launch_step<3>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
-                default: launch_step<4>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
-            }
+            lstm_chain(xw_b, w_hh_ug, h_b, c_b, h0, T, d, t, s);
+            if (split)
+                lstm_chain(xw_b + (long long)h0 * T * 4 * d, w_hh_ug, h_b + (long long)h0 * T * d, c_b + (long long)h0 * d, bn - h0, T, d, t, side);
+        }
+        if (split) {
+            QA_HIP(hipEventRecord(ev_join, side));
+            QA_HIP(hipStreamWaitEvent(s, ev_join, 0));
         }
         QA_LAUNCH_CHECK();
     }
@@ -158,14 +185,15 @@ static int lstm_launch_steps(const float* xw, const float* w_hh_ug, float* h_out
 namespace {
 struct LstmGraph {
     const void *xw, *w, *h, *c;
-    int B, T, d, device;
+    int B, T, d, device, split;
     hipGraph_t graph;
     hipGraphExec_t exec;
     unsigned long long stamp;
 };
 std::mutex g_lstm_mu;
 std::vector<LstmGraph> g_lstm_graphs;
-hipStream_t g_lstm_cap[16] = {};
+hipStream_t g_lstm_cap[16] = {}, g_lstm_side[16] = {}, g_lstm_cap_side[16] = {};
+hipEvent_t g_lstm_ev[16][2] = {};
 unsigned long long g_lstm_clock = 0;
 constexpr size_t LSTM_GRAPH_CACHE = 24;
 }  // namespace
@@ -177,18 +205,29 @@ int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_st
         const char* e = std::getenv("QA_LSTM_GRAPH");
         return !(e && e[0] == '0');
     }();
-    if (!use_graph || T < 8) return lstm_launch_steps(xw, w_hh_ug, h_out, c_state, B, T, d, s);
     int dev = 0;
     QA_HIP(hipGetDevice(&dev));
+    QA_REQUIRE(dev >= 0 && dev < 16, "lstm: device index %d out of range", dev);
     std::lock_guard<std::mutex> lock(g_lstm_mu);
+    if (!g_lstm_side[dev]) {
+        QA_HIP(hipStreamCreateWithFlags(&g_lstm_side[dev], hipStreamNonBlocking));
+        QA_HIP(hipStreamCreateWithFlags(&g_lstm_cap_side[dev], hipStreamNonBlocking));
+        QA_HIP(hipEventCreateWithFlags(&g_lstm_ev[dev][0], hipEventDisableTiming));
+        QA_HIP(hipEventCreateWithFlags(&g_lstm_ev[dev][1], hipEventDisableTiming));
+    }
+    hipStream_t side = serial_mode() ? nullptr : g_lstm_side[dev];  // qa_set_serial(1): every kernel alone on the device
+    if (!use_graph || T < 8) return lstm_launch_steps(xw, w_hh_ug, h_out, c_state, B, T, d, s, side, g_lstm_ev[dev][0], g_lstm_ev[dev][1]);
     LstmGraph* hit = nullptr;
+    const int split_tag = side ? 1 : 0;
     for (LstmGraph& g : g_lstm_graphs)
-        if (g.xw == xw && g.w == w_hh_ug && g.h == h_out && g.c == c_state && g.B == B && g.T == T && g.d == d && g.device == dev) hit = &g;
+        if (g.xw == xw && g.w == w_hh_ug && g.h == h_out && g.c == c_state && g.B == B && g.T == T && g.d == d && g.device == dev &&
+            g.split == split_tag)
+            hit = &g;
     if (!hit) {
-        QA_REQUIRE(dev >= 0 && dev < 16, "lstm: device index %d out of range", dev);
         if (!g_lstm_cap[dev]) QA_HIP(hipStreamCreateWithFlags(&g_lstm_cap[dev], hipStreamNonBlocking));
         QA_HIP(hipStreamBeginCapture(g_lstm_cap[dev], hipStreamCaptureModeThreadLocal));
-        const int st = lstm_launch_steps(xw, w_hh_ug, h_out, c_state, B, T, d, g_lstm_cap[dev]);
+        const int st = lstm_launch_steps(xw, w_hh_ug, h_out, c_state, B, T, d, g_lstm_cap[dev], side ? g_lstm_cap_side[dev] : nullptr,
+                                         g_lstm_ev[dev][0], g_lstm_ev[dev][1]);
         hipGraph_t graph = nullptr;
         const hipError_t e = hipStreamEndCapture(g_lstm_cap[dev], &graph);
         if (st != QA_OK) {
@@ -206,7 +245,7 @@ int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_st
             (void)hipGraphDestroy(g_lstm_graphs[lru].graph);
             g_lstm_graphs.erase(g_lstm_graphs.begin() + (long)lru);
         }
-        g_lstm_graphs.push_back(LstmGraph{xw, w_hh_ug, h_out, c_state, B, T, d, dev, graph, exec, 0});
+        g_lstm_graphs.push_back(LstmGraph{xw, w_hh_ug, h_out, c_state, B, T, d, dev, split_tag, graph, exec, 0});
         hit = &g_lstm_graphs.back();
     }
     hit->stamp = ++g_lstm_clock;
