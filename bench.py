@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-ssl", action="store_true", help="skip the secondary SSL front-end measurement")
     ap.add_argument("--no-lm", action="store_true", help="skip the secondary UniSE AR-LM tokens/sec measurement")
     ap.add_argument("--lm-batch", type=int, default=16, help="UniSE segments per GPU (BASELINE configs[2]: batch=16)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the widened secondaries (H-Codec 2.0 share of configs[4], TSE share of "
+                                                               "configs[3], second grouping point, LM CPU baseline)")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -174,15 +176,53 @@ def ssl_bench(dev, model, B, seconds, reps=3):
                        "dtype": "f32"}}
 
 
-def lm_bench(dev, rank, world, dist, batch, reps=2):
+HBM_PEAK_TBS = 8.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured float4 copy)
+
+
+def _lm_cpu_worker(batch, n_mix, steps, threads):
+    """Child process: oracle/llm_ref.py generate (greedy) on the host cores - the CPU baseline of the LM metric."""
+    import faulthandler
+
+    faulthandler.dump_traceback_later(150, exit=True)
+    torch.set_num_threads(threads)
+    from oracle import llm_ref as L
+
+    sd = L.lm_state_dict(4321)
+    mix = L.synth_feats(50, batch, n_mix)
+    t0 = time.perf_counter()
+    L.generate(sd, "se", None, mix, steps, 32, L.SPEC_UNISE)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"value": batch * (33 + steps) / dt, "unit": "tokens/sec", "cores": torch.get_num_threads(), "kind": "port",
+                      "sample": f"oracle/llm_ref.py (PyTorch-CPU restatement of LLM_SFT.generate, pinned to the reference's own class) greedy "
+                                f"generate of {batch} segments, prompt {n_mix + 2}, 33 + {steps} steps (one pass, prefill included)"}))
+
+
+def lm_cpu_baseline(batch=16, n_mix=250, steps=60):
+    import subprocess
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(cores, 32))
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", f"lm,{batch},{n_mix},{steps},{threads}"],
+                           capture_output=True, text=True, timeout=200, env=env, cwd=ROOT)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "unit": "tokens/sec", "cores": threads, "kind": "port", "sample": f"FAILED: {type(e).__name__}: {str(e)[:300]}"}
+
+
+def lm_bench(dev, rank, world, dist, batch, reps=2, task="se", n_enroll=0):
     """Secondary metric of BASELINE.json: UniSE AR tokens/sec = B * (33 + N) generated tokens / wall time of generate()
-    (prefill included), SE prompt of 252 embeddings (5 s segment), 283 greedy steps, features resident in HBM."""
+    (prefill included), SE prompt of 252 embeddings (5 s segment) - or TSE prompt of 503 with an enrollment - 283 greedy steps,
+    features resident in HBM.  The decode loop streams every weight and the whole KV cache once per step: `roofline` prices the
+    step against HBM."""
     import unified_audio_amd as qa
     from unified_audio_amd import synth
 
     sd = synth.lm_state_dict(4321)
     lm = qa.LLM_SFT(device=dev).load_state_dict(sd)
     mix = synth.synth_feats(50 + rank, batch, 250).to(dev)
+    enr = synth.synth_feats(90 + rank, batch, n_enroll).to(dev) if n_enroll else None
     mel = torch.zeros(batch, 250, 80)
     best = float("inf")
     for i in range(reps + 1):
@@ -190,7 +230,7 @@ def lm_bench(dev, rank, world, dist, batch, reps=2):
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
-        lm.generate("se", None, None, mel, mix, do_sample=False)
+        lm.generate(task, mel if enr is not None else None, enr, mel, mix, do_sample=False)
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
         if dist is not None:
@@ -199,9 +239,22 @@ def lm_bench(dev, rank, world, dist, batch, reps=2):
             dt = float(t.item())
         if i:
             best = min(best, dt)
+    # algorithmic HBM bytes of one decode step: 12 layers x (qkv 3 d^2 + o d^2 + gate/up 2 d I + down d I) fp32 weights + the active
+    # output_head slice, and K + V of every cached position of every sequence (fp32); averaged over the 283 steps
+    d, inter, layers, prompt = 512, 2048, 12, 2 + 250 + (1 + n_enroll if n_enroll else 0)
+    w_body = layers * (4 * d * d + 3 * d * inter) * 4
+    w_head = (33 * 4096 + 250 * 8192) / 283 * d * 4
+    kv = sum(layers * batch * (prompt + s + 1) * d * 2 * 4 for s in range(283)) / 283
+    step_bytes = w_body + w_head + kv
+    ms_step = 1e3 * best / 283
     return {"metric": "UniSE AR tokens/sec (greedy generate, prefill included)", "value": world * batch * 283 / best,
-            "unit": "tokens/sec", "ms_per_generate": 1e3 * best, "ms_per_decode_step_incl_prefill": 1e3 * best / 283,
-            "config": {"workload": f"LLM_SFT.generate SE task, {batch} segments x 5 s per GPU, prompt 252, 33 global + 250 semantic steps",
+            "unit": "tokens/sec", "ms_per_generate": 1e3 * best, "ms_per_decode_step_incl_prefill": ms_step,
+            "roofline": {"bound": "hbm", "achieved": step_bytes / (ms_step * 1e-3) / 1e12, "peak": HBM_PEAK_TBS, "unit": "TB/s",
+                         "frac": step_bytes / (ms_step * 1e-3) / 1e12 / HBM_PEAK_TBS,
+                         "bytes_per_step": {"weights": w_body + w_head, "kv_cache_mean": kv},
+                         "note": "whole decode step (62 dependent launches: 5 per layer + head + pick), prefill time included in the "
+                                 "denominator; the step is bound by ~4-6 us of latency per dependent launch, not by bytes (DESIGN.md)"},
+            "config": {"workload": f"LLM_SFT.generate {task.upper()} task, {batch} segments x 5 s per GPU, prompt {prompt}, 33 global + 250 semantic steps",
                        "dtype": "f32"}}
 
 
@@ -212,7 +265,10 @@ def log(msg):
 def main():
     args = parse()
     if args.cpu_baseline_worker:
-        c, sec, reps, thr, mdl = args.cpu_baseline_worker.split(",")
+        parts = args.cpu_baseline_worker.split(",")
+        if parts[0] == "lm":
+            return _lm_cpu_worker(int(parts[1]), int(parts[2]), int(parts[3]), int(parts[4]))
+        c, sec, reps, thr, mdl = parts
         return _cpu_baseline_worker(int(c), float(sec), int(reps), int(thr), mdl)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -328,6 +384,67 @@ def main():
         log("UniSE LM generate ...")
         lm_line = lm_bench(dev, rank, world, dist, args.lm_batch)
 
+    extras = {}
+    if rank == 0 and world == 1 and not args.lean and not args.no_extras and args.model == "1.5":
+        try:
+            # (1) the headline at a second grouping point (G ~ N25/8 ... N25/2): the per-call threshold of
+            #     Codec.encode (codec_adaptive.py:150-158) raised until about half the frames open a group
+            log("second grouping point ...")
+            lo_t, hi_t, best_t, best_g = spec.threshold, 1.0, None, None
+            for _ in range(7):
+                mid = 0.5 * (lo_t + hi_t)
+                g_ = codec.encode(wav.unsqueeze(1), feats.transpose(1, 2), threshold=mid)["acoustic_codes"].shape[-1]
+                if best_g is None or abs(g_ - 125) < abs(best_g - 125):
+                    best_t, best_g = mid, g_
+                lo_t, hi_t = (mid, hi_t) if g_ < 125 else (lo_t, mid)
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            for _ in range(3):
+                codes = codec.encode(wav.unsqueeze(1), feats.transpose(1, 2), threshold=best_t)
+                codec.decode(**codes)
+            torch.cuda.synchronize(dev)
+            dt2 = (time.perf_counter() - t2) / 3
+            extras["hcodec15_second_grouping_point"] = {"value": B * T / SR / dt2, "unit": "audio-seconds/sec", "ms_per_step": 1e3 * dt2,
+                                                        "groups_per_clip": int(best_g), "threshold": best_t,
+                                                        "note": "same batch, similarity threshold raised so that G ~ N25/2 = 125 (aggregator "
+                                                                "sequences 250 + G, RVQ over 32 x G vectors)"}
+        except Exception as e:  # noqa: BLE001
+            extras["hcodec15_second_grouping_point"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+    if rank == 0 and world == 1 and not args.lean and not args.no_extras and not args.no_lm:
+        try:
+            log("UniSE LM TSE share of configs[3] (8 segments per GPU, prompt 503) ...")
+            extras["unise_lm_tse_b8"] = lm_bench(dev, rank, world, None, 8, reps=1, task="tse", n_enroll=250)
+        except Exception as e:  # noqa: BLE001
+            extras["unise_lm_tse_b8"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+
+    if rank == 0 and world == 1 and not args.lean and not args.no_extras and args.model == "1.5":
+        try:
+            # (3) H-Codec 2.0, the per-GPU share of BASELINE configs[4]: 16 clips x 30 s @ 48 kHz (1.17 B parameters)
+            log("H-Codec 2.0 16 x 30 s (per-GPU share of configs[4]) ...")
+            spec20 = synth.Shapes20()
+            sd20 = synth.hcodec20_state_dict(1234, spec20)
+            n20 = sum(v.numel() for v in sd20.values())
+            codec20 = qa.Codec(None, None, None, spec=qa.SPEC_20, device=dev).load_state_dict(sd20)
+            del sd20
+            B20, T20 = 16, 30 * 48000 // spec20.frame_hop * spec20.frame_hop
+            wav20 = synth.synth_wav_fullband(17, B20, T20).to(dev)
+            feats20 = synth.synth_feat(19, B20, T20 // spec20.hop, 768).to(dev)
+            for i in range(4):
+                if i == 1:
+                    torch.cuda.synchronize(dev)
+                    t3 = time.perf_counter()
+                a20, s20 = codec20.encode(wav20, feats20)
+                rec20 = codec20.decode(a20, s20)
+            torch.cuda.synchronize(dev)
+            dt3 = (time.perf_counter() - t3) / 3
+            assert torch.isfinite(rec20).all()
+            extras["hcodec20_16x30s"] = {"value": B20 * T20 / 48000 / dt3, "unit": "audio-seconds/sec", "ms_per_step": 1e3 * dt3,
+                                         "config": {"workload": f"H-Codec 2.0 Codec.encode+Codec.decode ({n20 / 1e6:.0f} M parameters), 16 clips x "
+                                                                f"{T20 / 48000:.0f} s @48 kHz, 16 + 16 codebooks, SSL features precomputed", "dtype": "f32"}}
+            del codec20, wav20, feats20, rec20
+        except Exception as e:  # noqa: BLE001
+            extras["hcodec20_16x30s"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+
     ssl_line = None
     if world == 1 and not args.lean and not args.no_ssl and args.model != "2.0":
         log("SSL front-end ...")
@@ -353,11 +470,20 @@ def main():
         traffic, traffic_src, mfma_busy = None, None, None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic_hcodec15.json")
         if args.model == "1.5" and B == 32 and abs(args.seconds - 10.0) < 1e-6 and os.path.exists(pmc_file):
+            import hashlib
+
+            pmc = json.load(open(pmc_file))
+            src_hash = hashlib.sha256(open(os.path.join(ROOT, "unified_audio_amd", "csrc", "conv_gemm.hip"), "rb").read()).hexdigest()[:16]
             want = dom["kernel"].replace("conv_gemm_kernel<", "").rstrip(">").replace(",", ", ")
-            for k, v in json.load(open(pmc_file)).items():
-                if f"conv_gemm_kernel<{want}> (all" in k:
-                    traffic, traffic_src = v["hbm_bytes_per_launch"], "profiles/r01_g_hcodec15_pmc_hbm_mfma.md (2*FETCH_SIZE + WRITE_SIZE, per launch)"
-                    mfma_busy = v["mfma_busy_frac"]
+            if pmc.get("_kernel_source_sha256_16") != src_hash:  # counters of another build of the kernel: do not quote them
+                traffic_src = (f"stale: {pmc.get('_source', 'profiles/pmc_traffic_hcodec15.json')} was collected on conv_gemm.hip "
+                               f"{pmc.get('_kernel_source_sha256_16')}, this build is {src_hash}")
+            else:
+                for k, v in pmc.items():
+                    if isinstance(v, dict) and f"conv_gemm_kernel<{want}> (all" in k:
+                        traffic = v["hbm_bytes_per_launch"]
+                        traffic_src = pmc.get("_source", "profiles/") + " (2*FETCH_SIZE + WRITE_SIZE, per launch; rocprofv3 --pmc passes of this command)"
+                        mfma_busy = v["mfma_busy_frac"]
         gemm_ms = sum(prof[4 * i + 1] for i in range(3))
         line = {
             "metric": "audio-seconds/sec H-Codec encode+decode @16kHz b=32",
@@ -395,7 +521,19 @@ def main():
         line["pcie_inclusive"] = {"value": B * T / SR / pcie_elapsed, "unit": "audio-seconds/sec", "ms_per_step": 1e3 * pcie_elapsed,
                                   "note": "rank-0 only: wav+features H2D from pageable memory, codes D2H+H2D, waveform D2H included"}
         if lm_line is not None:
+            if world == 1 and not args.no_cpu_baseline and not args.no_extras:
+                log("LM cpu baseline ...")
+                lm_line["cpu_baseline"] = lm_cpu_baseline()
+            fe = lm_line.get("ssl_frontend")
+            if fe and "ms_per_pass" in fe:  # BASELINE configs[2] up to the tokens: WavLM features -> AR-LM token generation, B = 16
+                tot = (fe["ms_per_pass"] + lm_line["ms_per_generate"]) * 1e-3
+                lm_line["end_to_end_sr_b16"] = {"value": args.lm_batch * 283 / tot, "unit": "tokens/sec", "ms": 1e3 * tot,
+                                                "audio_seconds_per_sec": args.lm_batch * 5.0 / tot,
+                                                "note": "WavLM front-end + LLM_SFT.generate on the same 16 x 5 s segments (codec decode of the "
+                                                        "tokens is BiCodec in the reference, SURVEY 8f-2)"}
             line["unise_lm"] = lm_line
+        if extras:
+            line["extras"] = extras
         if ssl_line is not None:
             line["ssl_frontend"] = ssl_line
         if args.model == "2.0":
