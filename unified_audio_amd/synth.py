@@ -359,3 +359,107 @@ def synth_feats(seed: int, batch: int, frames: int, dim: int = 768) -> torch.Ten
     return torch.from_numpy(x.astype(np.float32))
 
 
+
+
+# ---- BiCodec detokenizer (QuarkAudio-UniSE/model/bicodec): quantizer look-up side, speaker detokenizer, prenet, wave generator ----
+
+@dataclasses.dataclass(frozen=True)
+class BiCodecShapes:
+    """Shapes of the Spark-TTS BiCodec checkpoint the reference loads (model/bicodec/bicodec.py:70-115); same field names as
+    oracle.bicodec_ref.BiCodecSpec and unified_audio_amd.BiCodecSpec."""
+
+    latent_dim: int = 1024
+    codebook_size: int = 8192
+    codebook_dim: int = 8
+    mel_dim: int = 128
+    spk_latent_dim: int = 128
+    token_num: int = 32
+    fsq_levels: Tuple[int, ...] = (4, 4, 4, 4, 4, 4)
+    vocos_dim: int = 384
+    vocos_inter: int = 2048
+    vocos_layers: int = 12
+    gen_channels: int = 1536
+    rates: Tuple[int, ...] = (8, 5, 4, 2)
+    kernel_sizes: Tuple[int, ...] = (16, 11, 8, 4)
+
+
+def bicodec_state_dict(seed: int, spec=None) -> Dict[str, torch.Tensor]:
+    """Seeded weights with the key names / shapes of the parts of `BiCodec.state_dict()` that `detokenize` reads
+    (bicodec.py:193-199): quantizer.codebook / out_project, speaker_encoder.quantizer.project_out / project, prenet.*, decoder.*
+    (checked against the reference's own modules by tests/test_bicodec_oracle_cpu.py).  weight_norm parameters come as
+    weight_g / weight_v like torch.nn.utils.weight_norm stores them (dim 0: for ConvTranspose1d that is the INPUT channel)."""
+    spec = spec or BiCodecShapes()
+    g = _Gen(seed)
+    rng, sd = g.rng, g.sd
+    L, C, I = spec.latent_dim, spec.vocos_dim, spec.vocos_inter
+
+    def wn_generic(name, shape, fan_in, gain=1.0):
+        w = g.uniform(shape, gain / math.sqrt(fan_in))
+        sd[name + ".weight_v"] = _t(w)
+        n0 = np.sqrt((w.reshape(shape[0], -1) ** 2).sum(1)) * rng.uniform(0.8, 1.25, size=shape[0])
+        sd[name + ".weight_g"] = _t(n0.reshape((shape[0],) + (1,) * (len(shape) - 1)))
+
+    sd["quantizer.codebook.weight"] = _t(rng.standard_normal((spec.codebook_size, spec.codebook_dim)))
+    g.conv("quantizer.out_project", L, spec.codebook_dim, 1, wn=True, gain=2.0)
+    g.linear("speaker_encoder.quantizer.project_out", spec.spk_latent_dim, len(spec.fsq_levels), gain=2.0)
+    g.linear("speaker_encoder.project", L, spec.spk_latent_dim * spec.token_num, gain=2.0)
+
+    def vocos(p, n_layers, cond):
+        g.conv(p + ".embed", C, C, 7)
+        if cond:
+            for nm, base in (("scale", 1.0), ("shift", 0.0)):
+                sd[f"{p}.norm.{nm}.weight"] = _t(g.uniform((C, cond), 0.5 / math.sqrt(cond)))
+                sd[f"{p}.norm.{nm}.bias"] = _t(base + 0.1 * rng.standard_normal(C))
+        else:
+            g.norm(p + ".norm", C)
+        for i in range(n_layers):
+            q = f"{p}.convnext.{i}"
+            sd[q + ".gamma"] = _t(rng.uniform(0.5, 1.5, size=C) / n_layers)
+            g.conv(q + ".dwconv", C, 1, 7)
+            if cond:
+                for nm, base in (("scale", 1.0), ("shift", 0.0)):
+                    sd[f"{q}.norm.{nm}.weight"] = _t(g.uniform((C, cond), 0.5 / math.sqrt(cond)))
+                    sd[f"{q}.norm.{nm}.bias"] = _t(base + 0.1 * rng.standard_normal(C))
+            else:
+                g.norm(q + ".norm", C)
+            g.linear(q + ".pwconv1", I, C)
+            g.linear(q + ".pwconv2", C, I)
+        g.norm(p + ".final_layer_norm", C)
+
+    g.linear("prenet.linear_pre", C, L)
+    for i in range(2):
+        vocos(f"prenet.downsample.{i}.1", 2, 0)
+    vocos("prenet.vocos_backbone", spec.vocos_layers, L)
+    g.linear("prenet.linear", L, C)
+
+    ch = spec.gen_channels
+    g.conv("decoder.model.0", ch, L, 7, wn=True)
+    for i, (k, s) in enumerate(zip(spec.kernel_sizes, spec.rates)):
+        cin, cout = ch // 2 ** i, ch // 2 ** (i + 1)
+        p = f"decoder.model.{i + 1}.block"
+        sd[p + ".0.alpha"] = _t(rng.uniform(0.5, 1.5, size=(1, cin, 1)))
+        wn_generic(p + ".1", (cin, cout, k), cin * k / s, gain=1.5)  # ConvTranspose1d weight [C_in, C_out, k]
+        sd[p + ".1.bias"] = _t(g.uniform((cout,), 0.05))
+        for j in range(3):
+            u = f"{p}.{j + 2}.block"
+            sd[u + ".0.alpha"] = _t(rng.uniform(0.5, 1.5, size=(1, cout, 1)))
+            g.conv(u + ".1", cout, cout, 7, wn=True)
+            sd[u + ".2.alpha"] = _t(rng.uniform(0.5, 1.5, size=(1, cout, 1)))
+            g.conv(u + ".3", cout, cout, 1, wn=True)
+    n = len(spec.rates)
+    cl = ch // 2 ** n
+    sd[f"decoder.model.{n + 1}.alpha"] = _t(rng.uniform(0.5, 1.5, size=(1, cl, 1)))
+    g.conv(f"decoder.model.{n + 2}", 1, cl, 7, wn=True, gain=0.35)  # keeps tanh out of saturation
+    return sd
+
+
+def bicodec_tokens(seed: int, batch: int, frames: int, spec=None):
+    """Seeded semantic tokens [B, frames] and global tokens [B, 1, token_num] (int64) in range."""
+    spec = spec or BiCodecShapes()
+    rng = np.random.default_rng(seed)
+    n_glob = 1
+    for lv in spec.fsq_levels:
+        n_glob *= lv
+    sem = torch.from_numpy(rng.integers(0, spec.codebook_size, size=(batch, frames)).astype(np.int64))
+    glob = torch.from_numpy(rng.integers(0, n_glob, size=(batch, 1, spec.token_num)).astype(np.int64))
+    return sem, glob
