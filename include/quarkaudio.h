@@ -12,6 +12,7 @@
  *   qa_rvq_lookup      <-> ResidualVQ.get_output_from_indices  call sites vq/codec.py:183-184 (vq/core_vq.py:406-412)
  *   qa_lm_create       <-> LLM_SFT(...) + load_state_dict   QuarkAudio-UniSE/model/llm/llm_sft.py:13-33, model/model.py:82-91
  *   qa_lm_generate     <-> LLM_SFT.generate(...)            QuarkAudio-UniSE/model/llm/llm_sft.py:93-195
+ *   qa_bicodec_detokenize <-> BiCodec.detokenize(...)       QuarkAudio-UniSE/model/bicodec/bicodec.py:182-199
  *
  * Conventions
  *   - every function returns 0 on success or a negative qa_status; nothing throws across the ABI;
@@ -242,6 +243,43 @@ int64_t qa_ssl_frames(const qa_ssl* h, int64_t T);
 /* wav float32 [B, T] (device) -> feats float32 [B, frames, hidden] (device, channel-last: what qa_hcodec_encode takes as `feat`
  * with strides (frames*hidden, 1, hidden)) */
 int qa_ssl_forward(qa_ssl* h, const float* wav, int64_t B, int64_t T, float* feats, void* stream);
+
+/* ---- BiCodec detokenizer ------------------------------------------------------------------------
+ * BiCodec.detokenize(semantic_tokens, global_tokens) (QuarkAudio-UniSE/model/bicodec/bicodec.py:182-199), the stage
+ * Model.test_step ends with (model/model.py:193,223): codebook look-up + out_project, FSQ look-up + speaker projection (d-vector),
+ * the AdaLN-Vocos prenet, and the Snake / ConvTranspose1d / dilated-residual wave generator.  Shapes of the Spark-TTS BiCodec
+ * checkpoint (its config.yaml is not part of the reference tree) are the defaults of unified_audio_amd.BiCodecSpec.
+ * Weights: the `BiCodec.state_dict()` entries quantizer.codebook / quantizer.out_project, speaker_encoder.quantizer.project_out,
+ * speaker_encoder.project, prenet.*, decoder.* (weight_g / weight_v or plain weight). */
+typedef struct qa_bicodec_spec {
+    int32_t latent_dim;        /* 1024  quantizer.input_dim = prenet in / out = d-vector width = decoder.input_channel */
+    int32_t codebook_size;     /* 8192 */
+    int32_t codebook_dim;      /* 8 */
+    int32_t spk_latent_dim;    /* 128 */
+    int32_t token_num;         /* 32 global tokens */
+    int32_t n_levels;          /* 6 */
+    int32_t levels[8];         /* 4,4,4,4,4,4 (FSQ) */
+    int32_t vocos_dim;         /* 384 */
+    int32_t vocos_inter;       /* 2048 */
+    int32_t vocos_layers;      /* 12 */
+    int32_t gen_channels;      /* 1536 */
+    int32_t n_rates;           /* 4 */
+    int32_t rates[8];          /* 8,5,4,2 */
+    int32_t kernel_sizes[8];   /* 16,11,8,4 */
+} qa_bicodec_spec;
+typedef struct qa_bicodec qa_bicodec;
+int qa_bicodec_create(qa_bicodec** out, const qa_bicodec_spec* spec, const qa_tensor* tensors, int64_t n_tensors, int device);
+void qa_bicodec_destroy(qa_bicodec* h);
+/* samples per semantic token = prod(rates) (320) */
+int64_t qa_bicodec_hop(const qa_bicodec* h);
+/* semantic_tokens int64 [B, T], global_tokens int64 [B, token_num] (the reference's [B, 1, token_num], contiguous) -> wav_out
+ * fp32 [B, T * hop] (the reference returns [B, 1, T * hop]).  Out-of-range tokens are clamped for memory safety only: validate
+ * with qa_codes_check where the reference's F.embedding would raise. */
+int qa_bicodec_detokenize(qa_bicodec* h, const int64_t* semantic_tokens, const int64_t* global_tokens, int64_t B, int64_t T,
+                          float* wav_out, void* stream);
+/* test hooks, as qa_hcodec_enable_taps / qa_hcodec_tap: z_q, d_vector, prenet.down, prenet.backbone, prenet.out, gen.block{i} */
+int qa_bicodec_enable_taps(qa_bicodec* h, int on);
+int64_t qa_bicodec_tap(qa_bicodec* h, const char* name, float* dst, int64_t cap, void* stream);
 
 /* ---- UniSE AR-LM ------------------------------------------------------------------------------------ */
 

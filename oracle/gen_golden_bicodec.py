@@ -18,7 +18,7 @@ from unified_audio_amd import synth
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
 SMALL = dict(latent_dim=64, codebook_size=128, codebook_dim=8, spk_latent_dim=32, token_num=4, vocos_dim=32, vocos_inter=64, vocos_layers=2,
-             gen_channels=128, rates=(4, 5, 2), kernel_sizes=(8, 11, 4))
+             gen_channels=256, rates=(4, 5, 2), kernel_sizes=(8, 11, 4))
 # full widths of the published configuration with a short backbone and few frames: every kernel shape of the real model, small file
 WIDE = dict(vocos_layers=2)
 CASES = {  # name -> (spec kwargs, seed, batch, frames)

@@ -58,6 +58,15 @@ class qa_lm_spec(C.Structure):
     ]
 
 
+class qa_bicodec_spec(C.Structure):
+    _fields_ = [
+        ("latent_dim", C.c_int32), ("codebook_size", C.c_int32), ("codebook_dim", C.c_int32), ("spk_latent_dim", C.c_int32),
+        ("token_num", C.c_int32), ("n_levels", C.c_int32), ("levels", C.c_int32 * 8), ("vocos_dim", C.c_int32),
+        ("vocos_inter", C.c_int32), ("vocos_layers", C.c_int32), ("gen_channels", C.c_int32), ("n_rates", C.c_int32),
+        ("rates", C.c_int32 * 8), ("kernel_sizes", C.c_int32 * 8),
+    ]
+
+
 class qa_ssl_spec(C.Structure):
     _fields_ = [
         ("n_conv", C.c_int32), ("conv_dim", C.c_int32 * 8), ("conv_kernel", C.c_int32 * 8), ("conv_stride", C.c_int32 * 8),
@@ -104,6 +113,12 @@ SYMBOLS = {
     "qa_ssl_destroy": (None, [C.c_void_p]),
     "qa_ssl_frames": (C.c_int64, [C.c_void_p, C.c_int64]),
     "qa_ssl_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "qa_bicodec_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(qa_bicodec_spec), C.POINTER(qa_tensor), C.c_int64, C.c_int]),
+    "qa_bicodec_destroy": (None, [C.c_void_p]),
+    "qa_bicodec_hop": (C.c_int64, [C.c_void_p]),
+    "qa_bicodec_detokenize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "qa_bicodec_enable_taps": (C.c_int, [C.c_void_p, C.c_int]),
+    "qa_bicodec_tap": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "qa_lm_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(qa_lm_spec), C.POINTER(qa_tensor), C.c_int64, C.c_int]),
     "qa_lm_destroy": (None, [C.c_void_p]),
     "qa_lm_generate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,

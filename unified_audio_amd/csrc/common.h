@@ -41,7 +41,7 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 
 // ---- activation codes shared by kernels (match qa_conv_args) ----
-enum { ACT_NONE = 0, ACT_ELU = 1, ACT_GELU = 2, ACT_SILU = 3 };
+enum { ACT_NONE = 0, ACT_ELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_SNAKE = 4, ACT_TANH = 5 };  // SNAKE needs ConvParams::alpha (conv_gemm epilogue only)
 enum { PAD_ZERO = 0, PAD_REFLECT = 1 };
 
 // ELU(alpha=1).  exp(x) - 1 instead of expm1f: ocml's expm1f brings divergent slow paths (and scratch spills) into the GEMM
@@ -56,6 +56,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case ACT_ELU: return elu_f(v);
         case ACT_GELU: return gelu_erf_f(v);
         case ACT_SILU: return silu_f(v);
+        case ACT_TANH: return tanhf(v);
         default: return v;
     }
 }
@@ -108,6 +109,14 @@ struct ConvParams {
     // (y[2i], y[2i+1]) <- (y[2i] c - y[2i+1] s, y[2i+1] c + y[2i] s) with (c, s) = rope[(t * rope_hd/2 + i) * 2 + {0,1}], t = m % rope_T, i = (n % rope_hd) / 2
     const float* rope;
     int rope_n, rope_hd, rope_T;
+    int dilation;  // tap j reads frame t * stride - pad_left + j * dilation (0 / 1 = dense); zero padding only
+    // Snake activation x + sin^2(alpha x) / (alpha + 1e-9) with a per-output-channel alpha (BiCodec wave generator, blocks/layers.py:31-36):
+    // `alpha` serves act / post_act == ACT_SNAKE; y2 (optional) receives snake(final value, alpha2) next to y, so that a residual
+    // unit's input exists both raw (for the skip) and activated (for its first convolution) without another pass over HBM
+    const float* alpha;
+    float* y2;
+    const float* alpha2;
+    long long ldy2;
 };
 
 // Live measurement hook (bench.py): when enabled every conv_gemm launch is bracketed by HIP events on its own stream.

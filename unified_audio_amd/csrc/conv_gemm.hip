@@ -48,6 +48,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stay
 
 constexpr int TAP_WIN = 8;  // taps per LDS source-frame table window (ksize <= 8: built once per tile)
 
+__device__ __forceinline__ float snake_f(float x, float a) {
+    const float s = sinf(a * x);
+    return x + s * s / (a + 1e-9f);
+}
+__device__ __forceinline__ f32x4 snake4(f32x4 v, const float* alpha, int n) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(alpha + n);
+    const f32x4 r = {snake_f(v.x, a.x), snake_f(v.y, a.y), snake_f(v.z, a.z), snake_f(v.w, a.w)};
+    return r;
+}
+
 // epilogue of 4 consecutive output channels of one row: v = acc + bias -> gate -> act -> gamma -> residual -> post_act
 __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const ConvParams& p, long long m, int n, f32x4 bias, f32x4 gamma) {
     v += bias;
@@ -55,15 +65,20 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const ConvParams& p, long lo
         const f32x4 g = *reinterpret_cast<const f32x4*>(p.gate + m * p.ldg + n);
         v.x *= silu_f(g.x); v.y *= silu_f(g.y); v.z *= silu_f(g.z); v.w *= silu_f(g.w);
     }
-    if (p.act != ACT_NONE) {
+    if (p.act == ACT_SNAKE) {
+        v = snake4(v, p.alpha, n);
+    } else if (p.act != ACT_NONE) {
         v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
     }
     if (p.gamma) v *= gamma;
     if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + n);
-    if (p.post_act != ACT_NONE) {
+    if (p.post_act == ACT_SNAKE) {
+        v = snake4(v, p.alpha, n);
+    } else if (p.post_act != ACT_NONE) {
         v.x = apply_act(v.x, p.post_act); v.y = apply_act(v.y, p.post_act); v.z = apply_act(v.z, p.post_act);
         v.w = apply_act(v.w, p.post_act);
     }
+    if (p.y2) *reinterpret_cast<f32x4*>(p.y2 + m * p.ldy2 + n) = snake4(v, p.alpha2, n);
     if (p.rope && n < p.rope_n) {  // interleaved pairs (2i, 2i+1): both members of a pair sit in this float4 (n % 4 == 0)
         const int t = (int)(m % p.rope_T), i = (n % p.rope_hd) >> 1;
         const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope + ((long long)t * (p.rope_hd >> 1) + i) * 2);  // c_i, s_i, c_i+1, s_i+1
@@ -115,12 +130,13 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(cons
     const bool reflect = p.pad_mode == PAD_REFLECT;
     const int ldx_i = (int)p.ldx;
     const int t_virtual = p.T_in * (p.in_rep > 1 ? p.in_rep : 1);
+    const int dil = p.dilation > 1 ? p.dilation : 1;
     auto build_taps = [&](int jbase) {
         for (int e = tid; e < BM * TAP_WIN; e += 256) {
             const int row = e / TAP_WIN, j = jbase + (e % TAP_WIN);
             const int m = min(m0 + row, p.M - 1);
             const int t = m % p.T_out;
-            int r = t * p.stride - p.pad_left + j;
+            int r = t * p.stride - p.pad_left + j * dil;
             const int rr = r < 0 ? -r : (r >= p.Lp ? 2 * (p.Lp - 1) - r : r);  // = resolve_frame()
             r = reflect ? rr : r;
             const bool ok = r >= 0 && r < t_virtual && j < p.ksize;
@@ -383,6 +399,11 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
     q.rep_one = p.in_rep > 1 ? 0u : 1u;
     q.rep_magic = p.in_rep > 1 ? (unsigned)(((1ULL << 32) + p.in_rep - 1) / p.in_rep) : 0u;
     QA_REQUIRE(p.in_rep <= 1 || p.pad_mode == PAD_ZERO, "conv_gemm: in_rep needs zero padding");
+    const bool snake = p.act == ACT_SNAKE || p.post_act == ACT_SNAKE;
+    QA_REQUIRE((!snake && !p.y2) || (q.vec_epi && (!snake || (p.alpha && al16(p.alpha))) &&
+                                     (!p.y2 || (p.alpha2 && al16(p.alpha2) && al16(p.y2) && p.ldy2 % 4 == 0))),
+               "conv_gemm: Snake activation / second output need the float4 epilogue and 16-byte aligned alpha vectors");
+    QA_REQUIRE(p.dilation <= 1 || (p.pad_mode == PAD_ZERO && p.in_rep <= 1), "conv_gemm: dilation needs zero padding");
     QA_REQUIRE(!p.rope || (q.vec_epi && p.rope_hd % 4 == 0 && p.rope_n % 4 == 0 && p.rope_T > 0 && al16(p.rope)),
                "conv_gemm: fused RoPE needs the float4 epilogue (N, strides, pointers multiples of 4 / 16 B)");
     int cfg;
