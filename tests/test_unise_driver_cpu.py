@@ -66,7 +66,7 @@ def test_driver_batches_segments_of_several_utterances():
     ea, eb = torch.full((1, 48000), 1.0), torch.full((1, 48000), 2.0)
     calls.clear()
     out = drv.enhance_tokens("tse", [a, b], [ea, eb])
-    assert calls["ssl"] == [(5, 80000), (2, 48000)] and calls["lm"]["Ne"] == 150
+    assert calls["ssl"] == [(2, 48000), (5, 80000)] and calls["lm"]["Ne"] == 150  # enrollment first, like model.py:204-212
     e = calls["lm"]["enroll"]
     assert e.shape[0] == 5 and (e[:2] == 1.0).all() and (e[2:] == 2.0).all()
     with pytest.raises(ValueError):
@@ -75,3 +75,55 @@ def test_driver_batches_segments_of_several_utterances():
         drv.enhance_tokens("ss", [a])
     with pytest.raises(RuntimeError):
         drv.enhance("se", [a])
+
+
+def test_ss_mode_runs_the_three_passes_of_the_reference():
+    """model.py:223-290: SE on the first 5 s -> detokenize -> peak-normalised enrollment (x 0.99) -> TSE and rTSE over all segments
+    with that enrollment tiled; two waveforms per mixture, each cut to the mixture's length."""
+    log = []
+
+    class FakeSSL:
+        def __call__(self, wavs):
+            log.append(("ssl", tuple(wavs.shape), float(wavs.abs().max())))
+            return wavs[:, :4].unsqueeze(-1).repeat(1, 1, 2)
+
+    class FakeLM:
+        def generate(self, task_name, enroll_mel, enroll_feats, mix_mel, mix_feats, do_sample):
+            B = mix_feats.shape[0]
+            log.append(("lm", task_name, B, None if enroll_feats is None else tuple(enroll_feats.shape), None if enroll_mel is None else enroll_mel.size(1)))
+            base = {"se": 0, "tse": 1000, "rtse": 2000}[task_name]
+            return torch.full((B, 32), base), torch.full((B, 250), base) + torch.arange(B)[:, None]
+
+    class FakeTok:
+        def detokenize(self, global_tokens, semantic_tokens):
+            assert global_tokens.shape[1:] == (1, 32) and semantic_tokens.shape[1] == 250
+            B = semantic_tokens.shape[0]
+            # waveform value encodes (task base + segment index); longer than a segment like a real codec's padding would be
+            return (semantic_tokens[:, :1].float() * 0.001).view(B, 1, 1).expand(B, 1, 80000 + 320).contiguous()
+
+    drv = U.UniSE(FakeLM(), FakeSSL(), tokenizer=FakeTok())
+    a, b = torch.randn(1, 30000), torch.randn(1, 170000)   # shorter than one segment / three segments
+    out = drv.enhance("ss", [a, b])
+    lm = [x for x in log if x[0] == "lm"]
+    assert [x[1:3] for x in lm] == [("se", 2), ("tse", 4), ("rtse", 4)]
+    assert lm[1][3] == (4, 4, 2) and lm[1][4] == 250 and lm[2][3] == (4, 4, 2)   # enrollment features tiled 1 + 3, 5 s of mel frames
+    ssl = [x for x in log if x[0] == "ssl"]
+    assert ssl[0][1] == (2, 80000)                       # first 5 s of both mixtures (the short one wrap-padded), un-normalised
+    assert ssl[1][1] == (2, 80000) and abs(ssl[1][2] - 0.99 * 0.001 / (0.001 + 1e-5)) < 1e-5   # enroll / (max|enroll| + 1e-5) * 0.99 (model.py:243)
+    (s1a, s2a), (s1b, s2b) = out
+    assert s1a.shape == s2a.shape == (30000,) and s1b.shape == s2b.shape == (170000,)
+    assert abs(float(s1b[0]) - 1.001) < 1e-5 and abs(float(s2b[0]) - 2.001) < 1e-5 and abs(float(s1a[0]) - 1.000) < 1e-5
+    assert abs(float(s1b[80320]) - 1.002) < 1e-5         # est.reshape(-1): segment 1 starts after segment 0's FULL decoded length (model.py:193)
+
+
+def test_stft_logmel_matches_the_reference_formula():
+    """model.py:53-79 with torchaudio.functional.melscale_fbanks(321, 0, 8000, 80, 16000) (HTK, norm=None) restated."""
+    x = torch.randn(2, 16000 + 123, generator=torch.Generator().manual_seed(0))
+    mel = U.stft_logmel(x)
+    assert mel.shape == (2, U.mel_frames(x.shape[-1]), 80) and torch.isfinite(mel).all()
+    # filter bank properties: triangles cover [0, 8000] Hz, peak 1 at their centres, every interior bin belongs to <= 2 filters
+    import math
+    tone = torch.sin(2 * math.pi * 1000.0 * torch.arange(16000) / 16000.0)[None]
+    m = U.stft_logmel(tone)[0].mean(0)
+    centre = 2595.0 * math.log10(1 + 1000.0 / 700.0) / (2595.0 * math.log10(1 + 8000.0 / 700.0)) * 81 - 1
+    assert abs(int(m.argmax()) - centre) <= 1.5

@@ -51,3 +51,48 @@ def test_batched_utterances_equal_one_at_a_time(qa_lib, gpu_device):
             gi, si = lm.generate("tse", emel, torch.cat([ef for _ in range(seg.size(0))], dim=0), mel, mix_feats, do_sample=False)
         assert torch.equal(gi, batched[1][0]) and torch.equal(si, batched[1][1])
         assert int(si.max()) < 128 and int(gi.max()) < 64
+
+
+def test_enhance_end_to_end_against_the_oracle_chain(qa_lib, gpu_device):
+    """Model.test_step 'se' and 'ss' on the HIP components (WavLM front-end -> AR-LM -> BiCodec detokenize) against the CPU oracles
+    chained the same way (ssl_ref -> llm_ref.generate -> bicodec_ref.detokenize): tokens equal up to audited near-ties, waveform of
+    the same tokens within the north_star tolerance, output length = input length."""
+    import dataclasses
+
+    import unified_audio_amd as qa
+    from oracle import bicodec_ref as BR
+    from tests.test_llm_gpu import _audit
+    from unified_audio_amd import synth
+    from unified_audio_amd import unise as U
+
+    sspec = S.SSLSpec(conv_dim=(64,) * 7, hidden_size=96, num_hidden_layers=2, num_attention_heads=3, intermediate_size=192,
+                      num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=2, num_buckets=32, max_bucket_distance=100,
+                      compress_exponent=0.0)
+    ssl_sd = S.synth_state_dict(4, sspec, "wavlm")
+    fx = qa.SSLFeatureExtractor(qa.SSLSpec(**{f: getattr(sspec, f) for f in sspec.__dataclass_fields__}), device=gpu_device).load_state_dict(ssl_sd)
+    bspec = BR.BiCodecSpec(latent_dim=64, codebook_size=128, codebook_dim=8, spk_latent_dim=32, token_num=32, vocos_dim=32, vocos_inter=64,
+                           vocos_layers=2, gen_channels=256, rates=(8, 5, 4, 2), kernel_sizes=(16, 11, 8, 4))
+    lspec = L.LMSpec(hidden=256, n_layers=2, n_heads=4, global_size=4096, semantic_size=128, feats_dim=96)
+    lm_sd = L.lm_state_dict(8, lspec)
+    lm = qa.LLM_SFT(feats_dim=96, llm_base_config=dict(global_size=4096, semantic_size=128, hidden_size=256, num_layers=2,
+                                                       num_attention_heads=4), device=gpu_device).load_state_dict(lm_sd)
+    bsd = synth.bicodec_state_dict(5, bspec)
+    bic = qa.BiCodec(qa.BiCodecSpec(**{f: getattr(bspec, f) for f in bspec.__dataclass_fields__}), device=gpu_device).load_state_dict(bsd)
+    drv = U.UniSE(lm, fx, tokenizer=qa.BiCodecTokenizer(model=bic))
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn(1, 90000, generator=g) * 0.1
+    # ---- 'se'
+    (gids, sids), = drv.enhance_tokens("se", [src.to(gpu_device)])
+    seg = U.segment(src, normalise=True)
+    with torch.no_grad():
+        feats = S.extract_features(ssl_sd, seg, sspec)
+    _audit(lm_sd, lspec, "se", None, feats, 250, 32, gids.cpu(), sids.cpu(), tol=5e-4)  # features differ by ~1e-6 from the oracle's
+    est, = drv.enhance("se", [src.to(gpu_device)])
+    assert est.shape == (90000,)
+    want = BR.detokenize(bsd, sids.cpu(), gids.cpu().unsqueeze(1), bspec).squeeze(1).reshape(-1)[:90000]
+    assert float((est.cpu() - want).pow(2).mean().sqrt()) < 1e-3
+    # ---- 'ss': two waveforms of the mixture's length, reproducible, and different from each other
+    (s1, s2), = drv.enhance("ss", [src.to(gpu_device)])
+    (t1, t2), = drv.enhance("ss", [src.to(gpu_device)])
+    assert s1.shape == s2.shape == (90000,) and torch.equal(s1, t1) and torch.equal(s2, t2) and not torch.equal(s1, s2)
+    assert torch.isfinite(s1).all() and torch.isfinite(s2).all()

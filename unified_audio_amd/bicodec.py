@@ -152,3 +152,25 @@ class BiCodec(torch.nn.Module):
             self._free()
         except Exception:
             pass
+
+
+class BiCodecTokenizer(torch.nn.Module):
+    """Decode side of the reference's BiCodecTokenizer (QuarkAudio-UniSE/model/bicodec/audio_tokenizer.py:107-120), the object
+    `Model.test_step` calls: `detokenize(global_tokens [B, 1, 32], semantic_tokens [B, T]) -> wav [B, 1, T * 320]`."""
+
+    def __init__(self, model_dir=None, device="cuda:0", *, model: BiCodec | None = None, spec: BiCodecSpec = SPEC_BICODEC, **kwargs):
+        super().__init__()
+        if model is None:
+            if model_dir is None:
+                raise ValueError("BiCodecTokenizer needs model_dir (with BiCodec/model.safetensors) or model=")
+            model = BiCodec.load_from_checkpoint(f"{model_dir}/BiCodec", device=device, spec=spec)  # audio_tokenizer.py:50-53
+        self.model = model
+        self.device = model.device
+
+    @torch.no_grad()
+    def detokenize(self, global_tokens: torch.Tensor, semantic_tokens: torch.Tensor) -> torch.Tensor:
+        return self.model.detokenize(semantic_tokens, global_tokens)
+
+    def tokenize(self, *args, **kwargs):
+        raise _lib.QuarkAudioError(-4, "BiCodec tokenize (wav2vec2-BERT features + ECAPA speaker encoder) is training-side and not part of "
+                                       "the inference path: the LM produces the tokens")

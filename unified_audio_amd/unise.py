@@ -7,9 +7,9 @@
 
 The reference handles ONE utterance per call (`batch_size == 1`, dataloader/data_module.py:340); here any number of
 utterances is accepted: their segments are concatenated into one batch for the front-end and the LM (segments are
-independent), and the tokens are handed back per utterance.  The last stage of `test_step` - BiCodec `detokenize` - is not
-part of this package: pass a callable `detokenize(global_ids[B,1,32], semantic_ids[B,N]) -> wav[B,1,t]` to
-get waveforms, otherwise tokens are returned.
+independent), and the results are handed back per utterance.  The last stage of `test_step` - BiCodec `detokenize` - is
+`unified_audio_amd.BiCodecTokenizer`: with it `UniSE.enhance` returns waveforms for 'se', 'tse' and the three-pass
+'ss' mode (model.py:223-290); without it `enhance_tokens` returns the tokens.
 """
 from __future__ import annotations
 
@@ -61,50 +61,112 @@ class _Frames:
         return self._shape[dim]
 
 
+def stft_logmel(x: torch.Tensor, hop_length: int = HOP_LENGTH, win_length: int = WIN_LENGTH, n_fft: int = 640, n_mels: int = 80) -> torch.Tensor:
+    """Model.stft_logmel (model.py:53-79), restated with the filter bank of torchaudio.functional.melscale_fbanks (HTK scale, no
+    normalisation, 0-8000 Hz).  NOT on the hot path: LLM_SFT.generate consumes only `mel.size(1)` (llm_sft.py:108), which
+    `mel_frames()` gives without computing anything; this function exists for callers that want the reference's tensor."""
+    assert x.ndim == 2
+    pad_length = math.ceil(x.size(-1) / hop_length) * hop_length - x.size(-1)
+    x = torch.nn.functional.pad(x, ((win_length - hop_length) // 2, pad_length + (win_length - hop_length) // 2))
+    spec = torch.stft(x, n_fft, hop_length, win_length=win_length, window=torch.hann_window(win_length, device=x.device), onesided=True,
+                      center=False, return_complex=True).transpose(1, 2)
+    n_freqs = n_fft // 2 + 1
+    all_freqs = torch.linspace(0, 16000 // 2, n_freqs)
+    hz2mel = lambda f: 2595.0 * math.log10(1.0 + f / 700.0)  # noqa: E731
+    m_pts = torch.linspace(hz2mel(0.0), hz2mel(8000.0), n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down, up = -slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:]
+    fb = torch.clamp(torch.minimum(down, up), min=0.0).to(x.device)
+    return torch.log(spec.abs() @ fb + 1e-10)
+
+
 class UniSE:
-    def __init__(self, dnn, semantic_model, detokenize: Optional[Callable] = None):
-        """dnn: unified_audio_amd.LLM_SFT; semantic_model: unified_audio_amd.SSLFeatureExtractor(SPEC_WAVLM_BASE_PLUS)."""
+    def __init__(self, dnn, semantic_model, tokenizer=None, detokenize: Optional[Callable] = None):
+        """dnn: unified_audio_amd.LLM_SFT; semantic_model: unified_audio_amd.SSLFeatureExtractor(SPEC_WAVLM_BASE_PLUS);
+        tokenizer: unified_audio_amd.BiCodecTokenizer (or any object / callable with the reference's
+        `detokenize(global_tokens [B, 1, 32], semantic_tokens [B, N]) -> wav [B, 1, t]`, model.py:193)."""
         self.dnn = dnn
         self.semantic_model = semantic_model
-        self.detokenize = detokenize
+        self.detokenize = detokenize if detokenize is not None else (tokenizer.detokenize if tokenizer is not None else None)
 
-    @torch.no_grad()
-    def enhance_tokens(self, mode: str, srcs: Sequence[torch.Tensor], enrolls: Optional[Sequence[torch.Tensor]] = None
-                       ) -> List[Tuple[torch.Tensor, torch.Tensor]]:
-        """srcs: utterances [1, T_i] (device tensors); enrolls (tse): one [1, T_e] per utterance, all of the same length.
-        Returns per utterance (global_ids [n_seg_i, 32], semantic_ids [n_seg_i, 250])."""
-        if mode not in ("se", "tse"):
-            raise KeyError(mode)
-        segs = [segment(s, normalise=(mode == "se")) for s in srcs]
-        counts = [s.size(0) for s in segs]
-        seg_src = torch.cat(segs, dim=0)
+    def _generate(self, mode: str, seg_src: torch.Tensor, counts: Sequence[int], enroll_feats_per_utt: Optional[torch.Tensor],
+                  enroll_samples: int):
         mix_feats = self.semantic_model(seg_src)                                   # extract_semantic_features, model.py:38-51
         mix_mel = _Frames(seg_src.size(0), mel_frames(SEG_LEN))
         enroll_mel = enroll_feats = None
-        if mode == "tse":
-            if enrolls is None or len(enrolls) != len(srcs):
-                raise ValueError("tse needs one enrollment per utterance")
-            if len({e.size(-1) for e in enrolls}) != 1:
-                raise ValueError("enrollments of one call must have the same length")
-            ef = self.semantic_model(torch.cat(list(enrolls), dim=0))             # [U, N_e, d]
+        if enroll_feats_per_utt is not None:
             # model.py:207-210: the utterance's enrollment is tiled over its segments
-            enroll_feats = torch.cat([ef[i:i + 1].expand(c, -1, -1) for i, c in enumerate(counts)], dim=0).contiguous()
-            enroll_mel = _Frames(seg_src.size(0), mel_frames(enrolls[0].size(-1)))
-        global_ids, semantic_ids = self.dnn.generate(task_name=mode, enroll_mel=enroll_mel, enroll_feats=enroll_feats, mix_mel=mix_mel,
-                                                     mix_feats=mix_feats, do_sample=False)
+            enroll_feats = torch.cat([enroll_feats_per_utt[i:i + 1].expand(c, -1, -1) for i, c in enumerate(counts)], dim=0).contiguous()
+            enroll_mel = _Frames(seg_src.size(0), mel_frames(enroll_samples))
+        return self.dnn.generate(task_name=mode, enroll_mel=enroll_mel, enroll_feats=enroll_feats, mix_mel=mix_mel, mix_feats=mix_feats,
+                                 do_sample=False)
+
+    @staticmethod
+    def _split(counts, *tensors):
         out, at = [], 0
         for c in counts:
-            out.append((global_ids[at:at + c], semantic_ids[at:at + c]))
+            out.append(tuple(t[at:at + c] for t in tensors))
             at += c
         return out
 
     @torch.no_grad()
-    def enhance(self, mode: str, srcs: Sequence[torch.Tensor], enrolls: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
-        """test_step up to `est.reshape(-1)[:src.size(-1)]` (model.py:192-193); needs the `detokenize` callable."""
+    def enhance_tokens(self, mode: str, srcs: Sequence[torch.Tensor], enrolls: Optional[Sequence[torch.Tensor]] = None
+                       ) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+        """srcs: utterances [1, T_i] (device tensors); enrolls (tse / rtse): one [1, T_e] per utterance, all of the same length.
+        Returns per utterance (global_ids [n_seg_i, 32], semantic_ids [n_seg_i, 250])."""
+        if mode not in ("se", "tse", "rtse"):
+            raise KeyError(mode)
+        segs = [segment(s, normalise=(mode == "se")) for s in srcs]
+        counts = [s.size(0) for s in segs]
+        seg_src = torch.cat(segs, dim=0)
+        ef, n_enr = None, 0
+        if mode != "se":
+            if enrolls is None or len(enrolls) != len(srcs):
+                raise ValueError(f"{mode} needs one enrollment per utterance")
+            if len({e.size(-1) for e in enrolls}) != 1:
+                raise ValueError("enrollments of one call must have the same length")
+            ef = self.semantic_model(torch.cat(list(enrolls), dim=0))             # [U, N_e, d]
+            n_enr = enrolls[0].size(-1)
+        global_ids, semantic_ids = self._generate(mode, seg_src, counts, ef, n_enr)
+        return self._split(counts, global_ids, semantic_ids)
+
+    def _wave(self, src: torch.Tensor, gids: torch.Tensor, sids: torch.Tensor) -> torch.Tensor:
+        est = self.detokenize(gids.unsqueeze(1), sids).squeeze(1)                 # model.py:192
+        return est.reshape(-1)[: src.size(-1)]
+
+    @torch.no_grad()
+    def enhance(self, mode: str, srcs: Sequence[torch.Tensor], enrolls: Optional[Sequence[torch.Tensor]] = None):
+        """Model.test_step up to the waveform (model.py:170-290).  'se' / 'tse': one tensor [T_i] per utterance
+        (`est.reshape(-1)[:src.size(-1)]`); 'ss': a pair (s1, s2) per utterance - SE on the first 5 s gives the enrollment, then TSE
+        (speaker 1) and rTSE (speaker 2) over all segments (model.py:223-290)."""
         if self.detokenize is None:
-            raise RuntimeError("UniSE.enhance needs a detokenize callable (BiCodec is not part of this package); use enhance_tokens")
-        outs = []
-        for src, (gids, sids) in zip(srcs, self.enhance_tokens(mode, srcs, enrolls)):
-            est = self.detokenize(gids.unsqueeze(1), sids).squeeze(1)
-            outs.append(est.reshape(-1)[: src.size(-1)])
-        return outs
+            raise RuntimeError("UniSE.enhance needs a tokenizer (unified_audio_amd.BiCodecTokenizer) or a detokenize callable; "
+                               "enhance_tokens returns the tokens")
+        if mode == "ss":
+            return self._separate(srcs)
+        return [self._wave(src, g, s) for src, (g, s) in zip(srcs, self.enhance_tokens(mode, srcs, enrolls))]
+
+    def _separate(self, srcs: Sequence[torch.Tensor]):
+        # pass 1 (model.py:224-242): SE on the first 5 s of every mixture (wrap-padded if shorter; no peak normalisation in this mode)
+        heads = []
+        for s in srcs:
+            if s.dim() != 2 or s.size(0) != 1:
+                raise ValueError(f"src must be [1, T] like the reference's batch, got {tuple(s.shape)}")
+            heads.append(s[:, :SEG_LEN] if s.size(-1) > SEG_LEN else wrap_pad(s))
+        head = torch.cat(heads, dim=0)
+        g0, s0 = self._generate("se", head, [1] * len(srcs), None, 0)
+        enroll = self.detokenize(g0.unsqueeze(1), s0).squeeze(1)[:, :SEG_LEN]                      # (U, t)
+        enroll = enroll / (enroll.abs().amax(dim=-1, keepdim=True) + 1e-5) * 0.99                  # model.py:243 (per mixture)
+        ef = self.semantic_model(enroll)
+        # passes 2 and 3 (model.py:249-288): TSE then rTSE over all (un-normalised) segments with the tiled enrollment
+        segs = [segment(s, normalise=False) for s in srcs]
+        counts = [s.size(0) for s in segs]
+        seg_src = torch.cat(segs, dim=0)
+        out = []
+        tse = self._split(counts, *self._generate("tse", seg_src, counts, ef, SEG_LEN))
+        rtse = self._split(counts, *self._generate("rtse", seg_src, counts, ef, SEG_LEN))
+        for src, (g1, s1), (g2, s2) in zip(srcs, tse, rtse):
+            out.append((self._wave(src, g1, s1), self._wave(src, g2, s2)))
+        return out
