@@ -71,7 +71,7 @@ def test_enhance_end_to_end_against_the_oracle_chain(qa_lib, gpu_device):
     ssl_sd = S.synth_state_dict(4, sspec, "wavlm")
     fx = qa.SSLFeatureExtractor(qa.SSLSpec(**{f: getattr(sspec, f) for f in sspec.__dataclass_fields__}), device=gpu_device).load_state_dict(ssl_sd)
     bspec = BR.BiCodecSpec(latent_dim=64, codebook_size=128, codebook_dim=8, spk_latent_dim=32, token_num=32, vocos_dim=32, vocos_inter=64,
-                           vocos_layers=2, gen_channels=256, rates=(8, 5, 4, 2), kernel_sizes=(16, 11, 8, 4))
+                           vocos_layers=2, gen_channels=512, rates=(8, 5, 4, 2), kernel_sizes=(16, 11, 8, 4))
     lspec = L.LMSpec(hidden=256, n_layers=2, n_heads=4, global_size=4096, semantic_size=128, feats_dim=96)
     lm_sd = L.lm_state_dict(8, lspec)
     lm = qa.LLM_SFT(feats_dim=96, llm_base_config=dict(global_size=4096, semantic_size=128, hidden_size=256, num_layers=2,
