@@ -258,6 +258,44 @@ def lm_bench(dev, rank, world, dist, batch, reps=2, task="se", n_enroll=0):
                        "dtype": "f32"}}
 
 
+def bicodec_bench(dev, batch, reps=3):
+    """Last stage of Model.test_step (model.py:193): BiCodec.detokenize of `batch` 5 s segments (250 semantic + 32 global tokens each),
+    published Spark-TTS BiCodec shapes, seeded weights, tokens resident in HBM."""
+    import unified_audio_amd as qa
+    from unified_audio_amd import synth
+
+    spec = synth.BiCodecShapes()
+    sd = synth.bicodec_state_dict(77, spec)
+    n_params = sum(v.numel() for v in sd.values())
+    m = qa.BiCodec(device=dev).load_state_dict(sd)
+    del sd
+    sem, glob = synth.bicodec_tokens(78, batch, 250, spec)
+    sem, glob = sem.to(dev), glob.to(dev)
+    wav = m.detokenize(sem, glob)
+    torch.cuda.synchronize(dev)
+    assert torch.isfinite(wav).all()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        wav = m.detokenize(sem, glob)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / reps
+    # contraction FLOPs per 5 s segment: wave generator (ConvTranspose1d + 3 residual units of k7 + k1 per block) + prenet
+    fl, ch, T = 0.0, 1536, 250
+    fl += 2.0 * T * 1024 * 1536 * 7
+    for k, s in zip((16, 11, 8, 4), (8, 5, 4, 2)):
+        co = ch // 2
+        fl += 2.0 * T * ch * co * k            # every input frame meets every tap once
+        T *= s
+        fl += 3 * 2.0 * T * co * co * 8        # k7 + k1
+        ch = co
+    fl += 2.0 * T * ch * 7
+    fl += 250 * (2.0 * 1024 * 384 * 2 + 3 * 2.0 * 384 * 384 * 7 + 16 * 2.0 * 2 * 384 * 2048)
+    return {"metric": "audio-seconds/sec BiCodec.detokenize", "value": batch * 5.0 / dt, "unit": "audio-seconds/sec", "ms_per_pass": 1e3 * dt,
+            "tflops": batch * fl / dt / 1e12,
+            "config": {"workload": f"BiCodec detokenizer ({n_params / 1e6:.0f} M parameters on the decode side, seeded random weights), {batch} segments x "
+                                   f"250 semantic + 32 global tokens -> {batch} x 80 000 samples @16 kHz", "dtype": "f32"}}
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -452,6 +490,7 @@ def main():
             ssl_line = ssl_bench(dev, args.model, B, args.seconds)
             if lm_line is not None:  # UniSE's own front-end (Model.extract_semantic_features): WavLM on the LM's 16 x 5 s segments
                 lm_line["ssl_frontend"] = ssl_bench(dev, "unise", args.lm_batch, 5.0)
+                lm_line["bicodec_detokenize"] = bicodec_bench(dev, args.lm_batch)
         except Exception as e:  # secondary: never take the headline line down with it
             ssl_line = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
 
@@ -525,12 +564,15 @@ def main():
                 log("LM cpu baseline ...")
                 lm_line["cpu_baseline"] = lm_cpu_baseline()
             fe = lm_line.get("ssl_frontend")
-            if fe and "ms_per_pass" in fe:  # BASELINE configs[2] up to the tokens: WavLM features -> AR-LM token generation, B = 16
-                tot = (fe["ms_per_pass"] + lm_line["ms_per_generate"]) * 1e-3
-                lm_line["end_to_end_sr_b16"] = {"value": args.lm_batch * 283 / tot, "unit": "tokens/sec", "ms": 1e3 * tot,
-                                                "audio_seconds_per_sec": args.lm_batch * 5.0 / tot,
-                                                "note": "WavLM front-end + LLM_SFT.generate on the same 16 x 5 s segments (codec decode of the "
-                                                        "tokens is BiCodec in the reference, SURVEY 8f-2)"}
+            bd = lm_line.get("bicodec_detokenize")
+            if fe and "ms_per_pass" in fe:  # BASELINE configs[2]: WavLM features -> AR-LM token generation -> codec decode, B = 16
+                parts = {"wavlm_ms": fe["ms_per_pass"], "lm_generate_ms": lm_line["ms_per_generate"],
+                         "bicodec_detokenize_ms": bd["ms_per_pass"] if bd and "ms_per_pass" in bd else None}
+                tot = sum(v for v in parts.values() if v is not None) * 1e-3
+                lm_line["end_to_end_b16"] = {"value": args.lm_batch * 5.0 / tot, "unit": "audio-seconds/sec", "ms": 1e3 * tot, "stages": parts,
+                                             "tokens_per_sec": args.lm_batch * 283 / tot,
+                                             "note": "Model.test_step 'se' on 16 x 5 s segments: WavLM front-end + LLM_SFT.generate + BiCodec.detokenize "
+                                                     "(the codec decode the reference's test.py uses, model.py:193), stages timed back to back"}
             line["unise_lm"] = lm_line
         if extras:
             line["extras"] = extras
