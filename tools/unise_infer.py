@@ -42,7 +42,7 @@ def main():
         lm_sd = ck.get("state_dict", ck)
         ssl_sd = torch.load(a.wavlm, map_location="cpu")
         bic = qa.BiCodec.load_from_checkpoint(a.bicodec, device=dev)
-    lm = qa.LLM_SFT(device=dev).load_state_dict({k: v for k, v in lm_sd.items() if k.startswith("dnn.") or "." in k})
+    lm = qa.LLM_SFT(device=dev).load_state_dict(lm_sd)  # `dnn.` prefix stripped, other entries ignored
     fx = qa.SSLFeatureExtractor(qa.SPEC_WAVLM_BASE_PLUS, device=dev).load_state_dict(ssl_sd)
     drv = UniSE(lm, fx, tokenizer=qa.BiCodecTokenizer(model=bic))
     srcs = [audio_io.load_audio(p, 16000, dev) for p in a.wavs]
