@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QA_VERSION 101 /* 0.1.1 */
+#define QA_VERSION 102 /* 0.1.1 */
 
 typedef enum qa_status {
     QA_OK = 0,
@@ -91,6 +91,11 @@ typedef struct qa_hcodec_spec {
     int32_t enc_convnext_layers; /* 24 */
     int32_t frame_stride;     /* 4 = int(50 / target_frame_rate) */
     int32_t tr_inter_cap;     /* 4096: transformer MLP width = min(4*d, cap); 0 = 4*d */
+    /* causal variant of the SEANet-family graph (versions 0 / 10, with or without `adaptive`): every SConv1d pads
+     * (k_eff - stride, extra) instead of splitting it (encoder_modules/conv.py:203-206), vq/conv.py's Conv1d /
+     * ConvTranspose1d pad (k - 1, 0) (vq/conv.py:44-47,76-79) and both Transformers apply the tril mask
+     * (encoder_modules/transformer.py:470-475).  vq/codec.py:31 ships causal=False. */
+    int32_t causal;
 } qa_hcodec_spec;
 
 typedef struct qa_hcodec qa_hcodec;

@@ -26,9 +26,17 @@ CASES = [
 ]
 
 
-def run_case(name, seed, head_bias, batch, samples):
+CASES_CAUSAL = [  # the reference's own encoder / decoder classes built with causal=True (ref_shim.make_causal_10)
+    ("hcodec10_b2_causal", 4321, 1.5, 2, 640 * 9 + 77),
+]
+
+
+def run_case(name, seed, head_bias, batch, samples, causal=False):
     sd = synth.hcodec10_state_dict(seed, head_logmag_bias=head_bias)
-    model = ref_shim.load_state(ref_shim.load_reference_codec("1.0"), sd)
+    model = ref_shim.load_reference_codec("1.0")
+    if causal:
+        model = ref_shim.make_causal_10(model)
+    model = ref_shim.load_state(model, sd)
     wav = R.pad_wav(synth.synth_wav(seed + 1, batch, samples))  # HCodecTokenizer.pad_wav
     feat = synth.synth_feat(seed + 2, batch, wav.shape[-1] // 320)
     with torch.no_grad():
@@ -38,7 +46,7 @@ def run_case(name, seed, head_bias, batch, samples):
         rec = model.decode(ac, sc)
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"),
-        seed=seed, head_bias=head_bias, batch=batch, samples=samples,
+        seed=seed, head_bias=head_bias, batch=batch, samples=samples, causal=int(causal),
         acoustic_codes=ac.numpy().astype(np.int16), semantic_codes=sc.numpy().astype(np.int16),
         wav_rec=rec.numpy().astype(np.float32),
         emb_sample=emb[:, ::37, ::3].numpy().astype(np.float32), sem_sample=sem[:, ::37, ::3].numpy().astype(np.float32),
@@ -102,6 +110,8 @@ def main():
     run_case_20("hcodec20_small_b2", 2000, 2, 3840 * 5 + 1000)
     for c in CASES:
         run_case(*c)
+    for c in CASES_CAUSAL:
+        run_case(*c, causal=True)
     for c in CASES_15:
         run_case_15(*c)
 

@@ -62,6 +62,9 @@ class HCodecSpec:
     bt_ff: int = 2048
     threshold: float = 0.6  # manual_threshold
     max_tokens_per_group: int = 8
+    # causal=True: the variant every block parameterises (SConv1d conv.py:203-206, Conv1d / ConvTranspose1d vq/conv.py:44-47,76-79,
+    # Transformer transformer.py:470-475); vq/codec.py:31 hard-codes False, so only reference MODULES built with causal=True pin it
+    causal: bool = False
 
     @property
     def enc_hop(self) -> int:
@@ -102,27 +105,30 @@ def _pad1d_reflect(x: Tensor, left: int, right: int) -> Tensor:
     return y[..., : y.shape[-1] - extra]
 
 
-def sconv1d(x: Tensor, w: Tensor, b: Optional[Tensor], stride: int, dilation: int = 1) -> Tensor:
-    """Non-causal SConv1d.forward, encoder_modules/conv.py:195-211."""
+def sconv1d(x: Tensor, w: Tensor, b: Optional[Tensor], stride: int, dilation: int = 1, causal: bool = False) -> Tensor:
+    """SConv1d.forward, encoder_modules/conv.py:195-211 (causal: the whole padding goes to the left, :203-206)."""
     k = w.shape[-1]
     k_eff = (k - 1) * dilation + 1
     padding_total = k_eff - stride
     extra = _extra_padding(x.shape[-1], k_eff, stride, padding_total)
-    right = padding_total // 2
-    left = padding_total - right
-    x = _pad1d_reflect(x, left, right + extra)
+    if causal:
+        x = _pad1d_reflect(x, padding_total, extra)
+    else:
+        right = padding_total // 2
+        left = padding_total - right
+        x = _pad1d_reflect(x, left, right + extra)
     return F.conv1d(x, w, b, stride=stride, dilation=dilation)
 
 
-def _wn_sconv(sd: SD, p: str, x: Tensor, stride: int = 1) -> Tensor:
-    return sconv1d(x, _fold_weight_norm(sd, p + ".conv.conv"), sd[p + ".conv.conv.bias"], stride)
+def _wn_sconv(sd: SD, p: str, x: Tensor, stride: int = 1, causal: bool = False) -> Tensor:
+    return sconv1d(x, _fold_weight_norm(sd, p + ".conv.conv"), sd[p + ".conv.conv.bias"], stride, causal=causal)
 
 
-def seanet_resblock(sd: SD, p: str, x: Tensor) -> Tensor:
+def seanet_resblock(sd: SD, p: str, x: Tensor, causal: bool = False) -> Tensor:
     """SEANetResnetBlock.forward, seanet.py:34-76: shortcut_1x1(x) + 1x1(ELU(k3(ELU(x))))."""
-    h = _wn_sconv(sd, p + ".block.1", F.elu(x))
-    h = _wn_sconv(sd, p + ".block.3", F.elu(h))
-    return _wn_sconv(sd, p + ".shortcut", x) + h
+    h = _wn_sconv(sd, p + ".block.1", F.elu(x), causal=causal)
+    h = _wn_sconv(sd, p + ".block.3", F.elu(h), causal=causal)
+    return _wn_sconv(sd, p + ".shortcut", x, causal=causal) + h
 
 
 # ----------------------------------------------------------------------------- transformer (+LSTM)
@@ -159,9 +165,10 @@ def _rotate_half(x: Tensor) -> Tensor:  # transformer.py:211-215
     return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
 
 
-def attention_block(sd: SD, p: str, x: Tensor, n_heads: int, taps=None) -> Tensor:
+def attention_block(sd: SD, p: str, x: Tensor, n_heads: int, taps=None, causal: bool = False, left_context: int = 0) -> Tensor:
     """Attention.forward, transformer.py:121-180: LSTM -> q/k/v (+bias) -> rotate-half RoPE ->
-    softmax(QK^T * d^-0.5) in fp32 -> O (no bias).  Non-causal: mask is None (transformer.py:469-475)."""
+    softmax(QK^T * d^-0.5) in fp32 -> O (no bias).  Non-causal: mask is None; causal: tril mask, with left_context > 0 the
+    sliding window tril * triu(-left_context + 1) (transformer.py:437-475, added as a -inf bias :169-175)."""
     b, n, d = x.shape
     hd = d // n_heads
     x = lstm_forward(x, sd[p + ".rnn.weight_ih_l0"], sd[p + ".rnn.weight_hh_l0"],
@@ -175,17 +182,22 @@ def attention_block(sd: SD, p: str, x: Tensor, n_heads: int, taps=None) -> Tenso
     q = q * cos + _rotate_half(q) * sin
     k = k * cos + _rotate_half(k) * sin
     w = torch.matmul(q, k.transpose(2, 3)) * hd ** -0.5
+    if causal:
+        seen = torch.tril(torch.ones(n, n, dtype=torch.bool))
+        if left_context > 0:
+            seen = seen & torch.triu(torch.ones(n, n, dtype=torch.bool), diagonal=-left_context + 1)
+        w = w + torch.zeros_like(w).masked_fill_(~seen, float("-inf"))
     w = F.softmax(w, dim=-1, dtype=torch.float32)
     o = torch.matmul(w, v).transpose(1, 2).reshape(b, n, d)
     return F.linear(o, sd[p + ".o_proj.weight"])
 
 
-def transformer(sd: SD, p: str, x: Tensor, n_layers: int, n_heads: int, taps=None) -> Tensor:
+def transformer(sd: SD, p: str, x: Tensor, n_layers: int, n_heads: int, taps=None, causal: bool = False, left_context: int = 0) -> Tensor:
     """Transformer.forward / TransformerLayer.forward, transformer.py:338-393,444-489."""
     for i in range(n_layers):
         lp = f"{p}.layers.{i}"
         h = rms_norm(x, sd[lp + ".input_layernorm.weight"])
-        x = x + attention_block(sd, lp + ".self_attn", h, n_heads, taps)
+        x = x + attention_block(sd, lp + ".self_attn", h, n_heads, taps, causal, left_context)
         h = rms_norm(x, sd[lp + ".post_attention_layernorm.weight"])
         h = F.linear(F.silu(F.linear(h, sd[lp + ".mlp.w1.weight"])) * F.linear(h, sd[lp + ".mlp.w3.weight"]),
                      sd[lp + ".mlp.w2.weight"])  # MLP.forward, transformer.py:218-226
@@ -200,19 +212,20 @@ def transformer(sd: SD, p: str, x: Tensor, n_layers: int, n_heads: int, taps=Non
 def seanet_encoder(sd: SD, wav: Tensor, spec: HCodecSpec = SPEC_10, taps=None) -> Tensor:
     """SEANetEncoder.forward, seanet.py:121-187,206-208.  wav [B,1,T] -> emb [B,dimension,N25]."""
     p = "encoder.model"
-    x = _wn_sconv(sd, f"{p}.0", wav)
+    cz = spec.causal
+    x = _wn_sconv(sd, f"{p}.0", wav, causal=cz)
     if taps is not None:
         taps["enc.conv0"] = x
     for i, r in enumerate(spec.ratios):
-        x = seanet_resblock(sd, f"{p}.{1 + 3 * i}", x)
-        x = _wn_sconv(sd, f"{p}.{3 + 3 * i}", F.elu(x), stride=r)
+        x = seanet_resblock(sd, f"{p}.{1 + 3 * i}", x, cz)
+        x = _wn_sconv(sd, f"{p}.{3 + 3 * i}", F.elu(x), stride=r, causal=cz)
         if taps is not None:
             taps[f"enc.stage{i}"] = x
     n = len(spec.ratios)
-    x = transformer(sd, f"{p}.{3 * n + 2}", x.transpose(1, 2), spec.enc_layers, spec.enc_heads, taps).transpose(1, 2)
+    x = transformer(sd, f"{p}.{3 * n + 2}", x.transpose(1, 2), spec.enc_layers, spec.enc_heads, taps, cz).transpose(1, 2)
     if taps is not None:
         taps["enc.transformer"] = x
-    x = _wn_sconv(sd, f"{p}.{3 * n + 5}", F.elu(x), stride=2)
+    x = _wn_sconv(sd, f"{p}.{3 * n + 5}", F.elu(x), stride=2, causal=cz)
     return x
 
 
@@ -276,33 +289,39 @@ def encode(sd: SD, wav: Tensor, feat: Tensor, spec: HCodecSpec = SPEC_10, taps=N
 
 # ----------------------------------------------------------------------------- decode side
 
-def subpixel_upsample(sd: SD, p: str, x: Tensor, stride: int = 2) -> Tensor:
+def _zero_pad(x: Tensor, k: int, causal: bool) -> Tensor:
+    """the ConstantPad1d of vq/conv.py:44-47 (Conv1d, stride 1) and :76-79 (ConvTranspose1d): (k - 1, 0) if causal else (k//2, k//2)"""
+    return F.pad(x, (k - 1, 0) if causal else (k // 2, k // 2))
+
+
+def subpixel_upsample(sd: SD, p: str, x: Tensor, stride: int = 2, causal: bool = False) -> Tensor:
     """vq/conv.py:58-91 ("ConvTranspose1d" = 1x1 conv -> pixel shuffle -> zero-pad -> depthwise k5)."""
     x = F.conv1d(x, sd[p + ".up.weight"], sd[p + ".up.bias"])
     b, _, t = x.shape
     d = x.shape[1] // stride
     x = x.unflatten(1, (stride, d)).permute(0, 2, 3, 1).flatten(-2, -1)  # sample t*stride+j <- block j
     w = sd[p + ".dw.weight"]
-    return F.conv1d(F.pad(x, (w.shape[-1] // 2, w.shape[-1] // 2)), w, sd[p + ".dw.bias"], groups=d)
+    return F.conv1d(_zero_pad(x, w.shape[-1], causal), w, sd[p + ".dw.bias"], groups=d)
 
 
 def _swish(x: Tensor) -> Tensor:
     return x * torch.sigmoid(x)
 
 
-def resnet_block(sd: SD, p: str, x: Tensor, groups: int) -> Tensor:
-    """vq/conv.py:263-304 (eval: dropout off): x + k3(swish(GN(k3(swish(GN(x))))))."""
+def resnet_block(sd: SD, p: str, x: Tensor, groups: int, causal: bool = False) -> Tensor:
+    """vq/conv.py:263-304 (eval: dropout off): x + k3(swish(GN(k3(swish(GN(x)))))).  The GroupNorm is over the whole clip in
+    the causal variant too (the flag only moves the conv padding)."""
     h = F.group_norm(x, groups, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], eps=1e-6)
-    h = F.conv1d(_swish(h), sd[p + ".conv1.conv.weight"], sd[p + ".conv1.conv.bias"], padding=1)
+    h = F.conv1d(_zero_pad(_swish(h), 3, causal), sd[p + ".conv1.conv.weight"], sd[p + ".conv1.conv.bias"])
     h = F.group_norm(h, groups, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], eps=1e-6)
-    h = F.conv1d(_swish(h), sd[p + ".conv2.conv.weight"], sd[p + ".conv2.conv.bias"], padding=1)
+    h = F.conv1d(_zero_pad(_swish(h), 3, causal), sd[p + ".conv2.conv.weight"], sd[p + ".conv2.conv.bias"])
     return x + h
 
 
-def convnext_block(sd: SD, p: str, x: Tensor) -> Tensor:
+def convnext_block(sd: SD, p: str, x: Tensor, causal: bool = False) -> Tensor:
     """vq/conv.py:168-211: dw k7 -> LN -> Linear -> GELU(erf) -> Linear -> *gamma -> +res."""
     c = x.shape[1]
-    h = F.conv1d(F.pad(x, (3, 3)), sd[p + ".dwconv.conv.weight"], sd[p + ".dwconv.conv.bias"], groups=c)
+    h = F.conv1d(_zero_pad(x, 7, causal), sd[p + ".dwconv.conv.weight"], sd[p + ".dwconv.conv.bias"], groups=c)
     h = F.layer_norm(h.transpose(1, 2), (c,), sd[p + ".norm.weight"], sd[p + ".norm.bias"], eps=1e-6)
     h = F.linear(h, sd[p + ".pwconv1.linear.weight"], sd[p + ".pwconv1.linear.bias"])
     h = F.linear(F.gelu(h), sd[p + ".pwconv2.linear.weight"], sd[p + ".pwconv2.linear.bias"])
@@ -333,25 +352,26 @@ def istft_head(sd: SD, x: Tensor, n_fft: int, hop: int, taps=None) -> Tensor:
 def codec_decoder(sd: SD, x: Tensor, spec: HCodecSpec = SPEC_10, taps=None) -> Tensor:
     """CodecDecoder.forward, vq/codec_decoder.py:58-67."""
     p = "decoder"
-    x = subpixel_upsample(sd, p + ".embed", x)
+    cz = spec.causal
+    x = subpixel_upsample(sd, p + ".embed", x, causal=cz)
     if taps is not None:
         taps["dec.embed"] = x
-    x = resnet_block(sd, p + ".prior_net.0", x, spec.gn_groups)
-    x = resnet_block(sd, p + ".prior_net.1", x, spec.gn_groups)
+    x = resnet_block(sd, p + ".prior_net.0", x, spec.gn_groups, cz)
+    x = resnet_block(sd, p + ".prior_net.1", x, spec.gn_groups, cz)
     if taps is not None:
         taps["dec.prior_res1"] = x
-    x = transformer(sd, p + ".prior_net.3", x.transpose(1, 2), spec.dec_layers, spec.dec_heads, taps).transpose(1, 2)
+    x = transformer(sd, p + ".prior_net.3", x.transpose(1, 2), spec.dec_layers, spec.dec_heads, taps, cz).transpose(1, 2)
     if taps is not None:
         taps["dec.transformer"] = x
-    x = resnet_block(sd, p + ".prior_net.5", x, spec.gn_groups)
-    x = resnet_block(sd, p + ".prior_net.6", x, spec.gn_groups)
+    x = resnet_block(sd, p + ".prior_net.5", x, spec.gn_groups, cz)
+    x = resnet_block(sd, p + ".prior_net.6", x, spec.gn_groups, cz)
     x = F.group_norm(x, spec.gn_groups, sd[p + ".prior_net.7.weight"], sd[p + ".prior_net.7.bias"], eps=1e-6)
     c = x.shape[1]
     x = F.layer_norm(x.transpose(1, 2), (c,), sd[p + ".norm.weight"], sd[p + ".norm.bias"], eps=1e-6).transpose(1, 2)
     if taps is not None:
         taps["dec.prior"] = x
     for i in range(spec.convnext_layers):
-        x = convnext_block(sd, f"{p}.post_net.{i}", x)
+        x = convnext_block(sd, f"{p}.post_net.{i}", x, cz)
     x = F.layer_norm(x.transpose(1, 2), (c,), sd[p + ".final_layer_norm.weight"],
                      sd[p + ".final_layer_norm.bias"], eps=1e-6)
     if taps is not None:

@@ -92,6 +92,24 @@ def load_reference_codec(version: str = "1.0", spec=None):
     return model.eval()
 
 
+def make_causal_10(model):
+    """Swap the H-Codec 1.0 encoder / decoder for the reference's OWN classes built with causal=True.  vq/codec.py:30-47
+    hard-codes causal=False, but every block takes the flag (seanet.py:107, codec_decoder.py:23); the constructor arguments
+    below are codec.py's with that one flag flipped, so the parameters (and state-dict keys) are identical."""
+    import sys
+
+    vq_codec = sys.modules[type(model).__module__]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model.encoder = vq_codec.CodecEncoder(
+            causal=True, n_residual_layers=1, norm='weight_norm', pad_mode='reflect', lstm=2,
+            dimension=512, channels=1, n_filters=32, ratios=[8, 5, 4, 2], activation='ELU',
+            kernel_size=7, residual_kernel_size=3, last_kernel_size=7, dilation_base=2,
+            true_skip=False, compress=2, use_transformer=True)
+        model.decoder = vq_codec.CodecDecoder(input_channels=512 * 2, dim=768, intermediate_dim=2304, causal=True)
+    return model.eval()
+
+
 def load_state(model, sd, strict_subset: bool = True):
     """Load a synth state_dict; keys the synth generator leaves out (training-only semantic_decoder.*)
     keep their random init."""

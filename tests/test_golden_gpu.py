@@ -1,4 +1,5 @@
 """HIP path against the committed golden vectors produced by the reference's own modules (tests/golden, oracle/gen_golden.py)."""
+import dataclasses
 import glob
 import os
 
@@ -21,7 +22,9 @@ def test_hip_path_reproduces_reference_golden(qa_lib, gpu_device, path):
     g = np.load(path)
     seed = int(g["seed"])
     sd = synth.hcodec10_state_dict(seed, head_logmag_bias=float(g["head_bias"]))
-    tok = qa.HCodecTokenizer(state_dict=sd, device=gpu_device)
+    causal = bool(int(g["causal"])) if "causal" in g.files else False  # hcodec10_b2_causal: the reference's blocks built causal=True
+    ospec = dataclasses.replace(R.SPEC_10, causal=causal)
+    tok = qa.HCodecTokenizer(state_dict=sd, device=gpu_device, spec=qa.HCodecSpec(causal=causal))
     wav = synth.synth_wav(seed + 1, int(g["batch"]), int(g["samples"]))  # un-padded: tokenize() pads like the reference
     padded = R.pad_wav(wav)
     feat = synth.synth_feat(seed + 2, int(g["batch"]), padded.shape[-1] // 320)
@@ -33,7 +36,7 @@ def test_hip_path_reproduces_reference_golden(qa_lib, gpu_device, path):
     # RVQ inputs the audit judges on are the oracle's, whose codes are the golden ones bit for bit (tests/test_oracle_cpu.py)
     taps = {}
     with torch.no_grad():
-        ac_o, sc_o = R.encode(sd, padded.unsqueeze(1), feat, taps=taps)
+        ac_o, sc_o = R.encode(sd, padded.unsqueeze(1), feat, ospec, taps=taps)
     assert torch.equal(ac_o, ref_ac) and torch.equal(sc_o, ref_sc)
     audit_codes_bnq(taps["enc.emb"], R.rvq_codebooks(sd, "quantizer", 4), ac, ref_ac)
     audit_codes_bnq(taps["enc.sem"], R.rvq_codebooks(sd, "semantic_quantizer", 4), sc, ref_sc)

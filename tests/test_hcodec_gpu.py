@@ -73,6 +73,37 @@ def test_mini_codec_parity(qa_lib, gpu_device):
     assert wav_g.shape == wav_o.shape
 
 
+def test_causal_variant_parity_and_no_lookahead(qa_lib, gpu_device):
+    """spec.causal (the causal= flags of conv.py:39-47 / transformer.py:432-475): stage-by-stage against the oracle,
+    whose causal graph is pinned to the reference's own blocks built with causal=True (tests/test_oracle_cpu.py), and the property
+    that makes it streamable: frames before a changed tail do not move."""
+    kw = dict(MINI, causal=True)
+    report, agree, (wav_g, wav_o) = _run_parity(kw, B=3, T=16 * 40, device=gpu_device)
+    print(report, agree)
+    bad = {k: v for k, v in report.items() if not v < STAGE_TOL}
+    assert not bad, bad
+    assert min(agree) > 0.98
+    ospec, sd, codec = _make(kw, 11, gpu_device)
+    hop = ospec.enc_hop
+    wav = synth.synth_wav(21, 2, hop * 24)
+    wav2 = wav.clone()
+    wav2[:, -hop * 4:] = synth.synth_wav(22, 2, hop * 4)
+    feat = synth.synth_feat(23, 2, wav.shape[-1] // (hop // 2), ospec.sem_in)
+    codec.encode(wav.to(gpu_device).unsqueeze(1), feat.to(gpu_device))
+    e1 = codec.tap("enc.emb").view(2, -1, ospec.code_dim).clone()
+    codec.encode(wav2.to(gpu_device).unsqueeze(1), feat.to(gpu_device))
+    e2 = codec.tap("enc.emb").view(2, -1, ospec.code_dim)
+    keep = 24 - 4 - 1  # the last window before the change still reflects into it (extra right padding only at the end)
+    assert torch.equal(e1[:, :keep], e2[:, :keep])
+    assert not torch.equal(e1[:, keep + 2:], e2[:, keep + 2:])
+    # and the non-causal graph does look ahead
+    _, _, nc = _make(dict(MINI), 11, gpu_device)
+    nc.encode(wav.to(gpu_device).unsqueeze(1), feat.to(gpu_device))
+    n1 = nc.tap("enc.emb").view(2, -1, ospec.code_dim).clone()
+    nc.encode(wav2.to(gpu_device).unsqueeze(1), feat.to(gpu_device))
+    assert not torch.equal(n1[:, :keep], nc.tap("enc.emb").view(2, -1, ospec.code_dim)[:, :keep])
+
+
 def test_hcodec10_full_size_parity(qa_lib, gpu_device):
     """The real H-Codec 1.0 architecture (141 M parameters) on 2 clips x 2 s (+ragged pad), seeded weights."""
     spec_kwargs = {f: getattr(R.SPEC_10, f) for f in R.SPEC_10.__dataclass_fields__}

@@ -1,5 +1,6 @@
 """Pins the CPU oracle: against the reference's own modules (where /root/reference exists), against the committed golden
 vectors (everywhere), and the C / torch RVQ restatements against each other."""
+import dataclasses
 import glob
 import os
 
@@ -27,9 +28,10 @@ def test_oracle_reproduces_reference_golden(path):
     wav = R.pad_wav(synth.synth_wav(seed + 1, int(g["batch"]), int(g["samples"])))
     feat = synth.synth_feat(seed + 2, int(g["batch"]), wav.shape[-1] // 320)
     taps = {}
+    spec = dataclasses.replace(R.SPEC_10, causal=bool(int(g["causal"])) if "causal" in g.files else False)
     with torch.no_grad():
-        ac, sc = R.encode(sd, wav.unsqueeze(1), feat, taps=taps)
-        rec = R.decode(sd, ac, sc)
+        ac, sc = R.encode(sd, wav.unsqueeze(1), feat, spec, taps=taps)
+        rec = R.decode(sd, ac, sc, spec)
     assert np.array_equal(ac.numpy(), g["acoustic_codes"].astype(np.int64))
     assert np.array_equal(sc.numpy(), g["semantic_codes"].astype(np.int64))
     np.testing.assert_allclose(taps["enc.emb"][:, ::37, ::3].numpy(), g["emb_sample"], rtol=0, atol=2e-5)
@@ -37,6 +39,35 @@ def test_oracle_reproduces_reference_golden(path):
     err = float(np.sqrt(np.mean((rec.numpy() - g["wav_rec"]) ** 2)) / np.sqrt(np.mean(g["wav_rec"] ** 2)))
     assert err < 1e-5, err
     assert rec.shape[-1] == wav.shape[-1]  # length rule len_out = ceil(len_in / hop) * hop
+
+
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference is only mounted in the build container")
+def test_causal_restatement_matches_reference_modules():
+    """spec.causal against the reference's own encoder / decoder classes constructed with causal=True (the flag every block
+    takes); a causal graph must also differ from the non-causal one and must not look ahead."""
+    sd = synth.hcodec10_state_dict(4322)
+    model = ref_shim.load_state(ref_shim.make_causal_10(ref_shim.load_reference_codec("1.0")), sd)
+    spec = dataclasses.replace(R.SPEC_10, causal=True)
+    wav = R.pad_wav(synth.synth_wav(15, 2, 640 * 6 + 200))
+    feat = synth.synth_feat(16, 2, wav.shape[-1] // 320)
+    with torch.no_grad():
+        emb_r = model.encoder(wav.unsqueeze(1))
+        emb = R.seanet_encoder(sd, wav.unsqueeze(1), spec)
+        assert float((emb - emb_r).abs().max()) < 2e-5 * float(emb_r.abs().max())
+        ac_r, sc_r = model.encode(wav.unsqueeze(1), feat)
+        ac, sc = R.encode(sd, wav.unsqueeze(1), feat, spec)
+        assert torch.equal(ac, ac_r) and torch.equal(sc, sc_r)
+        w_r, w = model.decode(ac_r, sc_r), R.decode(sd, ac_r, sc_r, spec)
+        assert float((w - w_r).abs().max()) < 1e-5 * float(w_r.abs().max())
+        assert not torch.equal(ac, R.encode(sd, wav.unsqueeze(1), feat)[0])
+        # no look-ahead in the SEANet encoder + causal transformer: changing the last second leaves earlier frames unchanged
+        wav2 = wav.clone()
+        wav2[:, -1600:] = 0.3 * torch.randn(2, 1600, generator=torch.Generator().manual_seed(3))
+        emb2 = R.seanet_encoder(sd, wav2.unsqueeze(1), spec)
+        keep = (wav.shape[-1] - 1600) // 640
+        # (the reflect padding of the LAST window is the only right-side dependence and lies inside the changed region)
+        assert torch.equal(emb[..., :keep - 1], emb2[..., :keep - 1])
+        assert not torch.equal(emb[..., keep + 1:], emb2[..., keep + 1:])
 
 
 @pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference is only mounted in the build container")

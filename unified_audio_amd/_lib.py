@@ -34,7 +34,7 @@ class qa_hcodec_spec(C.Structure):
         ("bt_layers", C.c_int32), ("bt_heads", C.c_int32), ("bt_ff", C.c_int32), ("max_tokens_per_group", C.c_int32),
         ("threshold", C.c_float),
         ("version", C.c_int32), ("enc_dim", C.c_int32), ("enc_inter", C.c_int32), ("enc_convnext_layers", C.c_int32),
-        ("frame_stride", C.c_int32), ("tr_inter_cap", C.c_int32),
+        ("frame_stride", C.c_int32), ("tr_inter_cap", C.c_int32), ("causal", C.c_int32),
     ]
 
 

@@ -35,9 +35,10 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
 }
 
 int launch_conv_in(const float* x, const float* w_kc, const float* bias, float* y, int B, int T, int Cout, int ksize,
-                   hipStream_t s) {
-    QA_REQUIRE(Cout % 4 == 0, "conv_in: Cout=%d must be a multiple of 4", Cout);
-    const int pad_total = ksize - 1, right = pad_total / 2, left = pad_total - right;
+                   hipStream_t s, int pad_left) {
+    QA_REQUIRE(Cout % 4 == 0 && pad_left < ksize, "conv_in: Cout=%d must be a multiple of 4 (pad_left %d, ksize %d)", Cout, pad_left, ksize);
+    const int pad_total = ksize - 1;
+    const int left = pad_left >= 0 ? pad_left : pad_total - pad_total / 2, right = pad_total - left;
     const int max_pad = left > right ? left : right;
     const int Lp = (T <= max_pad) ? max_pad + 1 : T;
     const long long total = (long long)B * T * (Cout / 4);
@@ -131,12 +132,11 @@ template <bool LN>
 __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, const float* __restrict__ lnw,
                                                      const float* __restrict__ lnb, float* __restrict__ y, int B, int T,
-                                                     int C, int ksize, float eps) {
+                                                     int C, int ksize, float eps, int pad) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (long long)B * T) return;
     const int b = (int)(row / T), t = (int)(row - (long long)b * T);
-    const int pad = ksize / 2;
     const float* xb = x + (long long)b * T * C;
     float4 v[MAX_V4];
     float s = 0.f;
@@ -190,15 +190,17 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
 }
 
 int launch_dwconv(const float* x, const float* w_kc, const float* bias, const float* lnw, const float* lnb, float* y,
-                  int B, int T, int C, int ksize, float eps, hipStream_t s) {
-    QA_REQUIRE(C % 4 == 0 && C <= 256 * MAX_V4 && (ksize & 1), "dwconv: C=%d ksize=%d unsupported", C, ksize);
+                  int B, int T, int C, int ksize, float eps, hipStream_t s, int pad_left) {
+    QA_REQUIRE(C % 4 == 0 && C <= 256 * MAX_V4 && (ksize & 1) && pad_left < ksize, "dwconv: C=%d ksize=%d pad_left=%d unsupported", C,
+               ksize, pad_left);
     const unsigned grid = (unsigned)ceil_div((long long)B * T, 4);
+    const int pad = pad_left >= 0 ? pad_left : ksize / 2;
     if (lnw)
         hipLaunchKernelGGL(dwconv_kernel<true>, dim3(grid), dim3(256), 0, s, x, w_kc, bias, lnw, lnb, y, B, T, C, ksize,
-                           eps);
+                           eps, pad);
     else
         hipLaunchKernelGGL(dwconv_kernel<false>, dim3(grid), dim3(256), 0, s, x, w_kc, bias, lnw, lnb, y, B, T, C,
-                           ksize, eps);
+                           ksize, eps, pad);
     QA_LAUNCH_CHECK();
     return QA_OK;
 }

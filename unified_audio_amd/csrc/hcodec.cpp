@@ -333,24 +333,31 @@ int linear_op(Ctx& c, const float* x, int64_t rows, const ConvW& w, float* y, in
 
 // "same" zero-padded stride-1 conv (vq/conv.py:33-56, semantic_module.py:28-31)
 int conv_same(Ctx& c, const float* x, int B, int T, const ConvW& w, float* y, int prologue = ACT_NONE,
-              int act = ACT_NONE, const float* res = nullptr) {
+              int act = ACT_NONE, const float* res = nullptr, bool causal = false) {
     const int pad = (w.ksize - 1) / 2;
-    return conv_op(c, x, w.C_in, B, T, w, y, w.N, T, 1, pad, pad, PAD_ZERO, prologue, act, nullptr, res, w.N, nullptr,
-                   ACT_NONE);
+    return conv_op(c, x, w.C_in, B, T, w, y, w.N, T, 1, causal ? w.ksize - 1 : pad, causal ? 0 : pad, PAD_ZERO, prologue, act,
+                   nullptr, res, w.N, nullptr, ACT_NONE);
 }
 
 // SConv1d geometry (encoder_modules/conv.py:195-211, non-causal): returns T_out and the paddings
 struct SGeom {
     int T_out, left, right;
 };
-SGeom sconv_geom(int L, int k, int stride) {
+SGeom sconv_geom(int L, int k, int stride, bool causal = false) {
     int64_t t = 0;
     int32_t left = 0, right = 0;
     (void)qa_sconv_geometry(L, k, stride, &t, &left, &right);
+    if (causal) {  // conv.py:203-206: pad (padding_total, extra_padding)
+        right -= (k - stride) / 2;
+        left = k - stride;
+    }
     return {(int)t, left, right};
 }
+// zero padding of vq/conv.py's Conv1d (stride 1, :44-47): (k - 1, 0) if causal else (k / 2, k / 2)
+inline int zpad_left(int k, bool causal) { return causal ? k - 1 : k / 2; }
+inline int zpad_right(int k, bool causal) { return causal ? 0 : k / 2; }
 
-int transformer_op(Ctx& c, const TransformerW& tw, float* x, int B, int N, const std::string& tap_prefix) {
+int transformer_op(Ctx& c, const TransformerW& tw, float* x, int B, int N, const std::string& tap_prefix, bool causal = false) {
     const int d = tw.d, H = tw.heads, hd = d / H;
     const int64_t rows = (int64_t)B * N;
     QA_REQUIRE(N <= MAX_POS, "transformer: sequence of %d frames exceeds %d", N, MAX_POS);
@@ -373,7 +380,7 @@ int transformer_op(Ctx& c, const TransformerW& tw, float* x, int B, int N, const
             QA_TRY(linear_op(c, hl, rows, L.qkv, qkv));
             QA_TRY(launch_rope(qkv, tw.rope, B, N, H, hd, 3 * d, 0, c.stream));
             QA_TRY(launch_attention(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, B, N, N, (long long)N * 3 * d, H, hd,
-                                    1.0f / std::sqrt((float)hd), 0, c.stream));
+                                    1.0f / std::sqrt((float)hd), causal ? 1 : 0, c.stream));
             QA_TRY(linear_op(c, att, rows, L.o, x, ACT_NONE, x));
             QA_TRY(launch_rmsnorm(x, L.ln2, hn, rows, d, 1e-6f, c.stream));
             QA_TRY(linear_op(c, hn, rows, L.w1, big));
@@ -451,24 +458,24 @@ int groupnorm_op(Ctx& c, const float* x, const float* w, const float* b, float* 
     return st;
 }
 
-int dec_resblock_op(Ctx& c, const DecResW& w, float* x, int B, int T, int C, int G) {
+int dec_resblock_op(Ctx& c, const DecResW& w, float* x, int B, int T, int C, int G, bool causal = false) {
     const size_t mark = c.arena.mark();
     float* t1 = c.arena.alloc<float>((size_t)B * T * C);
     float* t2 = c.arena.alloc<float>((size_t)B * T * C);
     QA_TRY(groupnorm_op(c, x, w.n1w, w.n1b, t1, B, T, C, G, 1));
-    QA_TRY(conv_same(c, t1, B, T, w.c1, t2));
+    QA_TRY(conv_same(c, t1, B, T, w.c1, t2, ACT_NONE, ACT_NONE, nullptr, causal));
     QA_TRY(groupnorm_op(c, t2, w.n2w, w.n2b, t1, B, T, C, G, 1));
-    QA_TRY(conv_same(c, t1, B, T, w.c2, x, ACT_NONE, ACT_NONE, x));
+    QA_TRY(conv_same(c, t1, B, T, w.c2, x, ACT_NONE, ACT_NONE, x, causal));
     c.arena.release(mark);
     return QA_OK;
 }
 
 // ---------------------------------------------------------------- encode / decode graphs
 
-int convnext_op(Ctx& c, const ConvNeXtW& w, float* x, float* t1, float* u, int B, int T, int d) {
+int convnext_op(Ctx& c, const ConvNeXtW& w, float* x, float* t1, float* u, int B, int T, int d, bool causal = false) {
     const int64_t rows = (int64_t)B * T;
     if (c.dry) return QA_OK;
-    QA_TRY(launch_dwconv(x, w.dw, w.dwb, w.lnw, w.lnb, t1, B, T, d, 7, 1e-6f, c.stream));
+    QA_TRY(launch_dwconv(x, w.dw, w.dwb, w.lnw, w.lnb, t1, B, T, d, 7, 1e-6f, c.stream, zpad_left(7, causal)));
     QA_TRY(linear_op(c, t1, rows, w.pw1, u, ACT_GELU));
     return linear_op(c, u, rows, w.pw2, x, ACT_NONE, x, nullptr, w.gamma);
 }
@@ -519,8 +526,9 @@ int encode_front(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const flo
     } else {
     // ---- SEANet encoder
     int C = sp.n_filters, L = T;
+    const bool cz = sp.causal != 0;
     float* x = c.arena.alloc<float>((size_t)B * L * C);
-    if (!c.dry) QA_TRY(launch_conv_in(wav, h->conv0_w, h->conv0_b, x, B, L, C, 7, c.stream));
+    if (!c.dry) QA_TRY(launch_conv_in(wav, h->conv0_w, h->conv0_b, x, B, L, C, 7, c.stream, cz ? 6 : -1));
     c.tap("enc.conv0", x, (int64_t)B * L * C);
     for (int i = 0; i < sp.n_ratios; ++i) {
         const int r = sp.ratios[i];
@@ -532,12 +540,12 @@ int encode_front(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const flo
         QA_TRY(conv_op(c, x, C, B, L, rb.sc, sc, C, L, 1, 0, 0, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, nullptr, 0, nullptr,
                        ACT_NONE));
         // ELU(k3(ELU(x)))  (reflect pad 1,1)
-        QA_TRY(conv_op(c, x, C, B, L, rb.k3, hh, rb.k3.N, L, 1, 1, 1, PAD_REFLECT, ACT_ELU, ACT_ELU, nullptr, nullptr, 0,
-                       nullptr, ACT_NONE));
+        QA_TRY(conv_op(c, x, C, B, L, rb.k3, hh, rb.k3.N, L, 1, cz ? 2 : 1, cz ? 0 : 1, PAD_REFLECT, ACT_ELU, ACT_ELU, nullptr,
+                       nullptr, 0, nullptr, ACT_NONE));
         // ELU(shortcut + 1x1(.))  -> the activation in front of the down-sampling conv is fused here
         QA_TRY(conv_op(c, hh, rb.pw.C_in, B, L, rb.pw, sc, C, L, 1, 0, 0, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, sc, C,
                        nullptr, ACT_ELU));
-        const SGeom g = sconv_geom(L, 2 * r, r);
+        const SGeom g = sconv_geom(L, 2 * r, r, cz);
         // the strided conv writes below the mark: allocate its output after releasing the block temporaries is not
         // possible (sc is its input), so the output is carved above them and compacted by pointer swap.
         float* y = c.arena.alloc<float>((size_t)B * g.T_out * 2 * C);
@@ -551,9 +559,9 @@ int encode_front(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const flo
     }
     QA_REQUIRE(C == sp.dimension, "encoder: channel ladder ends at %d, spec.dimension is %d", C, sp.dimension);
     N50 = L;
-    QA_TRY(transformer_op(c, h->enc_tr, x, B, N50, "encoder.model." + std::to_string(3 * sp.n_ratios + 2)));
+    QA_TRY(transformer_op(c, h->enc_tr, x, B, N50, "encoder.model." + std::to_string(3 * sp.n_ratios + 2), cz));
     c.tap("enc.transformer", x, (int64_t)B * N50 * C);
-    const SGeom g = sconv_geom(N50, 4, 2);
+    const SGeom g = sconv_geom(N50, 4, 2, cz);
     N25 = g.T_out;
     emb = c.arena.alloc<float>((size_t)B * N25 * sp.code_dim);
     QA_TRY(conv_op(c, x, C, B, N50, h->enc_out, emb, sp.code_dim, N25, 2, g.left, g.right, PAD_REFLECT, ACT_ELU, ACT_NONE,
@@ -647,6 +655,7 @@ int decode_tail(qa_hcodec* h, Ctx& c, const float* cat, int B, int N, float* wav
     // sub-pixel upsampler: 1x1 conv to 2*d channels; in channel-last layout the pixel shuffle (vq/conv.py:86-88) is a
     // pure reinterpretation [B, N, 2, d] -> [B, 2N, d]
     const bool v20 = sp.version == 20;
+    const bool cz = sp.causal != 0;
     const int N50 = (v20 ? sp.frame_stride : 2) * N;
     const int64_t rows = (int64_t)B * N50;
     float* x = c.arena.alloc<float>(rows * d);
@@ -659,22 +668,22 @@ int decode_tail(qa_hcodec* h, Ctx& c, const float* cat, int B, int N, float* wav
     } else {
         float* up = c.arena.alloc<float>(rows25 * 2 * d);
         QA_TRY(linear_op(c, cat, rows25, h->up, up));
-        if (!c.dry) QA_TRY(launch_dwconv(up, h->up_dw, h->up_dwb, nullptr, nullptr, x, B, N50, d, 5, 0.f, c.stream));
+        if (!c.dry) QA_TRY(launch_dwconv(up, h->up_dw, h->up_dwb, nullptr, nullptr, x, B, N50, d, 5, 0.f, c.stream, zpad_left(5, cz)));
     }
     c.tap("dec.embed", x, rows * d);
-    QA_TRY(dec_resblock_op(c, h->dres[0], x, B, N50, d, sp.gn_groups));
-    QA_TRY(dec_resblock_op(c, h->dres[1], x, B, N50, d, sp.gn_groups));
+    QA_TRY(dec_resblock_op(c, h->dres[0], x, B, N50, d, sp.gn_groups, cz));
+    QA_TRY(dec_resblock_op(c, h->dres[1], x, B, N50, d, sp.gn_groups, cz));
     c.tap("dec.prior_res1", x, rows * d);
-    QA_TRY(transformer_op(c, h->dec_tr, x, B, N50, "decoder.prior_net.3"));
+    QA_TRY(transformer_op(c, h->dec_tr, x, B, N50, "decoder.prior_net.3", cz));
     c.tap("dec.transformer", x, rows * d);
-    QA_TRY(dec_resblock_op(c, h->dres[2], x, B, N50, d, sp.gn_groups));
-    QA_TRY(dec_resblock_op(c, h->dres[3], x, B, N50, d, sp.gn_groups));
+    QA_TRY(dec_resblock_op(c, h->dres[2], x, B, N50, d, sp.gn_groups, cz));
+    QA_TRY(dec_resblock_op(c, h->dres[3], x, B, N50, d, sp.gn_groups, cz));
     float* t1 = c.arena.alloc<float>(rows * d);
     float* u = c.arena.alloc<float>(rows * sp.dec_inter);
     QA_TRY(groupnorm_op(c, x, h->gn_w, h->gn_b, t1, B, N50, d, sp.gn_groups, 0));
     if (!c.dry) QA_TRY(launch_layernorm(t1, h->norm_w, h->norm_b, x, rows, d, 1e-6f, c.stream));
     c.tap("dec.prior", x, rows * d);
-    for (const ConvNeXtW& w : h->cnx) QA_TRY(convnext_op(c, w, x, t1, u, B, N50, d));
+    for (const ConvNeXtW& w : h->cnx) QA_TRY(convnext_op(c, w, x, t1, u, B, N50, d, cz));
     if (!c.dry) QA_TRY(launch_layernorm(x, h->fnorm_w, h->fnorm_b, t1, rows, d, 1e-6f, c.stream));
     c.tap("dec.backbone", t1, rows * d);
     // ISTFT head
@@ -790,6 +799,7 @@ int build(qa_hcodec* h, const HostTable& tab) {
     const bool v20 = sp.version == 20;
     QA_REQUIRE(sp.version == 0 || sp.version == 10 || sp.version == 15 || v20, "spec: unknown version %d", sp.version);
     QA_REQUIRE(!(v20 && sp.adaptive), "spec: H-Codec 2.0 has no adaptive frame rate");
+    QA_REQUIRE(!(v20 && sp.causal), "spec: the causal variant is built for the SEANet family (versions 0 / 10) only");
     QA_REQUIRE(sp.n_sem_strides >= 1 && sp.n_sem_strides <= 4, "spec: bad counts");
     QA_REQUIRE(v20 || (sp.n_ratios >= 1 && sp.n_ratios <= 8 && sp.n_filters % 32 == 0), "spec: bad SEANet ladder");
     QA_REQUIRE((v20 ? sp.enc_dim : sp.dimension) % 128 == 0 && sp.dec_dim % 128 == 0, "spec: transformer widths must be multiples of 128");

@@ -7,13 +7,15 @@
 namespace qa {
 
 // ew.hip
+// pad_left < 0: the non-causal split of SConv1d (left = pad_total - pad_total / 2); causal SConv1d passes ksize - 1
 int launch_conv_in(const float* x, const float* w_kc, const float* bias, float* y, int B, int T, int Cout, int ksize,
-                   hipStream_t s);
+                   hipStream_t s, int pad_left = -1);
 int launch_rmsnorm(const float* x, const float* w, float* y, long long rows, int C, float eps, hipStream_t s);
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, long long rows, int C, float eps,
                      hipStream_t s);
+// pad_left < 0: "same" (ksize / 2 each side); the causal Conv1d of vq/conv.py:44-47 passes ksize - 1
 int launch_dwconv(const float* x, const float* w_kc, const float* bias, const float* lnw, const float* lnb, float* y,
-                  int B, int T, int C, int ksize, float eps, hipStream_t s);
+                  int B, int T, int C, int ksize, float eps, hipStream_t s, int pad_left = -1);
 size_t groupnorm_scratch_bytes(int B, int T, int G);
 int launch_groupnorm(const float* x, const float* w, const float* bias, float* y, double* scratch, int B, int T, int C,
                      int G, float eps, int swish, hipStream_t s);

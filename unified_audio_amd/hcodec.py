@@ -57,6 +57,9 @@ class HCodecSpec:
     enc_convnext_layers: int = 24
     frame_stride: int = 4
     tr_inter_cap: int = 0  # transformer MLP width = min(4 d, cap); 0 = 4 d
+    # the causal variant every block of the SEANet family parameterises (encoder_modules/conv.py:203-206, vq/conv.py:44-47,76-79,
+    # encoder_modules/transformer.py:470-475); vq/codec.py:31 ships False
+    causal: bool = False
 
     @property
     def enc_hop(self) -> int:
@@ -86,6 +89,7 @@ class HCodecSpec:
         s.max_tokens_per_group, s.threshold = self.max_tokens_per_group, self.threshold
         s.version, s.enc_dim, s.enc_inter = self.version, self.enc_dim, self.enc_inter
         s.enc_convnext_layers, s.frame_stride, s.tr_inter_cap = self.enc_convnext_layers, self.frame_stride, self.tr_inter_cap
+        s.causal = int(self.causal)
         return s
 
 
