@@ -96,6 +96,10 @@ typedef struct qa_hcodec_spec {
      * ConvTranspose1d pad (k - 1, 0) (vq/conv.py:44-47,76-79) and both Transformers apply the tril mask
      * (encoder_modules/transformer.py:470-475).  vq/codec.py:31 ships causal=False. */
     int32_t causal;
+    /* H-Codec 1.5: `causal` / `context_frames` of the two aggregators and `causal` / `context` of the bottleneck transformer
+     * (config_adaptive_v3.yaml:84,87,93,96,103,105; the YAML ships causal: false, where the context is ignored,
+     * mimi/transformer.py:403-413).  causal = 1: key j visible to query i iff 0 <= i - j < context (context 0 = unbounded). */
+    int32_t agg_causal, agg_context, bt_causal, bt_context;
 } qa_hcodec_spec;
 
 typedef struct qa_hcodec qa_hcodec;
@@ -248,6 +252,42 @@ int64_t qa_ssl_frames(const qa_ssl* h, int64_t T);
 /* wav float32 [B, T] (device) -> feats float32 [B, frames, hidden] (device, channel-last: what qa_hcodec_encode takes as `feat`
  * with strides (frames*hidden, 1, hidden)) */
 int qa_ssl_forward(qa_ssl* h, const float* wav, int64_t B, int64_t T, float* feats, void* stream);
+
+/* ---- mimi StreamingTransformer: causal / context windows and the streaming state --------------------------
+ * Replaces StreamingTransformer (QuarkAudio-HCodec/HCodec-1.5/adaptive/model_blocks/mimi/transformer.py:605-698) in the
+ * configuration H-Codec 1.5 instantiates it with (:722-736): positional_embedding "rope", norm "layer_norm", gating "none",
+ * LayerScale, no biases.  Weights: `<prefix>.layers.N.{self_attn.in_proj_weight, self_attn.out_proj.weight, norm1.*, norm2.*,
+ * linear1.weight, linear2.weight, layer_scale_1.scale, layer_scale_2.scale}`.
+ *   qa_mimi_forward       forward() outside streaming: no mask unless causal; causal: key j visible to query i iff
+ *                         0 <= i - j < context (context 0 = unbounded)                          (transformer.py:403-413)
+ *   qa_mimi_stream_begin  `with model.streaming(B)` / streaming_forever(B): one RingKVCache of capacity `context` per layer
+ *                         (:212-241,345-370); needs causal = 1 and context > 0 like the reference (:349-353,382)
+ *   qa_mimi_stream_step   forward() inside streaming on a chunk x [B, T, d], T <= context: RoPE at the running offset, the
+ *                         chunk's keys / values written to slots (offset + t) % context BEFORE the queries attend, positions
+ *                         and validity of the slots as RingKVCache.complete() computes them (:243-281) - including its
+ *                         treatment of the slot at the write cursor, which leaves context - 1 visible keys per query
+ *   qa_mimi_stream_reset  reset_streaming(): offsets to zero, cache contents kept but invisible (:239-241)
+ *   qa_mimi_stream_end    leaving the context manager (streaming.py:100-105)
+ * x and y are fp32 [B, T, d_model] device buffers (y may alias x). */
+typedef struct qa_mimi_spec {
+    int32_t d_model;          /* 512 / 1024 */
+    int32_t num_heads;        /* 8 */
+    int32_t num_layers;       /* 32 */
+    int32_t dim_feedforward;  /* 2048 */
+    int32_t causal;           /* config_adaptive_v3.yaml ships false */
+    int32_t context;          /* 16 */
+} qa_mimi_spec;
+typedef struct qa_mimi qa_mimi;
+int qa_mimi_create(qa_mimi** out, const qa_mimi_spec* spec, const qa_tensor* tensors, int64_t n_tensors, const char* prefix,
+                   int device);
+void qa_mimi_destroy(qa_mimi* m);
+int qa_mimi_forward(qa_mimi* m, const float* x, int64_t B, int64_t T, float* y, void* stream);
+int qa_mimi_stream_begin(qa_mimi* m, int64_t B);
+int qa_mimi_stream_step(qa_mimi* m, const float* x, int64_t T, float* y, void* stream);
+int qa_mimi_stream_reset(qa_mimi* m);
+int qa_mimi_stream_end(qa_mimi* m);
+/* tokens seen since begin / reset; -1 outside streaming */
+int64_t qa_mimi_stream_offset(const qa_mimi* m);
 
 /* ---- BiCodec detokenizer ------------------------------------------------------------------------
  * BiCodec.detokenize(semantic_tokens, global_tokens) (QuarkAudio-UniSE/model/bicodec/bicodec.py:182-199), the stage

@@ -29,12 +29,12 @@ SD = Dict[str, Tensor]
 
 # ------------------------------------------------------------------------------- mimi transformer
 
-def rope_interleaved(q: Tensor, k: Tensor, max_period: float = 10000.0) -> Tuple[Tensor, Tensor]:
-    """apply_rope, module/rope.py:13-69 (offset 0, [B,H,T,D] layout): pairs (2i, 2i+1) rotated by t * P^(-2i/D)."""
+def rope_interleaved(q: Tensor, k: Tensor, max_period: float = 10000.0, offset: int = 0) -> Tuple[Tensor, Tensor]:
+    """apply_rope, module/rope.py:13-69 ([B,H,T,D] layout): pairs (2i, 2i+1) rotated by (offset + t) * P^(-2i/D)."""
     b, h, t, d = q.shape
     ds = torch.arange(d // 2, dtype=torch.float32)
     freqs = torch.exp(ds * (-math.log(max_period) * 2 / d))
-    ts = torch.arange(t, dtype=torch.float32).view(1, -1, 1)
+    ts = (float(offset) + torch.arange(t, dtype=torch.float32)).view(1, -1, 1)
     rotr, roti = torch.cos(freqs * ts), torch.sin(freqs * ts)
 
     def rot(x):
@@ -45,24 +45,67 @@ def rope_interleaved(q: Tensor, k: Tensor, max_period: float = 10000.0) -> Tuple
     return rot(q), rot(k)
 
 
-def mimi_transformer(sd: SD, p: str, x: Tensor, n_layers: int, n_heads: int) -> Tensor:
-    """StreamingTransformer.forward (non-streaming, non-causal: attn_bias None, `context` ignored,
-    transformer.py:403-413), positional_embedding='rope', norm='layer_norm' (eps 1e-5), gating='none' (GELU FFN, no
-    biases), LayerScale.  x [B, T, C]."""
+class MimiStreamState:
+    """The streaming state of a StreamingTransformer (`with model.streaming(B)`): one RingKVCache of capacity `context` per layer
+    (mimi/transformer.py:212-281,345-370) and the running offset (:284-293,624-626)."""
+
+    def __init__(self, batch: int, n_layers: int, n_heads: int, head_dim: int, capacity: int):
+        self.capacity = capacity
+        self.cache = [torch.zeros(2, batch, n_heads, capacity, head_dim) for _ in range(n_layers)]
+        self.offset = 0
+
+    def reset(self):  # reset_streaming(): the caches are NOT cleared, `end_offset` alone invalidates them (:239-241)
+        self.offset = 0
+
+    def complete(self, layer: int, k: Tensor, v: Tensor):
+        """RingKVCache.complete (:243-281): write the chunk, return (keys, values, positions [capacity], -1 = never written)."""
+        t = k.shape[2]
+        assert t <= self.capacity
+        idx = (torch.arange(t) + self.offset) % self.capacity
+        self.cache[layer][0].index_copy_(2, idx, k)
+        self.cache[layer][1].index_copy_(2, idx, v)
+        end = self.offset + t
+        slots = torch.arange(self.capacity)
+        delta = slots - end % self.capacity
+        pos = torch.where(delta <= 0, end + delta, end + delta - self.capacity)
+        pos = torch.where(slots >= end, torch.full_like(pos, -1), pos)
+        return self.cache[layer][0], self.cache[layer][1], pos
+
+
+def mimi_transformer(sd: SD, p: str, x: Tensor, n_layers: int, n_heads: int, causal: bool = False, context: int = 0,
+                     state: "MimiStreamState" = None) -> Tensor:
+    """StreamingTransformer.forward, positional_embedding='rope', norm='layer_norm' (eps 1e-5), gating='none' (GELU FFN, no
+    biases), LayerScale.  x [B, T, C].  Non-causal: attn_bias None, `context` ignored (transformer.py:403-413).  causal: key j is
+    visible to query i iff 0 <= i - j < context (context 0 / None = unbounded).  state: the streaming step (`with
+    model.streaming(B)`): RoPE at the running offset, keys / values through the ring caches, offset advanced by T."""
     b, t, c = x.shape
     hd = c // n_heads
+    off = state.offset if state is not None else 0
+    assert state is None or causal, "Streaming only available for causal"  # transformer.py:382
     for i in range(n_layers):
         lp = f"{p}.layers.{i}"
         y = F.layer_norm(x, (c,), sd[lp + ".norm1.weight"], sd[lp + ".norm1.bias"], eps=1e-5)
         proj = F.linear(y, sd[lp + ".self_attn.in_proj_weight"])  # "b t (p h d) -> p b h t d"
         q, k, v = proj.view(b, t, 3, n_heads, hd).permute(2, 0, 3, 1, 4)
-        q, k = rope_interleaved(q, k)
-        a = F.scaled_dot_product_attention(q, k, v, None, dropout_p=0.0)
+        q, k = rope_interleaved(q, k, offset=off)
+        bias = None
+        if state is not None:
+            k, v, pos_k = state.complete(i, k, v)
+        else:
+            pos_k = torch.arange(t)
+        if causal:
+            delta = (off + torch.arange(t)).view(-1, 1) - pos_k.view(1, -1)
+            bias = (pos_k.view(1, -1) >= 0) & (delta >= 0)
+            if context:
+                bias = bias & (delta < context)
+        a = F.scaled_dot_product_attention(q, k, v, bias, dropout_p=0.0)
         a = a.transpose(1, 2).reshape(b, t, c)
         x = x + sd[lp + ".layer_scale_1.scale"] * F.linear(a, sd[lp + ".self_attn.out_proj.weight"])
         y = F.layer_norm(x, (c,), sd[lp + ".norm2.weight"], sd[lp + ".norm2.bias"], eps=1e-5)
         y = F.linear(F.gelu(F.linear(y, sd[lp + ".linear1.weight"])), sd[lp + ".linear2.weight"])
         x = x + sd[lp + ".layer_scale_2.scale"] * y
+    if state is not None:
+        state.offset += t
     return x
 
 
@@ -113,7 +156,8 @@ def query_token_aggregator(sd: SD, p: str, feats: Tensor, align: Tensor, nseg: T
     src_mask = torch.cat([frame_mask, group_mask], dim=1)
     perm = dest.masked_fill(~src_mask, t + g).argsort(dim=1, stable=True)
     inter = torch.gather(src, 2, perm.unsqueeze(1).expand(-1, d, -1))
-    out = mimi_transformer(sd, p + ".transformer.transformer", inter.transpose(1, 2), spec.agg_layers, spec.agg_heads)
+    out = mimi_transformer(sd, p + ".transformer.transformer", inter.transpose(1, 2), spec.agg_layers, spec.agg_heads,
+                           spec.agg_causal, spec.agg_context)
     out = out.transpose(1, 2)
     qpos = perm.argsort(dim=1, stable=True)[:, t:]
     agg = torch.gather(out, 2, qpos.unsqueeze(1).expand(-1, d, -1))
@@ -159,7 +203,7 @@ def decode(sd: SD, acoustic_codes: Tensor, semantic_codes: Tensor, spec: HCodecS
     qa = R.rvq_lookup(ac.transpose(1, 2), R.rvq_codebooks(sd, "quantizer", spec.num_quantizers))
     qs = R.rvq_lookup(sc.transpose(1, 2), R.rvq_codebooks(sd, "semantic_quantizer", spec.num_quantizers))
     cat = torch.cat([qa, qs], dim=2)  # [B, T, 2*code_dim]
-    bt = mimi_transformer(sd, "bottleneck_transformer.transformer", cat, spec.bt_layers, spec.bt_heads)
+    bt = mimi_transformer(sd, "bottleneck_transformer.transformer", cat, spec.bt_layers, spec.bt_heads, spec.bt_causal, spec.bt_context)
     if taps is not None:
         taps["dec.bottleneck"] = bt
     return R.codec_decoder(sd, bt.transpose(1, 2), spec, taps)

@@ -65,6 +65,11 @@ class HCodecSpec:
     # causal=True: the variant every block parameterises (SConv1d conv.py:203-206, Conv1d / ConvTranspose1d vq/conv.py:44-47,76-79,
     # Transformer transformer.py:470-475); vq/codec.py:31 hard-codes False, so only reference MODULES built with causal=True pin it
     causal: bool = False
+    # H-Codec 1.5 stacks: config_adaptive_v3.yaml:84,87,93,96 (aggregators causal / context_frames), :103,105 (bottleneck)
+    agg_causal: bool = False
+    agg_context: int = 16
+    bt_causal: bool = False
+    bt_context: int = 16
 
     @property
     def enc_hop(self) -> int:

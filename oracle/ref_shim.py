@@ -32,8 +32,10 @@ def _config_15(spec):
     ad = cfg["adaptive_config"]
     if spec is not None:  # the reference builds its stacks from this YAML, so smaller test variants are the reference's own code
         for k in ("semantic_aggregator", "acoustic_aggregator"):
-            ad["aggregators"][k].update(num_layers=spec.agg_layers, num_heads=spec.agg_heads, dim_feedforward=spec.agg_ff)
-        ad["transformer_kwargs"].update(num_layers=spec.bt_layers, num_heads=spec.bt_heads, dim_feedforward=spec.bt_ff)
+            ad["aggregators"][k].update(num_layers=spec.agg_layers, num_heads=spec.agg_heads, dim_feedforward=spec.agg_ff,
+                                        causal=spec.agg_causal, context_frames=spec.agg_context)
+        ad["transformer_kwargs"].update(num_layers=spec.bt_layers, num_heads=spec.bt_heads, dim_feedforward=spec.bt_ff,
+                                        causal=spec.bt_causal, context=spec.bt_context)
         ad["manual_threshold"] = spec.threshold
         ad["max_tokens_per_group"] = spec.max_tokens_per_group
     return cfg
@@ -86,6 +88,28 @@ def load_reference_codec(version: str = "1.0", spec=None):
                 cfg = _config_20(spec)
                 model = Codec(cfg["encoder_config"], cfg["decoder_config"], cfg["quantizer_config"],
                               cfg["semantic_encoder_config"], cfg["semantic_decoder_config"])
+    finally:
+        sys.path.remove(_STUBS)
+        sys.path.remove(root)
+    return model.eval()
+
+
+def load_reference_mimi(d_model: int, num_heads: int, num_layers: int, dim_feedforward: int, causal: bool, context: int):
+    """The reference's own StreamingTransformer (HCodec-1.5/adaptive/model_blocks/mimi/transformer.py:605-698) with the keyword
+    arguments QueryTokenAggregator / the bottleneck pass (:722-736): rope, layer_norm, gating none, layer_scale 0.01."""
+    if not reference_available():
+        raise RuntimeError(f"reference tree not found under {REFERENCE_ROOT}")
+    for name in [m for m in sys.modules if m == "vq" or m.startswith("vq.") or m == "adaptive" or m.startswith("adaptive.")]:
+        del sys.modules[name]
+    root = os.path.join(REFERENCE_ROOT, _VERSIONS["1.5"])
+    sys.path[:0] = [_STUBS, root]
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            from adaptive.model_blocks.mimi.transformer import StreamingTransformer  # type: ignore
+            model = StreamingTransformer(d_model=d_model, num_heads=num_heads, num_layers=num_layers, dim_feedforward=dim_feedforward,
+                                         causal=causal, context=context, positional_embedding="rope", max_period=10000,
+                                         layer_scale=0.01, gating="none", norm="layer_norm")
     finally:
         sys.path.remove(_STUBS)
         sys.path.remove(root)

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported_and_bound(qa_lib):
 def test_struct_layouts_match_header(qa_lib):
     from unified_audio_amd import _lib
 
-    assert C.sizeof(_lib.qa_hcodec_spec) == 4 * (31 + 9 + 6 + 1)  # 21 + 9 + 6 + 1 (causal) scalar 4-byte fields, ratios[8] and sem_strides[4] inline
+    assert C.sizeof(_lib.qa_hcodec_spec) == 4 * (31 + 9 + 6 + 5)  # 21 + 9 + 6 + 5 (causal flags / contexts) scalar 4-byte fields, ratios[8] and sem_strides[4] inline
     assert C.sizeof(_lib.qa_tensor) == 24
     assert C.sizeof(_lib.qa_conv_args) == 7 * 8 + 9 * 8 + 9 * 4 + 4  # 9 int32 + tail padding to 8
     assert C.sizeof(_lib.qa_lm_spec) == 40

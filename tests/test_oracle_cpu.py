@@ -172,6 +172,30 @@ def test_restatement15_matches_reference_modules():
     assert float((w - w_r).abs().max()) < 1e-5 * float(w_r.abs().max())
 
 
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference is only mounted in the build container")
+def test_restatement15_causal_stacks_match_reference_modules():
+    """The YAML's `causal: true` + `context_frames` / `context` for the aggregators and the bottleneck (config_adaptive_v3.yaml:84-105;
+    shipped false): the reference builds causal, windowed mimi stacks from it and the restatement follows."""
+    import dataclasses
+
+    from oracle import hcodec15_ref as R15
+
+    spec = dataclasses.replace(_spec15(0.7), agg_causal=True, agg_context=5, bt_causal=True, bt_context=7)
+    sd = synth.hcodec10_state_dict(778, spec)
+    model = ref_shim.load_state(ref_shim.load_reference_codec("1.5", spec), sd)
+    wav = R.pad_wav(synth.synth_wav(18, 2, 640 * 15))
+    feat = synth.synth_feat(19, 2, wav.shape[-1] // 320, spec.sem_in)
+    with torch.no_grad():
+        ref = model.encode(wav.unsqueeze(1), feat)
+        mine = R15.encode(sd, wav.unsqueeze(1), feat, spec)
+        assert torch.equal(ref["acoustic_codes"], mine["acoustic_codes"]) and torch.equal(ref["semantic_codes"], mine["semantic_codes"])
+        w_r = model.decode(**ref)
+        w = R15.decode(sd, ref["acoustic_codes"], ref["semantic_codes"], spec)
+        assert float((w - w_r).abs().max()) < 1e-5 * float(w_r.abs().max())
+        w_plain = R15.decode(sd, ref["acoustic_codes"], ref["semantic_codes"], _spec15(0.7))
+    assert float((w - w_plain).abs().max()) > 1e-3 * float(w_r.abs().max())  # the flags do change the graph
+
+
 def test_alignment_scan_rules():
     """Grouping rules of modeling_flexicodec_new.py:862-895 on a hand-made similarity pattern."""
     from oracle import hcodec15_ref as R15

@@ -10,7 +10,8 @@ from ._lib import QuarkAudioError, lib_path, load_library  # noqa: F401
 from .hcodec import Codec, HCodecSpec, HCodecTokenizer, SPEC_10, SPEC_15, SPEC_20  # noqa: F401
 from .llm import LLM_SFT, sample_logits  # noqa: F401
 from .bicodec import BiCodec, BiCodecSpec, BiCodecTokenizer, SPEC_BICODEC  # noqa: F401
+from .mimi import StreamingTransformer  # noqa: F401
 from .unise import UniSE  # noqa: F401
 from .ssl import SPEC_HUBERT_BASE, SPEC_WAVLM_BASE_PLUS, SPEC_XLSR53, SSLFeatureExtractor, SSLSpec  # noqa: F401
 
-__all__ = ["BiCodecTokenizer", "BiCodec", "BiCodecSpec", "SPEC_BICODEC", "sample_logits", "UniSE", "SSLFeatureExtractor", "SSLSpec", "SPEC_HUBERT_BASE", "SPEC_XLSR53", "SPEC_WAVLM_BASE_PLUS", "LLM_SFT", "Codec", "HCodecSpec", "HCodecTokenizer", "SPEC_10", "SPEC_15", "SPEC_20", "QuarkAudioError", "load_library", "lib_path"]
+__all__ = ["StreamingTransformer", "BiCodecTokenizer", "BiCodec", "BiCodecSpec", "SPEC_BICODEC", "sample_logits", "UniSE", "SSLFeatureExtractor", "SSLSpec", "SPEC_HUBERT_BASE", "SPEC_XLSR53", "SPEC_WAVLM_BASE_PLUS", "LLM_SFT", "Codec", "HCodecSpec", "HCodecTokenizer", "SPEC_10", "SPEC_15", "SPEC_20", "QuarkAudioError", "load_library", "lib_path"]

@@ -35,6 +35,7 @@ class qa_hcodec_spec(C.Structure):
         ("threshold", C.c_float),
         ("version", C.c_int32), ("enc_dim", C.c_int32), ("enc_inter", C.c_int32), ("enc_convnext_layers", C.c_int32),
         ("frame_stride", C.c_int32), ("tr_inter_cap", C.c_int32), ("causal", C.c_int32),
+        ("agg_causal", C.c_int32), ("agg_context", C.c_int32), ("bt_causal", C.c_int32), ("bt_context", C.c_int32),
     ]
 
 
@@ -56,6 +57,11 @@ class qa_lm_spec(C.Structure):
         ("global_size", C.c_int32), ("semantic_size", C.c_int32), ("feats_dim", C.c_int32), ("num_tasks", C.c_int32),
         ("rope_theta", C.c_float), ("rms_eps", C.c_float),
     ]
+
+
+class qa_mimi_spec(C.Structure):
+    _fields_ = [("d_model", C.c_int32), ("num_heads", C.c_int32), ("num_layers", C.c_int32), ("dim_feedforward", C.c_int32),
+                ("causal", C.c_int32), ("context", C.c_int32)]
 
 
 class qa_bicodec_spec(C.Structure):
@@ -109,6 +115,14 @@ SYMBOLS = {
     "qa_profile_begin": (C.c_int, []),
     "qa_profile_end": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
     "qa_set_serial": (C.c_int, [C.c_int32]),
+    "qa_mimi_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(qa_mimi_spec), C.POINTER(qa_tensor), C.c_int64, C.c_char_p, C.c_int]),
+    "qa_mimi_destroy": (None, [C.c_void_p]),
+    "qa_mimi_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "qa_mimi_stream_begin": (C.c_int, [C.c_void_p, C.c_int64]),
+    "qa_mimi_stream_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "qa_mimi_stream_reset": (C.c_int, [C.c_void_p]),
+    "qa_mimi_stream_end": (C.c_int, [C.c_void_p]),
+    "qa_mimi_stream_offset": (C.c_int64, [C.c_void_p]),
     "qa_ssl_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(qa_ssl_spec), C.POINTER(qa_tensor), C.c_int64, C.c_int]),
     "qa_ssl_destroy": (None, [C.c_void_p]),
     "qa_ssl_frames": (C.c_int64, [C.c_void_p, C.c_int64]),

@@ -4,6 +4,15 @@
 // (QuarkAudio-HCodec/HCodec-1.0/vq/encoder_modules/transformer.py:158-180) and a causal mask over a KV cache for the
 // UniSE Llama layers (QuarkAudio-UniSE/model/llm/llm.py:182-211).  RoPE has already been applied to q / k.
 //
+// Causal windows and the streaming ring (mimi/transformer.py:212-281,403-413; encoder_modules/transformer.py:437-447):
+//   causal = 1            key j visible to query i iff j <= i + off                       (off = n_keys - n_q)
+//   context > 0           ... and (i + off) - j < context   (StreamingMultiheadAttention `context`, Transformer `left_context`)
+//   ring_end > 0          the keys are the slots of a RingKVCache of capacity n_keys whose write cursor stands at ring_end
+//                         (= tokens seen so far, this chunk included): slot s holds position p(s) as RingKVCache.complete()
+//                         computes it (-1 = never written), query i sits at q_pos0 + i, visible iff p >= 0 and
+//                         0 <= pos_q - p < context.  Slots overwritten by later tokens of the same chunk are gone, as in the
+//                         reference (it writes the whole chunk before it attends).
+//
 // One wave64 owns 32 queries and walks the keys 32 at a time; both products run TRANSPOSED on
 // v_mfma_f32_32x32x2_f32 so that every softmax statistic is per lane (no cross-lane row reductions):
 //   S^T[key, q] = sum_d K[key, d] Q[q, d]     A = K tile (LDS, ds_read_b128), B = Q (registers)
@@ -23,7 +32,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         long long ldkv, long long kv_bstride, float* __restrict__ out,
                                                         long long ldo, int n_q, int n_keys, float scale, int causal,
-                                                        const float* __restrict__ gate, const float* __restrict__ relbias, int R) {
+                                                        const float* __restrict__ gate, const float* __restrict__ relbias, int R,
+                                                        int context, int q_pos0, int ring_end) {
     constexpr int LD = HD + 4;
     constexpr int DT = HD / 32;
     constexpr int NG = HD / 8;
@@ -66,13 +76,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const float* kb = k + (long long)b * kv_bstride + head * HD;
     const float* vb = v + (long long)b * kv_bstride + head * HD;
 
-    int last_key = n_keys - 1;
-    if (causal) {
+    const bool ring = ring_end > 0;
+    const bool lin_causal = causal && !ring;
+    int last_key = n_keys - 1, first_key = 0;
+    if (lin_causal) {
         const int q_last = min(q_blk0 + 127, n_q - 1);
         last_key = min(last_key, q_last + off);
+        if (context > 0) first_key = max(0, q_blk0 + off - context + 1);
     }
-    const int n_tiles = last_key / 32 + 1;
-    const int wave_last_key = causal ? min(n_keys - 1, min(q_blk0 + wave * 32 + 31, n_q - 1) + off) : n_keys - 1;
+    const int n_tiles = last_key / 32 + 1, kt0 = first_key / 32;
+    const int wave_last_key = lin_causal ? min(n_keys - 1, min(q_blk0 + wave * 32 + 31, n_q - 1) + off) : n_keys - 1;
+    const int wave_first_key = (lin_causal && context > 0) ? max(0, q_blk0 + wave * 32 + off - context + 1) : 0;
+    const int ring_idx = ring ? ring_end % n_keys : 0;  // RingKVCache.complete(): end_index
 
     // K / V tiles go global -> registers -> LDS; the loads of tile kt + 1 are issued right after tile kt is in LDS and stay in
     // flight under its 64 MFMAs (the first version loaded synchronously: one exposed L2 / HBM round trip per 32 keys)
@@ -92,8 +107,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
             }
         }
     };
-    fetch(0);
-    for (int kt = 0; kt < n_tiles; ++kt) {
+    fetch(kt0);
+    for (int kt = kt0; kt < n_tiles; ++kt) {
         __syncthreads();  // the previous tile is no longer read
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
@@ -104,7 +119,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         }
         __syncthreads();
         if (kt + 1 < n_tiles) fetch(kt + 1);
-        if (kt * 32 > wave_last_key) continue;  // wave-uniform: whole tile masked for this wave
+        if (kt * 32 > wave_last_key || kt * 32 + 31 < wave_first_key) continue;  // wave-uniform: whole tile masked for this wave
 
         // S^T = K Q^T
         f32x16 s;
@@ -124,7 +139,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const bool ok = key < n_keys && (!causal || key <= qi + off);
+            bool ok = key < n_keys;
+            if (ring) {
+                const int delta = key - ring_idx;
+                const int pos = key >= ring_end ? -1 : (delta <= 0 ? ring_end + delta : ring_end + delta - n_keys);
+                const int dq = q_pos0 + qi - pos;
+                ok = ok && pos >= 0 && dq >= 0 && dq < context;
+            } else if (causal) {
+                ok = ok && key <= qi + off && (context <= 0 || qi + off - key < context);
+            }
             float sc = s[r] * scale;
             if (BIAS) sc += gate_q * rb[max(-R, min(R, key - qi))];
             s[r] = ok ? sc : -INFINITY;
@@ -175,8 +198,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // gate [B, H, n_q] and relbias [H, 2R+1] (both optional, together): gated relative position bias, see attention_kernel
 int launch_attention(const float* q, long long ldq, const float* k, const float* v, long long ldkv, float* out,
                      long long ldo, int B, int n_q, int n_keys, long long kv_batch_stride, int H, int hd, float scale,
-                     int causal, hipStream_t s, const float* gate, const float* relbias, int R) {
-    QA_REQUIRE(n_q > 0 && n_keys > 0 && (!causal || n_keys >= n_q), "attention: n_q=%d n_keys=%d", n_q, n_keys);
+                     int causal, hipStream_t s, const float* gate, const float* relbias, int R, int context, int q_pos0,
+                     int ring_end) {
+    QA_REQUIRE(n_q > 0 && n_keys > 0 && (!causal || ring_end > 0 || n_keys >= n_q), "attention: n_q=%d n_keys=%d", n_q, n_keys);
+    QA_REQUIRE(context >= 0 && (context == 0 || causal) && (ring_end <= 0 || (causal && context > 0 && !gate)),
+               "attention: a context window needs causal=1; the ring mode needs causal=1 and context > 0");
     QA_REQUIRE((ldq % 4) == 0 && (ldkv % 4) == 0 && (ldo % 4) == 0, "attention: strides must be multiples of 4");
     QA_REQUIRE((gate == nullptr) == (relbias == nullptr) && (!gate || (R >= 0 && !causal && n_q == n_keys)),
                "attention: gate and relbias come together, for non-causal self-attention");
@@ -184,10 +210,10 @@ int launch_attention(const float* q, long long ldq, const float* k, const float*
 #define QA_ATT(HD)                                                                                                          \
     if (gate)                                                                                                                \
         hipLaunchKernelGGL((attention_kernel<HD, true>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, \
-                           n_keys, scale, causal, gate, relbias, R);                                                        \
+                           n_keys, scale, causal, gate, relbias, R, context, q_pos0, ring_end);                             \
     else                                                                                                                     \
         hipLaunchKernelGGL((attention_kernel<HD, false>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, \
-                           n_keys, scale, causal, nullptr, nullptr, 0)
+                           n_keys, scale, causal, nullptr, nullptr, 0, context, q_pos0, ring_end)
     switch (hd) {
         case 32: QA_ATT(32); break;
         case 64: QA_ATT(64); break;

@@ -106,9 +106,9 @@ struct ConvParams {
     int vec_epi;  // epilogue may move float4 (set by launch_conv_gemm from N, leading dimensions and pointer alignment)
     unsigned rep_magic, rep_one;  // r / in_rep == __umulhi(r, rep_magic) + r * rep_one  (branch-free; set by launch_conv_gemm)
     // fused interleaved-pair RoPE on output channels n < rope_n (the q and k parts of a fused QKV projection; mimi module/rope.py:13-69):
-    // (y[2i], y[2i+1]) <- (y[2i] c - y[2i+1] s, y[2i+1] c + y[2i] s) with (c, s) = rope[(t * rope_hd/2 + i) * 2 + {0,1}], t = m % rope_T, i = (n % rope_hd) / 2
+    // (y[2i], y[2i+1]) <- (y[2i] c - y[2i+1] s, y[2i+1] c + y[2i] s) with (c, s) = rope[(t * rope_hd/2 + i) * 2 + {0,1}], t = rope_pos0 + m % rope_T, i = (n % rope_hd) / 2
     const float* rope;
-    int rope_n, rope_hd, rope_T;
+    int rope_n, rope_hd, rope_T, rope_pos0;
     int dilation;  // tap j reads frame t * stride - pad_left + j * dilation (0 / 1 = dense); zero padding only
     // Snake activation x + sin^2(alpha x) / (alpha + 1e-9) with a per-output-channel alpha (BiCodec wave generator, blocks/layers.py:31-36):
     // `alpha` serves act / post_act == ACT_SNAKE; y2 (optional) receives snake(final value, alpha2) next to y, so that a residual

@@ -80,7 +80,7 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const ConvParams& p, long lo
     }
     if (p.y2) *reinterpret_cast<f32x4*>(p.y2 + m * p.ldy2 + n) = snake4(v, p.alpha2, n);
     if (p.rope && n < p.rope_n) {  // interleaved pairs (2i, 2i+1): both members of a pair sit in this float4 (n % 4 == 0)
-        const int t = (int)(m % p.rope_T), i = (n % p.rope_hd) >> 1;
+        const int t = p.rope_pos0 + (int)(m % p.rope_T), i = (n % p.rope_hd) >> 1;
         const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope + ((long long)t * (p.rope_hd >> 1) + i) * 2);  // c_i, s_i, c_i+1, s_i+1
         const f32x4 r = {v.x * cs.x - v.y * cs.y, v.y * cs.x + v.x * cs.y, v.z * cs.z - v.w * cs.w, v.w * cs.z + v.z * cs.w};
         v = r;

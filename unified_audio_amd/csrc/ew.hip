@@ -772,4 +772,29 @@ int launch_resample(const float* wav, const float* taps, float* out, int B, long
     return QA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// RingKVCache.complete() write (mimi/transformer.py:243-250): cache[:, (pos0 + t) % cap] = k[:, t]
+__global__ __launch_bounds__(256) void ring_append_kernel(const float* __restrict__ k, const float* __restrict__ v, long long ld,
+                                                          float* __restrict__ kc, float* __restrict__ vc, int B, int T, int d,
+                                                          int cap, int pos0) {
+    const int d4 = d >> 2;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)B * T * d4) return;
+    const int c = (int)(gid % d4) * 4;
+    const long long row = gid / d4;
+    const int b = (int)(row / T), t = (int)(row - (long long)b * T);
+    const long long dst = ((long long)b * cap + (pos0 + t) % cap) * d + c;
+    *reinterpret_cast<float4*>(kc + dst) = *reinterpret_cast<const float4*>(k + row * ld + c);
+    *reinterpret_cast<float4*>(vc + dst) = *reinterpret_cast<const float4*>(v + row * ld + c);
+}
+
+int launch_ring_append(const float* k, const float* v, long long ld, float* kc, float* vc, int B, int T, int d, int cap, int pos0,
+                       hipStream_t s) {
+    QA_REQUIRE(d % 4 == 0 && ld % 4 == 0 && T >= 1 && T <= cap && pos0 >= 0, "ring_append: T=%d cap=%d d=%d (a chunk must fit the ring)", T, cap, d);
+    const long long total = (long long)B * T * (d / 4);
+    hipLaunchKernelGGL(ring_append_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, k, v, ld, kc, vc, B, T, d, cap, pos0);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
 }  // namespace qa

@@ -44,7 +44,13 @@ struct MimiLayerW {  // StreamingTransformerLayer (mimi/transformer.py:436-594)
 struct MimiW {
     std::vector<MimiLayerW> layers;
     int d = 0, heads = 0, ff = 0;
+    int causal = 0, context = 0;  // StreamingMultiheadAttention causal / context (mimi/transformer.py:403-413); context is ignored unless causal
     const float* rope = nullptr;  // interleaved-pair table [MAX_POS][hd/2][2]
+};
+// _MHAState of every layer (mimi/transformer.py:284-293): RingKVCache [B, cap, d] x 2 and the offset
+struct MimiStream {
+    std::vector<float*> kc, vc;
+    int B = 0, cap = 0, offset = 0;
 };
 
 constexpr int MAX_POS = 8192;
@@ -99,6 +105,19 @@ struct qa_hcodec {
     hipStream_t side = nullptr;  // second stream: the two aggregator stacks are independent and run concurrently
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // workspace
+    char* ws = nullptr;
+    size_t ws_cap = 0;
+    Ctx ctx;
+};
+
+// One StreamingTransformer with its optional streaming state (mimi/transformer.py:605-698)
+struct qa_mimi {
+    qa_mimi_spec spec{};
+    int device = 0;
+    WeightStore store;
+    MimiW w;
+    MimiStream st;       // st.B > 0: inside `with model.streaming(B)`
+    float* ring = nullptr;  // backing store of the ring caches
     char* ws = nullptr;
     size_t ws_cap = 0;
     Ctx ctx;
@@ -264,10 +283,13 @@ void build_transformer(Builder& b, TransformerW* tw, const std::string& p, int d
     b.raw(&tw->rope, cs);
 }
 
-void build_mimi(Builder& b, MimiW* mw, const std::string& p, int d, int n_layers, int heads, int ff) {
+void build_mimi(Builder& b, MimiW* mw, const std::string& p, int d, int n_layers, int heads, int ff, int causal = 0,
+                int context = 0) {
     mw->d = d;
     mw->heads = heads;
     mw->ff = ff;
+    mw->causal = causal;
+    mw->context = context;
     mw->layers.resize(n_layers);
     for (int l = 0; l < n_layers; ++l) {
         MimiLayerW& L = mw->layers[l];
@@ -307,7 +329,7 @@ void build_mimi(Builder& b, MimiW* mw, const std::string& p, int d, int n_layers
 int conv_op(Ctx& c, const float* x, int64_t ldx, int B, int T_in, const ConvW& w, float* y, int64_t ldy, int T_out,
             int stride, int pad_left, int pad_right, int pad_mode, int prologue, int act, const float* gamma,
             const float* res, int64_t ldr, const float* gate, int post_act, int in_rep = 1, const float* rope = nullptr,
-            int rope_n = 0, int rope_hd = 0, int rope_T = 0) {
+            int rope_n = 0, int rope_hd = 0, int rope_T = 0, int rope_pos0 = 0) {
     if (c.dry) return QA_OK;
     qa_conv_args a{};
     a.x = x; a.w = w.w; a.bias = w.b; a.gamma = gamma; a.residual = res; a.gate = gate; a.y = y;
@@ -320,7 +342,7 @@ int conv_op(Ctx& c, const float* x, int64_t ldx, int B, int T_in, const ConvW& w
     QA_TRY(conv_params_from_args(a, &p));
     p.algo_n = w.algo_n;
     p.algo_k = w.algo_cin ? w.algo_cin * w.ksize : 0;
-    p.rope = rope; p.rope_n = rope_n; p.rope_hd = rope_hd; p.rope_T = rope_T;
+    p.rope = rope; p.rope_n = rope_n; p.rope_hd = rope_hd; p.rope_T = rope_T; p.rope_pos0 = rope_pos0;
     return launch_conv_gemm(p, c.stream);
 }
 
@@ -404,15 +426,26 @@ MimiTemps mimi_temps(Ctx& c, const MimiW& mw, int64_t rows) {
     t.u = c.arena.alloc<float>(rows * mw.ff);
     return t;
 }
-int mimi_layer(Ctx& c, const MimiW& mw, const MimiLayerW& L, float* x, const MimiTemps& t, int B, int N) {
+// st != nullptr: streaming step of N frames at st->offset (layer index li selects the ring caches); the caller advances the offset
+int mimi_layer(Ctx& c, const MimiW& mw, const MimiLayerW& L, float* x, const MimiTemps& t, int B, int N, MimiStream* st = nullptr,
+               size_t li = 0) {
     const int d = mw.d, H = mw.heads, hd = d / H;
     const int64_t rows = (int64_t)B * N;
+    const int pos0 = st ? st->offset : 0;
+    const float scale = 1.0f / std::sqrt((float)hd);
     QA_TRY(launch_layernorm(x, L.n1w, L.n1b, t.hn, rows, d, 1e-5f, c.stream));
     // fused QKV projection with the interleaved-pair RoPE of q and k applied in the GEMM epilogue (one launch less per layer)
     QA_TRY(conv_op(c, t.hn, d, 1, (int)rows, L.in_proj, t.qkv, 3 * d, (int)rows, 1, 0, 0, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, nullptr,
-                   3 * d, nullptr, ACT_NONE, 1, mw.rope, 2 * d, hd, N));
-    QA_TRY(launch_attention(t.qkv, 3 * d, t.qkv + d, t.qkv + 2 * d, 3 * d, t.att, d, B, N, N, (long long)N * 3 * d, H, hd,
-                            1.0f / std::sqrt((float)hd), 0, c.stream));
+                   3 * d, nullptr, ACT_NONE, 1, mw.rope, 2 * d, hd, N, pos0));
+    if (st) {
+        // RingKVCache.complete(): the chunk's keys / values are written first, then every query attends over the ring
+        QA_TRY(launch_ring_append(t.qkv + d, t.qkv + 2 * d, 3 * d, st->kc[li], st->vc[li], B, N, d, st->cap, pos0, c.stream));
+        QA_TRY(launch_attention(t.qkv, 3 * d, st->kc[li], st->vc[li], d, t.att, d, B, N, st->cap, (long long)st->cap * d, H, hd, scale, 1,
+                                c.stream, nullptr, nullptr, 0, mw.context, pos0, pos0 + N));
+    } else {
+        QA_TRY(launch_attention(t.qkv, 3 * d, t.qkv + d, t.qkv + 2 * d, 3 * d, t.att, d, B, N, N, (long long)N * 3 * d, H, hd, scale,
+                                mw.causal, c.stream, nullptr, nullptr, 0, mw.causal ? mw.context : 0));
+    }
     QA_TRY(linear_op(c, t.att, rows, L.out_proj, x, ACT_NONE, x, nullptr, L.ls1));
     QA_TRY(launch_layernorm(x, L.n2w, L.n2b, t.hn, rows, d, 1e-5f, c.stream));
     QA_TRY(linear_op(c, t.hn, rows, L.lin1, t.u, ACT_GELU));
@@ -984,9 +1017,13 @@ int build(qa_hcodec* h, const HostTable& tab) {
         QA_REQUIRE(sp.agg_heads > 0 && sp.bt_heads > 0 && sp.code_dim % sp.agg_heads == 0 && (2 * sp.code_dim) % sp.bt_heads == 0,
                    "spec: bad head counts for the adaptive stacks");
         QA_REQUIRE(sp.agg_ff % 32 == 0 && sp.bt_ff % 32 == 0 && sp.max_tokens_per_group >= 1, "spec: bad adaptive widths");
-        build_mimi(b, &h->agg_sem, "semantic_aggregator.transformer.transformer", sp.code_dim, sp.agg_layers, sp.agg_heads, sp.agg_ff);
-        build_mimi(b, &h->agg_ac, "acoustic_aggregator.transformer.transformer", sp.code_dim, sp.agg_layers, sp.agg_heads, sp.agg_ff);
-        build_mimi(b, &h->bottleneck, "bottleneck_transformer.transformer", 2 * sp.code_dim, sp.bt_layers, sp.bt_heads, sp.bt_ff);
+        QA_REQUIRE(sp.agg_context >= 0 && sp.bt_context >= 0, "spec: negative attention context");
+        build_mimi(b, &h->agg_sem, "semantic_aggregator.transformer.transformer", sp.code_dim, sp.agg_layers, sp.agg_heads, sp.agg_ff,
+                   sp.agg_causal, sp.agg_context);
+        build_mimi(b, &h->agg_ac, "acoustic_aggregator.transformer.transformer", sp.code_dim, sp.agg_layers, sp.agg_heads, sp.agg_ff,
+                   sp.agg_causal, sp.agg_context);
+        build_mimi(b, &h->bottleneck, "bottleneck_transformer.transformer", 2 * sp.code_dim, sp.bt_layers, sp.bt_heads, sp.bt_ff,
+                   sp.bt_causal, sp.bt_context);
         b.vec(&h->qemb_sem, "semantic_aggregator.query_embedding", sp.code_dim);
         b.vec(&h->qemb_ac, "acoustic_aggregator.query_embedding", sp.code_dim);
         QA_REQUIRE(2 * sp.code_dim == sp.dec_dim || true, "unused");
@@ -1196,5 +1233,157 @@ int64_t qa_hcodec_tap(qa_hcodec* h, const char* name, float* dst, int64_t cap, v
     }
     return it->second.numel;
 }
+
+
+/* ---- mimi StreamingTransformer ----------------------------------------------------------------------------------------- */
+
+int qa_mimi_create(qa_mimi** out, const qa_mimi_spec* spec, const qa_tensor* tensors, int64_t n_tensors, const char* prefix,
+                   int device) {
+    if (!out || !spec || !tensors || !prefix) {
+        set_error("qa_mimi_create: null argument");
+        return QA_ERR_INVALID;
+    }
+    *out = nullptr;
+    const qa_mimi_spec& sp = *spec;
+    QA_REQUIRE(sp.d_model > 0 && sp.num_heads > 0 && sp.d_model % sp.num_heads == 0 && sp.num_layers > 0 && sp.dim_feedforward > 0,
+               "qa_mimi_create: bad sizes");
+    const int hd = sp.d_model / sp.num_heads;
+    QA_REQUIRE(hd == 32 || hd == 64 || hd == 96 || hd == 128, "qa_mimi_create: head_dim %d unsupported (32/64/96/128)", hd);
+    QA_REQUIRE(sp.d_model % 32 == 0 && sp.dim_feedforward % 32 == 0, "qa_mimi_create: widths must be multiples of 32");
+    QA_REQUIRE(sp.context >= 0 && (sp.causal || sp.context == 0 || true), "qa_mimi_create: negative context");
+    QA_HIP(hipSetDevice(device));
+    std::unique_ptr<qa_mimi> m(new qa_mimi());
+    m->spec = sp;
+    m->device = device;
+    HostTable tab(tensors, n_tensors);
+    Builder b{Folder{tab, m->store}};
+    build_mimi(b, &m->w, prefix, sp.d_model, sp.num_layers, sp.num_heads, sp.dim_feedforward, sp.causal, sp.context);
+    if (!b.f.ok) return b.f.status;
+    const int st = m->store.upload();
+    if (st != QA_OK) {
+        m->store.release();
+        return st;
+    }
+    b.resolve();
+    *out = m.release();
+    return QA_OK;
+}
+
+void qa_mimi_destroy(qa_mimi* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipDeviceSynchronize();
+    m->store.release();
+    if (m->ring) (void)hipFree(m->ring);
+    if (m->ws) (void)hipFree(m->ws);
+    delete m;
+}
+
+static int mimi_run(qa_mimi* m, const float* x, int B, int T, float* y, hipStream_t stream, bool streaming) {
+    Ctx& c = m->ctx;
+    c.stream = stream;
+    const int64_t rows = (int64_t)B * T;
+    for (int pass = 0; pass < 2; ++pass) {
+        c.dry = pass == 0;
+        c.arena.begin(c.dry ? nullptr : m->ws, c.dry ? 0 : m->ws_cap);
+        const MimiTemps t = mimi_temps(c, m->w, rows);
+        if (c.dry) {
+            if (c.arena.peak() > m->ws_cap) {
+                if (m->ws) QA_HIP(hipFree(m->ws));
+                m->ws = nullptr;
+                m->ws_cap = 0;
+                QA_HIP(hipMalloc(reinterpret_cast<void**>(&m->ws), c.arena.peak() + c.arena.peak() / 8));
+                m->ws_cap = c.arena.peak() + c.arena.peak() / 8;
+            }
+            continue;
+        }
+        if (y != x) QA_HIP(hipMemcpyAsync(y, x, sizeof(float) * rows * m->w.d, hipMemcpyDeviceToDevice, stream));
+        for (size_t l = 0; l < m->w.layers.size(); ++l)
+            QA_TRY(mimi_layer(c, m->w, m->w.layers[l], y, t, B, T, streaming ? &m->st : nullptr, l));
+    }
+    return QA_OK;
+}
+
+int qa_mimi_forward(qa_mimi* m, const float* x, int64_t B, int64_t T, float* y, void* stream) {
+    if (!m || !x || !y) {
+        set_error("qa_mimi_forward: null argument");
+        return QA_ERR_INVALID;
+    }
+    QA_REQUIRE(B > 0 && T > 0 && T <= MAX_POS && B * T < (1LL << 31), "qa_mimi_forward: x is [%lld, %lld, d] (T <= %d)", (long long)B,
+               (long long)T, MAX_POS);
+    QA_REQUIRE(m->st.B == 0, "qa_mimi_forward: the handle is in streaming mode, use qa_mimi_stream_step");
+    QA_HIP(hipSetDevice(m->device));
+    return mimi_run(m, x, (int)B, (int)T, y, static_cast<hipStream_t>(stream), false);
+}
+
+int qa_mimi_stream_begin(qa_mimi* m, int64_t B) {
+    if (!m) {
+        set_error("qa_mimi_stream_begin: null handle");
+        return QA_ERR_INVALID;
+    }
+    QA_REQUIRE(m->spec.causal, "qa_mimi_stream_begin: Streaming only available for causal (mimi/transformer.py:382)");
+    QA_REQUIRE(m->spec.context > 0, "qa_mimi_stream_begin: Cannot create a streaming KVCache without a context to estimate capacity "
+               "(mimi/transformer.py:349-353)");
+    QA_REQUIRE(B > 0 && B < (1 << 20), "qa_mimi_stream_begin: batch %lld", (long long)B);
+    QA_HIP(hipSetDevice(m->device));
+    if (m->ring) QA_HIP(hipFree(m->ring));
+    m->ring = nullptr;
+    const size_t L = m->w.layers.size(), per = (size_t)B * m->spec.context * m->w.d;
+    QA_HIP(hipMalloc(reinterpret_cast<void**>(&m->ring), sizeof(float) * 2 * L * per));
+    QA_HIP(hipMemset(m->ring, 0, sizeof(float) * 2 * L * per));  // RingKVCache.__init__: zeros
+    m->st.kc.resize(L);
+    m->st.vc.resize(L);
+    for (size_t l = 0; l < L; ++l) {
+        m->st.kc[l] = m->ring + (2 * l) * per;
+        m->st.vc[l] = m->ring + (2 * l + 1) * per;
+    }
+    m->st.B = (int)B;
+    m->st.cap = m->spec.context;
+    m->st.offset = 0;
+    return QA_OK;
+}
+
+int qa_mimi_stream_step(qa_mimi* m, const float* x, int64_t T, float* y, void* stream) {
+    if (!m || !x || !y) {
+        set_error("qa_mimi_stream_step: null argument");
+        return QA_ERR_INVALID;
+    }
+    QA_REQUIRE(m->st.B > 0, "qa_mimi_stream_step: not streaming (call qa_mimi_stream_begin)");
+    QA_REQUIRE(T >= 1 && T <= m->st.cap, "qa_mimi_stream_step: a chunk of %lld frames does not fit the ring of %d (RingKVCache.complete "
+               "would write one slot twice)", (long long)T, m->st.cap);
+    QA_REQUIRE((int64_t)m->st.offset + T <= MAX_POS, "qa_mimi_stream_step: offset %d + %lld exceeds the RoPE table (%d positions); "
+               "reset the stream", m->st.offset, (long long)T, MAX_POS);
+    QA_HIP(hipSetDevice(m->device));
+    QA_TRY(mimi_run(m, x, m->st.B, (int)T, y, static_cast<hipStream_t>(stream), true));
+    m->st.offset += (int)T;
+    return QA_OK;
+}
+
+int qa_mimi_stream_reset(qa_mimi* m) {
+    if (!m) {
+        set_error("qa_mimi_stream_reset: null handle");
+        return QA_ERR_INVALID;
+    }
+    QA_REQUIRE(m->st.B > 0, "qa_mimi_stream_reset: Trying to reset streaming, but the transformer wasn't streaming (streaming.py:118-121)");
+    m->st.offset = 0;  // RingKVCache.reset(): the caches keep their contents, end_offset = 0 alone invalidates them
+    return QA_OK;
+}
+
+int qa_mimi_stream_end(qa_mimi* m) {
+    if (!m) {
+        set_error("qa_mimi_stream_end: null handle");
+        return QA_ERR_INVALID;
+    }
+    (void)hipSetDevice(m->device);
+    if (m->ring) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(m->ring);
+    }
+    m->ring = nullptr;
+    m->st = MimiStream{};
+    return QA_OK;
+}
+
+int64_t qa_mimi_stream_offset(const qa_mimi* m) { return (m && m->st.B > 0) ? m->st.offset : -1; }
 
 }  // extern "C"

@@ -51,7 +51,12 @@ int launch_resample(const float* wav, const float* taps, float* out, int B, long
 //   (WavLM gated relative position bias)
 int launch_attention(const float* q, long long ldq, const float* k, const float* v, long long ldkv, float* out,
                      long long ldo, int B, int n_q, int n_keys, long long kv_batch_stride, int H, int hd, float scale,
-                     int causal, hipStream_t s, const float* gate = nullptr, const float* relbias = nullptr, int R = 0);
+                     int causal, hipStream_t s, const float* gate = nullptr, const float* relbias = nullptr, int R = 0,
+                     int context = 0, int q_pos0 = 0, int ring_end = 0);
+// RingKVCache.complete() write (mimi/transformer.py:243-250): rows t = 0..T-1 of k / v (row stride ld, batch stride T * ld) go to
+// slot (pos0 + t) % cap of the caches [B, cap, d]
+int launch_ring_append(const float* k, const float* v, long long ld, float* kc, float* vc, int B, int T, int d, int cap, int pos0,
+                       hipStream_t s);
 
 // lstm.hip : one nn.LSTM layer (batch_first, zero initial state) given the precomputed input projection
 //   xw [B, T, 4d] = x W_ih^T + b_ih + b_hh with the 4d axis permuted to (unit, gate) order,

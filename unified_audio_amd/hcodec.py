@@ -60,6 +60,12 @@ class HCodecSpec:
     # the causal variant every block of the SEANet family parameterises (encoder_modules/conv.py:203-206, vq/conv.py:44-47,76-79,
     # encoder_modules/transformer.py:470-475); vq/codec.py:31 ships False
     causal: bool = False
+    # H-Codec 1.5: `causal` / `context_frames` of the aggregators, `causal` / `context` of the bottleneck transformer
+    # (config_adaptive_v3.yaml:84-105; shipped causal: false, where mimi/transformer.py:403-413 ignores the context)
+    agg_causal: bool = False
+    agg_context: int = 16
+    bt_causal: bool = False
+    bt_context: int = 16
 
     @property
     def enc_hop(self) -> int:
@@ -90,6 +96,7 @@ class HCodecSpec:
         s.version, s.enc_dim, s.enc_inter = self.version, self.enc_dim, self.enc_inter
         s.enc_convnext_layers, s.frame_stride, s.tr_inter_cap = self.enc_convnext_layers, self.frame_stride, self.tr_inter_cap
         s.causal = int(self.causal)
+        s.agg_causal, s.agg_context, s.bt_causal, s.bt_context = int(self.agg_causal), self.agg_context, int(self.bt_causal), self.bt_context
         return s
 
 
@@ -122,7 +129,9 @@ def _spec_from_config(config: dict, device=None) -> HCodecSpec:
                           agg_heads=agg["num_heads"], agg_ff=agg["dim_feedforward"], bt_layers=tk["num_layers"],
                           bt_heads=tk["num_heads"], bt_ff=tk["dim_feedforward"],
                           threshold=float(thr if thr is not None else ad["similarity_threshold"]),
-                          max_tokens_per_group=ad["max_tokens_per_group"])
+                          max_tokens_per_group=ad["max_tokens_per_group"],
+                          agg_causal=bool(agg.get("causal", False)), agg_context=int(agg.get("context_frames") or 0),
+                          bt_causal=bool(tk.get("causal", False)), bt_context=int(tk.get("context") or 0))
     se = config["semantic_encoder_config"]  # H-Codec 2.0
     stride = int(50 / enc["target_frame_rate"])
     return HCodecSpec(version=20, enc_dim=enc["dim"], enc_inter=enc["intermediate_dim"], enc_convnext_layers=enc["convnext_layers"],

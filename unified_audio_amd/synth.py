@@ -97,6 +97,13 @@ def _mimi(self, p, d, n_layers, ff):
 _Gen.mimi = _mimi
 
 
+def mimi_state_dict(seed: int, d: int, n_layers: int, ff: int, prefix: str = "transformer"):
+    """Seeded weights of one StreamingTransformer (keys `<prefix>.layers.N...`, mimi/transformer.py:436-594)."""
+    g = _Gen(seed)
+    g.mimi(prefix, d, n_layers, ff)
+    return g.sd
+
+
 def hcodec10_state_dict(seed: int = 1234, spec=SPEC_10, head_logmag_bias: float = 1.5,
                         head_gain: float = 1.0) -> Dict[str, torch.Tensor]:
     g = _Gen(seed)
