@@ -1,0 +1,108 @@
+"""Shape fuzzing of the implicit-GEMM Conv1d and the RVQ search through the C-ABI (hypothesis-driven shapes
+on top of the hand-picked edge cases of tests/test_kernels_gpu.py).  Every draw is checked against torch's own convolution on the CPU
+(the reference's op) / the plain-C RVQ oracle; the seeds are derandomised so a failure reproduces."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from oracle import hcodec_ref as R
+from oracle import rvq_c
+from tests.util import act_ref, conv1d_cl, rel_err
+
+pytestmark = pytest.mark.gpu
+FUZZ = settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+
+
+@st.composite
+def conv_cases(draw):
+    k = draw(st.sampled_from([1, 1, 2, 3, 4, 5, 7, 8, 9, 10, 16, 17]))
+    stride = draw(st.integers(1, k)) if k > 1 else 1
+    mode = draw(st.sampled_from(["reflect", "causal", "zero", "valid"])) if k > 1 else "valid"
+    cin = draw(st.sampled_from([16, 32, 48, 64, 96, 128, 160, 512]))
+    n = draw(st.integers(1, 300))
+    if cin % 32 != 0:  # C_in multiples of 16 only take the BK = 16 tiles: N > 32, no ELU prologue (conv_gemm.hip launch rules)
+        n = max(n, 33)
+    t_min = k if mode in ("valid",) else 1
+    T = draw(st.integers(t_min, 400))
+    B = draw(st.integers(1, 3))
+    prologue = draw(st.sampled_from([0, 1])) if cin % 32 == 0 else 0
+    return dict(B=B, T=T, Cin=cin, N=n, k=k, stride=stride, mode=mode, prologue=prologue, act=draw(st.integers(0, 3)),
+                post=draw(st.integers(0, 3)), gamma=draw(st.booleans()), res=draw(st.booleans()), gate=draw(st.booleans()),
+                seed=draw(st.integers(0, 2 ** 16)))
+
+
+@FUZZ
+@given(conv_cases())
+def test_conv1d_cl_fuzz(qa_lib, gpu_device, case):
+    g = torch.Generator().manual_seed(case["seed"])
+    B, T, Cin, N, k, stride, mode = (case[f] for f in ("B", "T", "Cin", "N", "k", "stride", "mode"))
+    x = torch.randn(B, T, Cin, generator=g)
+    w = torch.randn(N, k, Cin, generator=g) / (k * Cin) ** 0.5
+    bias = torch.randn(N, generator=g)
+    xc = x.transpose(1, 2)
+    wc = w.permute(0, 2, 1).contiguous()
+    if case["prologue"]:
+        xc = F.elu(xc)
+    if mode in ("reflect", "causal"):  # SConv1d, encoder_modules/conv.py:195-211 (the oracle's restatement, pinned to it)
+        ref = R.sconv1d(xc, wc, bias, stride, causal=(mode == "causal"))
+        T_out = ref.shape[-1]
+        pt, extra = k - stride, T_out * stride - T
+        pad, pm = ((pt, extra) if mode == "causal" else (pt - pt // 2, pt // 2 + extra)), 1
+    elif mode == "zero":
+        left = (k - 1) // 2
+        T_out = (T + 2 * left - k) // stride + 1
+        if T_out < 1:
+            return
+        ref = F.conv1d(xc, wc, bias, stride=stride, padding=left)
+        pad, pm = (left, left), 0
+    else:
+        ref = F.conv1d(xc, wc, bias, stride=stride)
+        T_out, pad, pm = ref.shape[-1], (0, 0), 0
+    ref = ref.transpose(1, 2)
+    gamma = torch.rand(N, generator=g) + 0.5 if case["gamma"] else None
+    res = torch.randn(B, T_out, N, generator=g) if case["res"] else None
+    gate = torch.randn(B, T_out, N, generator=g) if case["gate"] else None
+    if gate is not None:
+        ref = F.silu(gate) * ref
+    ref = act_ref(ref, case["act"])
+    if gamma is not None:
+        ref = ref * gamma
+    if res is not None:
+        ref = ref + res
+    ref = act_ref(ref, case["post"])
+    dev = gpu_device
+    y = conv1d_cl(qa_lib, x.to(dev), w.to(dev), bias.to(dev), stride=stride, pad=pad, pad_mode=pm, prologue=case["prologue"],
+                  act=case["act"], post_act=case["post"], gamma=None if gamma is None else gamma.to(dev),
+                  residual=None if res is None else res.to(dev), gate=None if gate is None else gate.to(dev), T_out=T_out)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all(), case
+    assert rel_err(y, ref) < 3e-6, case
+
+
+@settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(n=st.integers(1, 1500), Q=st.integers(1, 6), K=st.sampled_from([1, 7, 32, 64, 100, 256, 1024]), D=st.sampled_from([8, 32, 64, 96, 128, 512]),
+       seed=st.integers(0, 2 ** 16))
+def test_rvq_search_fuzz(qa_lib, gpu_device, n, Q, K, D, seed):
+    """Both search paths (GEMM + pick for D % 32 == 0, K % 4 == 0, K >= 32; the fused kernel otherwise): every index is an exact
+    arg-min of the double-precision distance up to fp32 summation noise (oracle/rvq_ref.c check_f64)."""
+    from unified_audio_amd import _lib
+
+    rng = np.random.default_rng(seed)
+    cb = np.stack([rng.standard_normal((K, D)).astype(np.float32) * (0.6 * 0.5 ** q) for q in range(Q)])
+    x = (rng.standard_normal((n, D)) * 0.6).astype(np.float32)
+    xd, cbd = torch.from_numpy(x).to(gpu_device), torch.from_numpy(cb).to(gpu_device)
+    idx = torch.empty((n, Q), dtype=torch.int64, device=gpu_device)
+    quant = torch.empty((n, D), dtype=torch.float32, device=gpu_device)
+    _lib.check(qa_lib.qa_rvq_search(xd.data_ptr(), n, cbd.data_ptr(), Q, K, D, idx.data_ptr(), quant.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    got = idx.cpu().numpy()
+    assert got.min() >= 0 and got.max() < K
+    excess, best, gap = rvq_c.check_f64(x, cb, got)
+    tol = 2e-5 * max(float((x.astype(np.float64) ** 2).sum(1).mean()), 1e-6)
+    assert excess.max() <= tol, (n, Q, K, D, float(excess.max()))
+    assert (got[gap > tol] == best[gap > tol]).all()
+    np.testing.assert_allclose(quant.cpu().numpy(), rvq_c.lookup_f32(got, cb), rtol=0, atol=1e-5)

@@ -261,6 +261,17 @@ def test_hcodec20_full_width_parity(qa_lib, gpu_device):
     assert min(agree) > 0.95
 
 
+def test_hcodec20_full_depth_parity(qa_lib, gpu_device):
+    """The published H-Codec 2.0 architecture at FULL depth (24 + 32 ConvNeXt blocks, 1.17 G parameters, large_12.5hz_config.yaml)
+    on one 0.64 s clip: every stage and the waveform against the oracle, codes by the near-tie audit."""
+    from oracle import hcodec20_ref as R20
+
+    report, agree = _run_parity_20(R20.SPEC_20, B=1, T=3840 * 8, device=gpu_device, seed=71)
+    print(report, agree)
+    assert all(v < 4 * STAGE_TOL for v in report.values()), report  # 56 residual blocks deep: round-off accumulates
+    assert report["wav"] < 1e-4
+
+
 # ---- product mode overlaps the two H-Codec 1.5 aggregator stacks on internal streams; with taps enabled or qa_set_serial(1)
 # everything stays on the caller's stream.  Same integers, same floats (and for 1.0: repeated calls re-use the arena).
 def _streams_vs_serial(codec, wav, feat, adaptive):
