@@ -560,14 +560,21 @@ int encode_front(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const flo
     // ---- SEANet encoder
     int C = sp.n_filters, L = T;
     const bool cz = sp.causal != 0;
-    float* x = c.arena.alloc<float>((size_t)B * L * C);
-    if (!c.dry) QA_TRY(launch_conv_in(wav, h->conv0_w, h->conv0_b, x, B, L, C, 7, c.stream, cz ? 6 : -1));
-    c.tap("enc.conv0", x, (int64_t)B * L * C);
+    // stage 0 at C = 32: conv0 + residual block + ELU in ONE launch (seanet_front.hip): the [B L, 32] conv0 output never exists in HBM
+    const bool front = seanet_front_supported(C, C / 2, L);
+    float* x = (front && !c.capture) ? nullptr : c.arena.alloc<float>((size_t)B * L * C);
+    if (!c.dry && x) QA_TRY(launch_conv_in(wav, h->conv0_w, h->conv0_b, x, B, L, C, 7, c.stream, cz ? 6 : -1));
+    if (x) c.tap("enc.conv0", x, (int64_t)B * L * C);
     for (int i = 0; i < sp.n_ratios; ++i) {
         const int r = sp.ratios[i];
         const ResBlockW& rb = h->res[i];
         const size_t mark = c.arena.mark();
         float* sc = c.arena.alloc<float>((size_t)B * L * C);
+        if (i == 0 && front) {
+            if (!c.dry)
+                QA_TRY(launch_seanet_front(wav, h->conv0_w, h->conv0_b, rb.k3.w, rb.k3.b, rb.sc.w, rb.sc.b, rb.pw.w, rb.pw.b, sc,
+                                           B, L, C, C / 2, cz ? 1 : 0, c.stream));
+        } else {
         float* hh = c.arena.alloc<float>((size_t)B * L * rb.k3.N);
         // shortcut_1x1(x)
         QA_TRY(conv_op(c, x, C, B, L, rb.sc, sc, C, L, 1, 0, 0, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, nullptr, 0, nullptr,
@@ -578,6 +585,7 @@ int encode_front(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const flo
         // ELU(shortcut + 1x1(.))  -> the activation in front of the down-sampling conv is fused here
         QA_TRY(conv_op(c, hh, rb.pw.C_in, B, L, rb.pw, sc, C, L, 1, 0, 0, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, sc, C,
                        nullptr, ACT_ELU));
+        }
         const SGeom g = sconv_geom(L, 2 * r, r, cz);
         // the strided conv writes below the mark: allocate its output after releasing the block temporaries is not
         // possible (sc is its input), so the output is carved above them and compacted by pointer swap.

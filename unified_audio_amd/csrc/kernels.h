@@ -10,6 +10,11 @@ namespace qa {
 // pad_left < 0: the non-causal split of SConv1d (left = pad_total - pad_total / 2); causal SConv1d passes ksize - 1
 int launch_conv_in(const float* x, const float* w_kc, const float* bias, float* y, int B, int T, int Cout, int ksize,
                    hipStream_t s, int pad_left = -1);
+// seanet_front.hip: conv0 + SEANetResnetBlock + the ELU in front of the strided conv, one launch, `a` written once
+bool seanet_front_supported(int C, int hid, int L);
+int launch_seanet_front(const float* wav, const float* w0, const float* b0, const float* w3, const float* b3, const float* wsc,
+                        const float* bsc, const float* wpw, const float* bpw, float* a, int B, int L, int C, int hid, int causal,
+                        hipStream_t s);
 int launch_rmsnorm(const float* x, const float* w, float* y, long long rows, int C, float eps, hipStream_t s);
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, long long rows, int C, float eps,
                      hipStream_t s);
