@@ -11,6 +11,9 @@ from tests.util import conv1d_cl  # noqa: E402
 from unified_audio_amd import load_library  # noqa: E402
 
 SHAPES = [  # name, M(rows), N, Cin, k, stride
+    ("small.rvq_dist", 1056, 1024, 512, 1, 1), ("small.lm_qkv", 4032, 1536, 512, 1, 1), ("small.lm_o", 4032, 512, 512, 1, 1),
+    ("small.lm_gateup", 4032, 4096, 512, 1, 1), ("small.lm_down", 4032, 512, 2048, 1, 1), ("small.agg_2k", 2112, 512, 512, 1, 1),
+    ("small.ssl_ffn", 3984, 3072, 768, 1, 1), ("small.bicodec", 4000, 384, 2048, 1, 1),
     ("cal.4096^3", 4096, 4096, 4096, 1, 1), ("cal.8192x4096x4096", 8192, 4096, 4096, 1, 1), ("cal.16384x1024x2048", 16384, 1024, 2048, 1, 1),
     ("mimi.in_proj", 9056, 1536, 512, 1, 1), ("mimi.out_proj", 9056, 512, 512, 1, 1), ("mimi.lin1", 9056, 2048, 512, 1, 1),
     ("mimi.lin2", 9056, 512, 2048, 1, 1), ("bt.in_proj", 8000, 3072, 1024, 1, 1), ("bt.lin1", 8000, 2048, 1024, 1, 1),

@@ -47,7 +47,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const int qi = q_blk0 + wave * 32 + ql;
     const int off = n_keys - n_q;  // causal: key j visible iff j <= qi + off
 
-    // Q fragment: lane (q, h) keeps d = 8g + 4h + e  ->  qreg[4g + e]
+    // Q fragment: lane (q, h) keeps d = 8g + 4h + e  ->  qreg[4g + e].  The softmax runs in base 2: scale * log2(e) is folded into
+    // Q once, so that a score needs no multiply and an exponential is the single v_exp_f32 instruction (ocml's expf is ~10
+    // instructions, and a vector instruction issued beside the other waves' MFMAs costs ~30 cycles, conv_gemm.hip)
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float qs = scale * LOG2E;
     float qreg[HD / 2];
     {
         const int qrow = qi < n_q ? qi : n_q - 1;
@@ -55,14 +59,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const float4 t = *reinterpret_cast<const float4*>(qp + 8 * g);
-            qreg[4 * g + 0] = t.x; qreg[4 * g + 1] = t.y; qreg[4 * g + 2] = t.z; qreg[4 * g + 3] = t.w;
+            qreg[4 * g + 0] = t.x * qs; qreg[4 * g + 1] = t.y * qs; qreg[4 * g + 2] = t.z * qs; qreg[4 * g + 3] = t.w * qs;
         }
     }
 
     float gate_q = 0.f;
     const float* rb = nullptr;
     if (BIAS) {
-        gate_q = gate[((long long)b * gridDim.y + head) * n_q + (qi < n_q ? qi : n_q - 1)];
+        gate_q = LOG2E * gate[((long long)b * gridDim.y + head) * n_q + (qi < n_q ? qi : n_q - 1)];
         rb = relbias + (long long)head * (2 * R + 1) + R;
     }
 
@@ -134,42 +138,51 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * g + 2], s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * g + 3], s, 0, 0, 0);
         }
-        // online softmax (per lane = per query; the two halves of the wave hold interleaved key groups)
+        // online softmax in base 2 (per lane = per query; the two halves of the wave hold interleaved key groups).  Masks are
+        // evaluated only on tiles that can contain a hidden key for some query of this wave (wave-uniform test).
+        const int q_first = q_blk0 + wave * 32, q_last = q_first + 31;
+        const bool need_mask = ring || kt * 32 + 31 >= n_keys ||
+                               (lin_causal && (kt * 32 + 31 > q_first + off || (context > 0 && kt * 32 < q_last + off - context + 1)));
         float tmax = -INFINITY;
+        if (BIAS || need_mask) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            bool ok = key < n_keys;
-            if (ring) {
-                const int delta = key - ring_idx;
-                const int pos = key >= ring_end ? -1 : (delta <= 0 ? ring_end + delta : ring_end + delta - n_keys);
-                const int dq = q_pos0 + qi - pos;
-                ok = ok && pos >= 0 && dq >= 0 && dq < context;
-            } else if (causal) {
-                ok = ok && key <= qi + off && (context <= 0 || qi + off - key < context);
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                bool ok = key < n_keys;
+                if (ring) {
+                    const int delta = key - ring_idx;
+                    const int pos = key >= ring_end ? -1 : (delta <= 0 ? ring_end + delta : ring_end + delta - n_keys);
+                    const int dq = q_pos0 + qi - pos;
+                    ok = ok && pos >= 0 && dq >= 0 && dq < context;
+                } else if (causal) {
+                    ok = ok && key <= qi + off && (context <= 0 || qi + off - key < context);
+                }
+                float sc = s[r];
+                if (BIAS) sc += gate_q * rb[max(-R, min(R, key - qi))];
+                s[r] = ok ? sc : -INFINITY;
             }
-            float sc = s[r] * scale;
-            if (BIAS) sc += gate_q * rb[max(-R, min(R, key - qi))];
-            s[r] = ok ? sc : -INFINITY;
-            tmax = fmaxf(tmax, s[r]);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = expf(m_run - m_use);  // m_run = -inf -> 0
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = expf(s[r] - m_use);
+            s[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
             psum += s[r];
         }
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (__any(alpha != 1.f)) {  // the running maximum moved for some query of the wave: rescale (rare after the first tiles)
 #pragma unroll
-        for (int t = 0; t < DT; ++t)
+            for (int t = 0; t < DT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
         // O^T += V^T P^T ; k-slot (step st, half h) <-> key (st&3) + 8*(st>>2) + 4*h
 #pragma unroll
         for (int st = 0; st < 16; ++st) {

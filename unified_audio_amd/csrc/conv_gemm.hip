@@ -359,7 +359,14 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
         const char* e = getenv("QA_GEMM_BK16");
         return e ? atoi(e) : 1 << 30;
     }();
-    if (BN >= 64 && p.prologue != ACT_ELU && (p.K <= bk16_max_k || p.C_in % 32 != 0))
+    // ... but only when the launch has enough tiles for that co-residency: with about one workgroup per CU nobody covers the
+    // exposed latency of the next chunk's global loads, which a BK = 16 chunk's 0.45 us of MFMAs is too short to hide (measured: the
+    // 144-tile RVQ distance GEMM 1056 x 1024 x 512 ran 37 us, 2.5 x its MFMA time).  QA_GEMM_BK16_MIN_TILES = fewest tiles that take BK = 16.
+    static const long long bk16_min_tiles = [] {
+        const char* e = getenv("QA_GEMM_BK16_MIN_TILES");
+        return e ? atoll(e) : 384LL;
+    }();
+    if (BN >= 64 && p.prologue != ACT_ELU && ((p.K <= bk16_max_k && tiles >= bk16_min_tiles) || p.C_in % 32 != 0))
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, (BN >= 64 ? 16 : 32)>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
     else if (p.prologue == ACT_ELU)
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
