@@ -88,7 +88,11 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const ConvParams& p, long lo
     return v;
 }
 
-template <int BM, int BN, int WM, int WN, bool PRO_ELU, int BK = 32>
+// LINEAR: ksize 1, stride 1, no padding, no input repetition (every Linear / 1x1 of the graphs: most of the FLOPs).  Row m of A is
+// x + m * ldx, so the per-chunk source-frame lookup (LDS read, clamp, select, 64-bit address build) and the padding multiply
+// disappear from the main loop - about 20 of its ~50 non-MFMA instructions, each of which costs ~30 cycles beside the co-resident
+// workgroup's MFMAs.
+template <int BM, int BN, int WM, int WN, bool PRO_ELU, int BK = 32, bool LINEAR = false>
 __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(const ConvParams p) {
     constexpr int LDS = BK + 4;
     constexpr int RPP = 256 / (BK / 4);  // rows staged per pass: 8 (BK=32) or 4 (BK=16) threads cover one row chunk
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(cons
             s_tap[e] = ok ? (int)(src * (unsigned)ldx_i) : -1;
         }
     };
-    build_taps(0);
+    if (!LINEAR) build_taps(0);
     int jbase = 0;
 
     const float* a_ptr[A_IT];  // clip base + this thread's column offset inside a chunk
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(cons
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int m = min(m0 + ld_row + RPP * i, p.M - 1);
-        a_ptr[i] = p.x + (long long)(m / p.T_out) * p.T_in * p.ldx + ld_c4;
+        a_ptr[i] = LINEAR ? p.x + (long long)m * p.ldx + ld_c4 : p.x + (long long)(m / p.T_out) * p.T_in * p.ldx + ld_c4;
         a_tab[i] = (ld_row + RPP * i) * TAP_WIN;
     }
     const float* b_ptr[B_IT];
@@ -180,17 +184,21 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(cons
 #define QA_LOAD_GLOBAL(KC)                                                                                     \
     {                                                                                                          \
         const int k0_ = (KC) * BK;                                                                             \
-        const int j_ = k0_ / p.C_in;                                                                           \
-        const int c_ = k0_ - j_ * p.C_in;                                                                      \
-        if (j_ >= jbase + TAP_WIN) { /* block-uniform; only for ksize > TAP_WIN */                             \
-            jbase = j_;                                                                                        \
-            build_taps(jbase);                                                                                 \
-            __syncthreads();                                                                                   \
-        }                                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                                     \
-            const int off_ = s_tap[a_tab[i] + (j_ - jbase)];                                                   \
-            a_keep[i] = off_ >= 0 ? 1.f : 0.f;                                                                 \
-            a_reg[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + (unsigned)(max(off_, 0) + c_));              \
+        if (LINEAR) {                                                                                          \
+            _Pragma("unroll") for (int i = 0; i < A_IT; ++i) a_reg[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + k0_); \
+        } else {                                                                                               \
+            const int j_ = k0_ / p.C_in;                                                                       \
+            const int c_ = k0_ - j_ * p.C_in;                                                                  \
+            if (j_ >= jbase + TAP_WIN) { /* block-uniform; only for ksize > TAP_WIN */                         \
+                jbase = j_;                                                                                    \
+                build_taps(jbase);                                                                             \
+                __syncthreads();                                                                               \
+            }                                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                                 \
+                const int off_ = s_tap[a_tab[i] + (j_ - jbase)];                                               \
+                a_keep[i] = off_ >= 0 ? 1.f : 0.f;                                                             \
+                a_reg[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + (unsigned)(max(off_, 0) + c_));          \
+            }                                                                                                  \
         }                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < B_IT; ++i) b_reg[i] = *reinterpret_cast<const f32x4*>(b_ptr[i] + k0_); \
     }
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(cons
         float* a_ = sA + (BUF) * BM * LDS;                                                                     \
         float* b_ = sB + (BUF) * BN * LDS;                                                                     \
         _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                                     \
-            f32x4 v = a_reg[i] * a_keep[i];                                                                    \
+            f32x4 v = LINEAR ? a_reg[i] : a_reg[i] * a_keep[i];                                                \
             if (PRO_ELU) {                                                                                     \
                 v.x = elu_f(v.x); v.y = elu_f(v.y); v.z = elu_f(v.z); v.w = elu_f(v.w);                        \
             }                                                                                                  \
@@ -366,10 +374,21 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
         const char* e = getenv("QA_GEMM_BK16_MIN_TILES");
         return e ? atoll(e) : 384LL;
     }();
-    if (BN >= 64 && p.prologue != ACT_ELU && ((p.K <= bk16_max_k && tiles >= bk16_min_tiles) || p.C_in % 32 != 0))
+    static const bool linear_on = [] {
+        const char* e = getenv("QA_GEMM_LINEAR");
+        return !e || atoi(e) != 0;
+    }();
+    const bool linear = linear_on && p.ksize == 1 && p.stride == 1 && p.pad_left == 0 && p.in_rep <= 1 && p.T_in == p.T_out &&
+                        (p.dilation <= 1);
+    const bool bk16 = BN >= 64 && p.prologue != ACT_ELU && ((p.K <= bk16_max_k && tiles >= bk16_min_tiles) || p.C_in % 32 != 0);
+    if (bk16 && linear)
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, (BN >= 64 ? 16 : 32), true>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
+    else if (bk16)
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, (BN >= 64 ? 16 : 32)>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
     else if (p.prologue == ACT_ELU)
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
+    else if (linear)
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, 32, true>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
     else
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
     if (prof) profile_record_end(stream);
