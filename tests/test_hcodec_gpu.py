@@ -117,6 +117,18 @@ def test_hcodec10_full_size_parity(qa_lib, gpu_device):
     assert report["wav"] < 1e-3
 
 
+def test_baseline_config0_one_4s_clip(qa_lib, gpu_device):
+    """BASELINE.json configs[0] as a parity case: H-Codec 1.0, ONE 4 s 16 kHz clip, T = 64 000,
+    feat [1, 768, 200] -> codes [1, 4, 100] x 2 -> wav [1, 64 000]."""
+    spec_kwargs = {f: getattr(R.SPEC_10, f) for f in R.SPEC_10.__dataclass_fields__}
+    report, agree, (wav_g, wav_o) = _run_parity(spec_kwargs, B=1, T=64000, device=gpu_device, seed=4000)
+    print(report, agree)
+    bad = {k: v for k, v in report.items() if not v < STAGE_TOL}
+    assert not bad, bad
+    assert wav_g.shape == wav_o.shape == (1, 64000)
+    assert float((wav_g - wav_o).pow(2).mean().sqrt()) < 1e-3 and report["wav"] < 1e-4
+
+
 def test_encode_rejects_unpadded_wav(qa_lib, gpu_device):
     import unified_audio_amd as qa
 
