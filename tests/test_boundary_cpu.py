@@ -55,3 +55,39 @@ def test_tensor_table_accepts_reduced_precision_checkpoints_and_skips_integer_bu
     assert n == 4 and sorted(x.decode() for x in names) == ["a.weight", "b.weight", "c.weight", "f.weight"]
     assert all(t.dtype == torch.float32 and t.is_contiguous() for t in keep)
     assert torch.equal(keep[0], sd["a.weight"].float())
+
+
+def test_streaming_transformer_rejects_configurations_it_does_not_implement(qa_lib):
+    """Only the H-Codec 1.5 configuration of the mimi StreamingTransformer (transformer.py:722-736) is offered; anything else
+    fails at construction, not silently at run time."""
+    import unified_audio_amd as qa
+
+    for kw in (dict(positional_embedding="sin"), dict(gating="silu"), dict(norm="rms_norm"), dict(layer_scale=None),
+               dict(weights_per_step=4), dict(max_period=100.0)):
+        with pytest.raises(qa.QuarkAudioError):
+            qa.StreamingTransformer(64, 2, 1, 128, **kw)
+    m = qa.StreamingTransformer(64, 2, 1, 128, causal=True, context=4)
+    assert not m.is_streaming and m.streaming_offset == -1
+    with pytest.raises(qa.QuarkAudioError, match="no weights"):
+        m(torch.zeros(1, 2, 64))
+
+
+def test_causal_flags_are_read_from_the_reference_yaml(qa_lib):
+    """`causal:` / `context_frames:` / `context:` of config_adaptive_v3.yaml:84-105 reach the spec (shipped: causal false)."""
+    import copy
+
+    import yaml
+
+    from oracle import ref_shim
+    from unified_audio_amd.hcodec import _spec_from_config
+
+    if not ref_shim.reference_available():
+        pytest.skip("/root/reference is only mounted in the build container")
+    cfg = yaml.safe_load(open(os.path.join(ref_shim.REFERENCE_ROOT, "QuarkAudio-HCodec/HCodec-1.5/conf/config_adaptive_v3.yaml")))
+    spec = _spec_from_config(cfg)
+    assert (spec.agg_causal, spec.agg_context, spec.bt_causal, spec.bt_context, spec.causal) == (False, 16, False, 16, False)
+    cfg2 = copy.deepcopy(cfg)
+    cfg2["adaptive_config"]["aggregators"]["semantic_aggregator"].update(causal=True, context_frames=9)
+    cfg2["adaptive_config"]["transformer_kwargs"].update(causal=True, context=11)
+    spec2 = _spec_from_config(cfg2)
+    assert (spec2.agg_causal, spec2.agg_context, spec2.bt_causal, spec2.bt_context) == (True, 9, True, 11)

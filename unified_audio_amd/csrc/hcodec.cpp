@@ -1034,7 +1034,6 @@ int build(qa_hcodec* h, const HostTable& tab) {
                    sp.bt_causal, sp.bt_context);
         b.vec(&h->qemb_sem, "semantic_aggregator.query_embedding", sp.code_dim);
         b.vec(&h->qemb_ac, "acoustic_aggregator.query_embedding", sp.code_dim);
-        QA_REQUIRE(2 * sp.code_dim == sp.dec_dim || true, "unused");
     }
     if (!b.f.ok) return b.f.status;
     QA_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->host_sync), sizeof(int) * 4));
@@ -1258,7 +1257,7 @@ int qa_mimi_create(qa_mimi** out, const qa_mimi_spec* spec, const qa_tensor* ten
     const int hd = sp.d_model / sp.num_heads;
     QA_REQUIRE(hd == 32 || hd == 64 || hd == 96 || hd == 128, "qa_mimi_create: head_dim %d unsupported (32/64/96/128)", hd);
     QA_REQUIRE(sp.d_model % 32 == 0 && sp.dim_feedforward % 32 == 0, "qa_mimi_create: widths must be multiples of 32");
-    QA_REQUIRE(sp.context >= 0 && (sp.causal || sp.context == 0 || true), "qa_mimi_create: negative context");
+    QA_REQUIRE(sp.context >= 0 && sp.context <= MAX_POS, "qa_mimi_create: context %d outside [0, %d]", sp.context, MAX_POS);
     QA_HIP(hipSetDevice(device));
     std::unique_ptr<qa_mimi> m(new qa_mimi());
     m->spec = sp;
