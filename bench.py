@@ -265,7 +265,7 @@ def lm_bench(dev, rank, world, dist, batch, reps=2, task="se", n_enroll=0):
                          "frac": step_bytes / (ms_step * 1e-3) / 1e12 / HBM_PEAK_TBS,
                          "bytes_per_step": {"weights": w_body + w_head, "kv_cache_mean": kv},
                          "note": "whole decode step (62 dependent launches: 5 per layer + head + pick), prefill time included in the "
-                                 "denominator; the step is bound by ~4-6 us of latency per dependent launch, not by bytes (DESIGN.md)"},
+                                 "denominator; the step is bound by the latency of its dependent launches (3.1 us floor each, 5-10 us measured), not by bytes (DESIGN.md section 11)"},
             "config": {"workload": f"LLM_SFT.generate {task.upper()} task, {batch} segments x 5 s per GPU, prompt {prompt}, 33 global + 250 semantic steps",
                        "dtype": "f32"}}
 

@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         }
         __syncthreads();
         if (kt + 1 < n_tiles) fetch(kt + 1);
-        if (kt * 32 > wave_last_key || kt * 32 + 31 < wave_first_key) continue;  // wave-uniform: whole tile masked for this wave
+        // wave-uniform skips: the whole tile is masked for this wave, or the wave owns no query at all (the last query block of a
+        // sequence that is not a multiple of 128: at N = 283 three of the four waves of block 3 would multiply clamped rows)
+        if (kt * 32 > wave_last_key || kt * 32 + 31 < wave_first_key || q_blk0 + wave * 32 >= n_q) continue;
 
         // S^T = K Q^T
         f32x16 s;

@@ -26,11 +26,43 @@ namespace qa {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// streamed-once data (weights, KV rows): non-temporal 16-byte load
+// streamed-once data (weights, KV rows): non-temporal 16-byte load (tools/variants.py -DQA_LM_NT=0 builds the cached-load variant)
+#ifndef QA_LM_NT
+#define QA_LM_NT 1
+#endif
 __device__ __forceinline__ float4 ldg_nt(const float* p) {
+#if QA_LM_NT
     const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#endif
     return make_float4(v.x, v.y, v.z, v.w);
 }
+
+#ifdef QA_LM_TIMING  // tuning builds only (tools/variants.py): shader-cycle totals per GEMV kind and phase, wave 0 of every workgroup
+__device__ unsigned long long g_lm_timing[6][6];
+#define LMT_DECL long long lmt_last = __builtin_readcyclecounter(); const int lmt_kind = (MODE == GM_RESID && ATT) ? 4 : MODE;
+#define LMT_TICK(i)                                                                                          \
+    {                                                                                                        \
+        if ((i) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+        const long long now_ = __builtin_readcyclecounter();                                                 \
+        if (threadIdx.x == 0) atomicAdd(&g_lm_timing[lmt_kind][i], (unsigned long long)(now_ - lmt_last));   \
+        lmt_last = now_;                                                                                     \
+    }
+#define LMT_COUNT if (threadIdx.x == 0) atomicAdd(&g_lm_timing[lmt_kind][5], 1ULL);
+extern "C" int qa_debug_lm_timing(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lm_timing), sizeof(g_lm_timing)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[36] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_lm_timing), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define LMT_DECL
+#define LMT_TICK(i)
+#define LMT_COUNT
+#endif
 
 // merged attention output for 4 * NF consecutive channels k.. of row `row` (all inside one head since 8 | hd):
 // o = sum_s f_s o_s / sum_s f_s l_s with f_s = exp(m_s - max_s m_s); partial record = [o (hd) | m | l | pad2]
@@ -218,6 +250,7 @@ __global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a) {
     const int tile = blockIdx.x;
     const int K = a.K, M = a.M;
     const int kw = K >> 3, k0 = wave * kw, nchunk = kw >> 5;
+    LMT_DECL
     const float* wp = a.w + ((long long)tile * NT + (li & (NT - 1))) * K + k0 + 8 * kq;
     // weights do not depend on anything computed here: get the first batch in flight before touching the activations
     float4 wr[NB][2];
@@ -263,6 +296,7 @@ __global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a) {
                 }
             }
         __builtin_amdgcn_sched_barrier(0);  // keep every load of the batch ahead of the first MFMA (hipcc sinks them one by one)
+        LMT_TICK(0)
 #pragma unroll
         for (int c = 0; c < NB; ++c)
 #pragma unroll
@@ -280,6 +314,7 @@ __global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a) {
                 acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, w1.w, acc[m], 0, 0, 0);
             }
     }
+    LMT_TICK(1)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -294,7 +329,10 @@ __global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a) {
         }
     }
     __syncthreads();
+    LMT_TICK(2)
     gemv_epilogue<MT, NT, MODE>(a, part, s_sq, tile, tid, epi);
+    LMT_TICK(3)
+    LMT_COUNT
 }
 
 // The same GEMV for NARROW column tiles (NT = 4 * C columns, C = 1 or 2) on v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4x1
@@ -312,6 +350,7 @@ __global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a) {
     const int tile = blockIdx.x;
     const int K = a.K, M = a.M;
     const int kw = K >> 3, k0 = wave * kw, nstep = kw >> 4;
+    LMT_DECL
     const int kbase = k0 + 4 * p;
     const float* wp[C];
 #pragma unroll
@@ -353,6 +392,7 @@ __global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a) {
                 else xa[m][s] = *reinterpret_cast<const float4*>(xrow[m] + kbase + (s0 + s) * 16);
             }
         __builtin_amdgcn_sched_barrier(0);
+        LMT_TICK(0)
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -371,6 +411,7 @@ __global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a) {
                 }
             }
     }
+    LMT_TICK(1)
     // D of block (g, p): VGPR r = batch row 4g + r, lane & 3 = column; sum the 4 K phases (lane bits 2, 3)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -393,7 +434,10 @@ __global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a) {
         }
     }
     __syncthreads();
+    LMT_TICK(2)
     gemv_epilogue<MT, NT, MODE>(a, part, s_sq, tile, tid, epi);
+    LMT_TICK(3)
+    LMT_COUNT
 }
 
 // column-tile width: as wide as possible while the launch still spreads over >= 96 workgroups (measured on MI355X at B = 16:
