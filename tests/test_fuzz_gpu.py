@@ -106,3 +106,56 @@ def test_rvq_search_fuzz(qa_lib, gpu_device, n, Q, K, D, seed):
     assert excess.max() <= tol, (n, Q, K, D, float(excess.max()))
     assert (got[gap > tol] == best[gap > tol]).all()
     np.testing.assert_allclose(quant.cpu().numpy(), rvq_c.lookup_f32(got, cb), rtol=0, atol=1e-5)
+
+
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(hd=st.sampled_from([32, 64, 96, 128]), heads=st.integers(1, 3), B=st.integers(1, 3), T=st.integers(1, 300), causal=st.booleans(),
+       ctx=st.integers(0, 320), seed=st.integers(0, 2 ** 16))
+def test_mimi_attention_windows_fuzz(qa_lib, gpu_device, hd, heads, B, T, causal, ctx, seed):
+    """Every head_dim instance of `attention_kernel`, sequence lengths that are not multiples of the 32-key / 128-query tiles, and the
+    causal / context-window masks, through one mimi layer (QKV GEMM with fused RoPE -> attention -> out-proj -> FFN) against the oracle."""
+    import unified_audio_amd as qa
+    from oracle import hcodec15_ref as R15
+    from oracle import synth
+
+    d, ff = hd * heads, 64
+    sd = synth.mimi_state_dict(seed, d, 1, ff)
+    x = torch.randn(B, T, d, generator=torch.Generator().manual_seed(seed + 1))
+    with torch.no_grad():
+        ref = R15.mimi_transformer(sd, "transformer", x, 1, heads, causal, ctx)
+    m = qa.StreamingTransformer(d, heads, 1, ff, causal=causal, context=ctx or None, device=gpu_device, prefix="transformer").load_state_dict(sd)
+    y = m(x.to(gpu_device))
+    assert torch.isfinite(y).all()
+    assert rel_err(y, ref) < 5e-5, (hd, heads, B, T, causal, ctx)
+
+
+@settings(max_examples=20, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(hd=st.sampled_from([32, 64]), ctx=st.integers(2, 24), chunks=st.lists(st.integers(1, 24), min_size=1, max_size=12), seed=st.integers(0, 2 ** 16))
+def test_mimi_streaming_fuzz(qa_lib, gpu_device, hd, ctx, chunks, seed):
+    """Random chunk partitions against the oracle's RingKVCache restatement (pinned to the reference's module): ring wrap-around at any
+    phase, chunks as long as the ring (first query fully masked -> 0), two layers so that the ring feeds a second ring."""
+    import unified_audio_amd as qa
+    from oracle import hcodec15_ref as R15
+    from oracle import synth
+
+    chunks = [min(c, ctx) for c in chunks]
+    heads, layers, ff = 2, 2, 64
+    d = hd * heads
+    sd = synth.mimi_state_dict(seed, d, layers, ff)
+    x = torch.randn(2, sum(chunks), d, generator=torch.Generator().manual_seed(seed + 1))
+    st_ = R15.MimiStreamState(2, layers, heads, hd, ctx)
+    outs, at = [], 0
+    with torch.no_grad():
+        for c in chunks:
+            outs.append(R15.mimi_transformer(sd, "transformer", x[:, at:at + c], layers, heads, True, ctx, st_))
+            at += c
+    ref = torch.cat(outs, 1)
+    m = qa.StreamingTransformer(d, heads, layers, ff, causal=True, context=ctx, device=gpu_device, prefix="transformer").load_state_dict(sd)
+    xg, got, at = x.to(gpu_device), [], 0
+    with m.streaming(2):
+        for c in chunks:
+            got.append(m(xg[:, at:at + c]))
+            at += c
+    y = torch.cat(got, 1)
+    assert torch.isfinite(y).all()
+    assert rel_err(y, ref) < 5e-5, (hd, ctx, chunks)
