@@ -63,12 +63,17 @@ CASES_15 = [
 ]
 
 
-def run_case_15(name, seed, batch, samples, threshold):
+CASES_15_CAUSAL = [  # the YAML's `causal: true` + context windows for the aggregators and the bottleneck (config_adaptive_v3.yaml:84-105)
+    ("hcodec15_b2_causal_stacks", 1510, 2, 640 * 20, 0.66, dict(agg_causal=True, agg_context=6, bt_causal=True, bt_context=9)),
+]
+
+
+def run_case_15(name, seed, batch, samples, threshold, flags=None):
     import dataclasses
 
     from . import hcodec15_ref  # noqa: F401  (same spec object the tests use)
 
-    spec = dataclasses.replace(R.SPEC_15, agg_layers=2, bt_layers=2, threshold=threshold)
+    spec = dataclasses.replace(R.SPEC_15, agg_layers=2, bt_layers=2, threshold=threshold, **(flags or {}))
     sd = synth.hcodec10_state_dict(seed, spec)
     model = ref_shim.load_state(ref_shim.load_reference_codec("1.5", spec), sd)
     wav = R.pad_wav(synth.synth_wav(seed + 1, batch, samples))
@@ -78,6 +83,7 @@ def run_case_15(name, seed, batch, samples, threshold):
         rec = model.decode(codes["acoustic_codes"], codes["semantic_codes"])
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"), seed=seed, batch=batch, samples=samples, threshold=threshold,
+        **{k: int(v) for k, v in (flags or {}).items()},
         acoustic_codes=codes["acoustic_codes"].numpy().astype(np.int32), semantic_codes=codes["semantic_codes"].numpy().astype(np.int32),
         wav_rec=rec.numpy().astype(np.float32))
     print(name, tuple(codes["acoustic_codes"].shape), tuple(rec.shape), "lens", (codes["semantic_codes"][0, 0] // 1024 + 1).tolist())
@@ -113,6 +119,8 @@ def main():
     for c in CASES_CAUSAL:
         run_case(*c, causal=True)
     for c in CASES_15:
+        run_case_15(*c)
+    for c in CASES_15_CAUSAL:
         run_case_15(*c)
 
 

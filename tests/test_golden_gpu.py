@@ -58,7 +58,8 @@ def test_hip_path_reproduces_reference_golden_15(qa_lib, gpu_device, path):
 
     g = np.load(path)
     seed = int(g["seed"])
-    ospec = dataclasses.replace(R.SPEC_15, agg_layers=2, bt_layers=2, threshold=float(g["threshold"]))
+    flags = {k: (bool(g[k]) if k.endswith("causal") else int(g[k])) for k in ("agg_causal", "agg_context", "bt_causal", "bt_context") if k in g.files}
+    ospec = dataclasses.replace(R.SPEC_15, agg_layers=2, bt_layers=2, threshold=float(g["threshold"]), **flags)
     sd = synth.hcodec10_state_dict(seed, ospec)
     kw = {f: getattr(ospec, f) for f in ospec.__dataclass_fields__}
     tok = qa.HCodecTokenizer(state_dict=sd, device=gpu_device, spec=qa.HCodecSpec(**kw))

@@ -133,6 +133,8 @@ def test_oracle15_reproduces_reference_golden(path):
 
     g = np.load(path)
     seed, spec = int(g["seed"]), _spec15(float(g["threshold"]))
+    flags = {k: (bool(g[k]) if k.endswith("causal") else int(g[k])) for k in ("agg_causal", "agg_context", "bt_causal", "bt_context") if k in g.files}
+    spec = dataclasses.replace(spec, **flags)  # hcodec15_b2_causal_stacks: the reference built from the YAML with causal: true
     sd = synth.hcodec10_state_dict(seed, spec)
     wav = R.pad_wav(synth.synth_wav(seed + 1, int(g["batch"]), int(g["samples"])))
     feat = synth.synth_feat(seed + 2, int(g["batch"]), wav.shape[-1] // 320, spec.sem_in)
