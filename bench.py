@@ -495,6 +495,31 @@ def main():
         except Exception as e:  # noqa: BLE001
             extras["hcodec20_16x30s"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
 
+    if rank == 0 and world == 1 and not args.lean and not args.no_extras and args.model == "1.5":
+        try:
+            # (4) H-Codec 1.0 at the metric's own batch (32 x 10 s @16 kHz): the non-adaptive SEANet / ConvNeXt codec of configs[0], at size
+            log("H-Codec 1.0 32 x 10 s ...")
+            sd10 = synth.hcodec10_state_dict(1234, qa.SPEC_10)
+            codec10 = qa.Codec(None, None, None, spec=qa.SPEC_10, device=dev).load_state_dict(sd10)
+            n10 = sum(v.numel() for v in sd10.values())
+            del sd10
+            feats10 = synth.synth_feat(9 + rank, B, T // hop_in, qa.SPEC_10.sem_in).to(dev)
+            for i in range(6):
+                if i == 1:
+                    torch.cuda.synchronize(dev)
+                    t4 = time.perf_counter()
+                a10, s10 = codec10.encode(wav.unsqueeze(1), feats10)
+                rec10 = codec10.decode(a10, s10)
+            torch.cuda.synchronize(dev)
+            dt4 = (time.perf_counter() - t4) / 5
+            assert torch.isfinite(rec10).all()
+            extras["hcodec10_32x10s"] = {"value": B * T / SR / dt4, "unit": "audio-seconds/sec", "ms_per_step": 1e3 * dt4,
+                                         "config": {"workload": f"H-Codec 1.0 Codec.encode+Codec.decode ({n10 / 1e6:.0f} M parameters), {B} clips x "
+                                                                f"{T / SR:.0f} s @16 kHz, 4 + 4 codebooks, SSL features precomputed", "dtype": "f32"}}
+            del codec10, feats10, rec10
+        except Exception as e:  # noqa: BLE001
+            extras["hcodec10_32x10s"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+
     ssl_line = None
     if world == 1 and not args.lean and not args.no_ssl and args.model != "2.0":
         log("SSL front-end ...")
