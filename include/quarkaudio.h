@@ -91,7 +91,8 @@ typedef struct qa_hcodec_spec {
     int32_t enc_convnext_layers; /* 24 */
     int32_t frame_stride;     /* 4 = int(50 / target_frame_rate) */
     int32_t tr_inter_cap;     /* 4096: transformer MLP width = min(4*d, cap); 0 = 4*d */
-    /* causal variant of the SEANet-family graph (versions 0 / 10, with or without `adaptive`): every SConv1d pads
+    /* causal variant (all versions; 2.0: `causal` of encoder_config / decoder_config, codec_encoder.py:23, codec_decoder.py:25):
+     * every SConv1d pads
      * (k_eff - stride, extra) instead of splitting it (encoder_modules/conv.py:203-206), vq/conv.py's Conv1d /
      * ConvTranspose1d pad (k - 1, 0) (vq/conv.py:44-47,76-79) and both Transformers apply the tril mask
      * (encoder_modules/transformer.py:470-475).  vq/codec.py:31 ships causal=False. */

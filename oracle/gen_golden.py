@@ -93,11 +93,11 @@ SPEC20_SMALL = dict(enc_dim=256, enc_inter=512, enc_convnext_layers=2, enc_trans
                     codebook_size=64, num_quantizers=5, dec_dim=256, dec_inter=512, dec_convnext_layers=2, dec_transformer_layers=1)
 
 
-def run_case_20(name, seed, batch, samples):
+def run_case_20(name, seed, batch, samples, causal=False):
     """H-Codec 2.0 built by the reference from a reduced YAML (same code path as the 1.28 B-parameter configuration)."""
     from . import hcodec20_ref as R20
 
-    spec = R20.HCodec20Spec(**SPEC20_SMALL)
+    spec = R20.HCodec20Spec(**SPEC20_SMALL, causal=causal)
     sd = synth.hcodec20_state_dict(seed, spec)
     model = ref_shim.load_state(ref_shim.load_reference_codec("2.0", spec), sd)
     wav = R.pad_wav(synth.synth_wav_fullband(seed + 1, batch, samples), spec.frame_hop)
@@ -105,7 +105,7 @@ def run_case_20(name, seed, batch, samples):
     with torch.no_grad():
         ac, sc = model.encode(wav, feat)
         rec = model.decode(ac, sc)
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, batch=batch, samples=samples,
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, batch=batch, samples=samples, causal=int(causal),
                         acoustic_codes=ac.numpy().astype(np.int16), semantic_codes=sc.numpy().astype(np.int16),
                         wav_rec=rec.numpy().astype(np.float32))
     print(name, tuple(ac.shape), tuple(rec.shape))
@@ -114,6 +114,7 @@ def run_case_20(name, seed, batch, samples):
 def main():
     os.makedirs(OUT, exist_ok=True)
     run_case_20("hcodec20_small_b2", 2000, 2, 3840 * 5 + 1000)
+    run_case_20("hcodec20_small_b2_causal", 2001, 2, 3840 * 4 + 500, causal=True)
     for c in CASES:
         run_case(*c)
     for c in CASES_CAUSAL:

@@ -48,6 +48,7 @@ class HCodec20Spec:
     dec_transformer_layers: int = 2
     gn_groups: int = 32
     tr_inter_cap: int = 4096  # min(dim * 4, 4096), codec_encoder.py:49
+    causal: bool = False  # `causal` of encoder_config / decoder_config (codec_encoder.py:23, codec_decoder.py:25; the YAML ships false)
 
     @property
     def frame_hop(self) -> int:  # samples per code frame (audio_tokenizer.py:41)
@@ -67,8 +68,14 @@ class HCodec20Spec:
 SPEC_20 = HCodec20Spec()
 
 
-def _transformer(sd: SD, p: str, x: Tensor, layers: int, heads: int, taps=None) -> Tensor:
-    return R.transformer(sd, p, x, layers, heads, taps)  # MLP width is read off the weights (w1: [inter, d])
+def _transformer(sd: SD, p: str, x: Tensor, layers: int, heads: int, taps=None, causal: bool = False) -> Tensor:
+    return R.transformer(sd, p, x, layers, heads, taps, causal)  # MLP width is read off the weights (w1: [inter, d])
+
+
+def _conv(x: Tensor, w: Tensor, b: Tensor, stride: int, causal: bool) -> Tensor:
+    """vq/conv.py Conv1d (:32-56): ConstantPad1d (k - stride, 0) if causal else (k // 2, k // 2), then a plain strided Conv1d."""
+    k = w.shape[-1]
+    return F.conv1d(F.pad(x, (k - stride, 0) if causal else (k // 2, k // 2)), w, b, stride=stride)
 
 
 def codec_encoder(sd: SD, wav: Tensor, spec: HCodec20Spec = SPEC_20, taps=None) -> Tensor:
@@ -81,17 +88,17 @@ def codec_encoder(sd: SD, wav: Tensor, spec: HCodec20Spec = SPEC_20, taps=None) 
     if taps is not None:
         taps["enc.stft"] = x
     p = "encoder"
-    x = F.conv1d(F.pad(x, (1, 1)), sd[p + ".embed.conv.weight"], sd[p + ".embed.conv.bias"])
+    cz = spec.causal
+    x = _conv(x, sd[p + ".embed.conv.weight"], sd[p + ".embed.conv.bias"], 1, cz)
     c = x.shape[1]
     x = F.layer_norm(x.transpose(1, 2), (c,), sd[p + ".norm.weight"], sd[p + ".norm.bias"], eps=1e-6).transpose(1, 2)
     for i in range(spec.enc_convnext_layers):
-        x = R.convnext_block(sd, f"{p}.prior_net.{i}", x)
+        x = R.convnext_block(sd, f"{p}.prior_net.{i}", x, cz)
     if taps is not None:
         taps["enc.prior"] = x
-    x = _transformer(sd, p + ".post_net.1", x.transpose(1, 2), spec.enc_transformer_layers, c // 64, taps).transpose(1, 2)
+    x = _transformer(sd, p + ".post_net.1", x.transpose(1, 2), spec.enc_transformer_layers, c // 64, taps, cz).transpose(1, 2)
     x = F.layer_norm(x.transpose(1, 2), (c,), sd[p + ".final_layer_norm.weight"], sd[p + ".final_layer_norm.bias"], eps=1e-6).transpose(1, 2)
-    k = 2 * spec.stride + 1
-    return F.conv1d(F.pad(x, (k // 2, k // 2)), sd[p + ".out.conv.weight"], sd[p + ".out.conv.bias"], stride=spec.stride)
+    return _conv(x, sd[p + ".out.conv.weight"], sd[p + ".out.conv.bias"], spec.stride, cz)
 
 
 def encode(sd: SD, wav: Tensor, feat: Tensor, spec: HCodec20Spec = SPEC_20, taps=None):
@@ -109,21 +116,21 @@ def codec_decoder(sd: SD, x: Tensor, spec: HCodec20Spec = SPEC_20, taps=None) ->
     """codec_decoder.py:61-72."""
     p = "decoder"
     s10 = spec.as_10(spec.dec_dim, spec.dec_transformer_layers)
+    cz = spec.causal
     x = x.repeat_interleave(spec.stride, dim=-1)
-    k = spec.stride + 1
-    x = F.conv1d(F.pad(x, (k // 2, k // 2)), sd[p + ".embed.conv.weight"], sd[p + ".embed.conv.bias"])
+    x = _conv(x, sd[p + ".embed.conv.weight"], sd[p + ".embed.conv.bias"], 1, cz)
     if taps is not None:
         taps["dec.embed"] = x
-    x = R.resnet_block(sd, p + ".prior_net.0", x, spec.gn_groups)
-    x = R.resnet_block(sd, p + ".prior_net.1", x, spec.gn_groups)
+    x = R.resnet_block(sd, p + ".prior_net.0", x, spec.gn_groups, cz)
+    x = R.resnet_block(sd, p + ".prior_net.1", x, spec.gn_groups, cz)
     c = x.shape[1]
-    x = _transformer(sd, p + ".prior_net.3", x.transpose(1, 2), spec.dec_transformer_layers, c // 64, taps).transpose(1, 2)
-    x = R.resnet_block(sd, p + ".prior_net.5", x, spec.gn_groups)
-    x = R.resnet_block(sd, p + ".prior_net.6", x, spec.gn_groups)
+    x = _transformer(sd, p + ".prior_net.3", x.transpose(1, 2), spec.dec_transformer_layers, c // 64, taps, cz).transpose(1, 2)
+    x = R.resnet_block(sd, p + ".prior_net.5", x, spec.gn_groups, cz)
+    x = R.resnet_block(sd, p + ".prior_net.6", x, spec.gn_groups, cz)
     x = F.group_norm(x, spec.gn_groups, sd[p + ".prior_net.7.weight"], sd[p + ".prior_net.7.bias"], eps=1e-6)
     x = F.layer_norm(x.transpose(1, 2), (c,), sd[p + ".norm.weight"], sd[p + ".norm.bias"], eps=1e-6).transpose(1, 2)
     for i in range(spec.dec_convnext_layers):
-        x = R.convnext_block(sd, f"{p}.post_net.{i}", x)
+        x = R.convnext_block(sd, f"{p}.post_net.{i}", x, cz)
     x = F.layer_norm(x.transpose(1, 2), (c,), sd[p + ".final_layer_norm.weight"], sd[p + ".final_layer_norm.bias"], eps=1e-6)
     if taps is not None:
         taps["dec.backbone"] = x

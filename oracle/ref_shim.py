@@ -49,10 +49,10 @@ def _config_20(spec):
         rate = 50.0 / spec.stride
         cfg["encoder_config"].update(dim=spec.enc_dim, intermediate_dim=spec.enc_inter, dimension=spec.dimension, n_fft=spec.n_fft,
                                      hop_length=spec.hop, convnext_layers=spec.enc_convnext_layers,
-                                     transformer_layers=spec.enc_transformer_layers, target_frame_rate=rate)
+                                     transformer_layers=spec.enc_transformer_layers, target_frame_rate=rate, causal=spec.causal)
         cfg["decoder_config"].update(input_channels=2 * spec.dimension, dim=spec.dec_dim, intermediate_dim=spec.dec_inter,
                                      convnext_layers=spec.dec_convnext_layers, transformer_layers=spec.dec_transformer_layers,
-                                     n_fft=spec.n_fft, hop_length=spec.hop, target_frame_rate=rate)
+                                     n_fft=spec.n_fft, hop_length=spec.hop, target_frame_rate=rate, causal=spec.causal)
         cfg["quantizer_config"].update(dim=spec.dimension, codebook_size=spec.codebook_size, num_quantizers=spec.num_quantizers)
         for k, a, b in (("semantic_encoder_config", "input_channels", "encode_channels"),):
             cfg[k].update({a: spec.sem_in, b: spec.sem_ch, "out_channels": spec.dimension, "strides": list(spec.sem_strides),

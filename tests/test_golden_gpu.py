@@ -84,20 +84,22 @@ def test_hip_path_reproduces_reference_golden_15(qa_lib, gpu_device, path):
     assert rms < 1e-3 and rms / float(np.sqrt(np.mean(g["wav_rec"] ** 2))) < 1e-4, rms
 
 
-def test_hip_path_reproduces_reference_golden_20(qa_lib, gpu_device):
-    """H-Codec 2.0 against vectors produced by the reference's vq.Codec built from a reduced YAML."""
+@pytest.mark.parametrize("name", ["hcodec20_small_b2", "hcodec20_small_b2_causal"])
+def test_hip_path_reproduces_reference_golden_20(qa_lib, gpu_device, name):
+    """H-Codec 2.0 against vectors produced by the reference's vq.Codec built from a reduced YAML (the second with `causal: true`)."""
     import unified_audio_amd as qa
     from oracle import hcodec20_ref as R20
     from oracle.gen_golden import SPEC20_SMALL
 
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hcodec20_small_b2.npz"))
-    seed, o = int(g["seed"]), R20.HCodec20Spec(**SPEC20_SMALL)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    causal = bool(int(g["causal"])) if "causal" in g.files else False
+    seed, o = int(g["seed"]), R20.HCodec20Spec(**SPEC20_SMALL, causal=causal)
     sd = synth.hcodec20_state_dict(seed, o)
     pspec = qa.HCodecSpec(version=20, enc_dim=o.enc_dim, enc_inter=o.enc_inter, enc_convnext_layers=o.enc_convnext_layers,
                           enc_layers=o.enc_transformer_layers, frame_stride=o.stride, tr_inter_cap=o.tr_inter_cap, dimension=o.dimension,
                           code_dim=o.dimension, sem_in=o.sem_in, sem_ch=o.sem_ch, sem_strides=o.sem_strides, codebook_size=o.codebook_size,
                           num_quantizers=o.num_quantizers, dec_dim=o.dec_dim, dec_inter=o.dec_inter, dec_heads=o.dec_dim // 64,
-                          dec_layers=o.dec_transformer_layers, convnext_layers=o.dec_convnext_layers, n_fft=o.n_fft, hop=o.hop)
+                          dec_layers=o.dec_transformer_layers, convnext_layers=o.dec_convnext_layers, n_fft=o.n_fft, hop=o.hop, causal=causal)
     tok = qa.HCodecTokenizer(state_dict=sd, device=gpu_device, spec=pspec)
     assert tok.hop_length == 3840  # int(sampling_rate / target_frame_rate), HCodec-2.0/audio_tokenizer.py:41
     wav = synth.synth_wav_fullband(seed + 1, int(g["batch"]), int(g["samples"]))

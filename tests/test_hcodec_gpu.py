@@ -226,7 +226,7 @@ def _run_parity_20(ospec, B, T, device, seed=51, tol=STAGE_TOL):
                           sem_strides=ospec.sem_strides, codebook_size=ospec.codebook_size, num_quantizers=ospec.num_quantizers,
                           dec_dim=ospec.dec_dim, dec_inter=ospec.dec_inter, dec_heads=ospec.dec_dim // 64,
                           dec_layers=ospec.dec_transformer_layers, convnext_layers=ospec.dec_convnext_layers, n_fft=ospec.n_fft,
-                          hop=ospec.hop, gn_groups=ospec.gn_groups)
+                          hop=ospec.hop, gn_groups=ospec.gn_groups, causal=ospec.causal)
     codec = qa.Codec(None, None, None, spec=pspec, device=device).load_state_dict(sd)
     codec.enable_taps()
     wav = synth.synth_wav_fullband(seed + 1, B, T)
@@ -271,6 +271,20 @@ def test_hcodec20_full_width_parity(qa_lib, gpu_device):
     print(report, agree)
     assert all(v < 2 * STAGE_TOL for v in report.values()), report
     assert min(agree) > 0.95
+
+
+def test_hcodec20_causal_parity(qa_lib, gpu_device):
+    """`causal: true` of the H-Codec 2.0 YAML (pinned to the reference built from it in tests/test_oracle_cpu.py)."""
+    import dataclasses
+
+    from oracle import hcodec20_ref as R20
+
+    ospec = dataclasses.replace(R20.HCodec20Spec(enc_dim=256, enc_inter=512, enc_convnext_layers=2, enc_transformer_layers=1, dimension=128,
+                                                 sem_in=64, sem_ch=128, codebook_size=64, num_quantizers=5, dec_dim=256, dec_inter=512,
+                                                 dec_convnext_layers=2, dec_transformer_layers=1), causal=True)
+    report, agree = _run_parity_20(ospec, B=2, T=3840 * 6, device=gpu_device, seed=53)
+    print(report, agree)
+    assert all(v < STAGE_TOL for v in report.values()), report
 
 
 def test_hcodec20_full_depth_parity(qa_lib, gpu_device):

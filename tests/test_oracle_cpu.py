@@ -220,11 +220,14 @@ def _spec20_small():
     return R20.HCodec20Spec(**SPEC20_SMALL)
 
 
-def test_oracle20_reproduces_reference_golden():
+@pytest.mark.parametrize("name", ["hcodec20_small_b2", "hcodec20_small_b2_causal"])
+def test_oracle20_reproduces_reference_golden(name):
     from oracle import hcodec20_ref as R20
 
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hcodec20_small_b2.npz"))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
     seed, spec = int(g["seed"]), _spec20_small()
+    if "causal" in g.files and int(g["causal"]):
+        spec = dataclasses.replace(spec, causal=True)
     sd = synth.hcodec20_state_dict(seed, spec)
     wav = R.pad_wav(synth.synth_wav_fullband(seed + 1, int(g["batch"]), int(g["samples"])), spec.frame_hop)
     feat = synth.synth_feat(seed + 2, int(g["batch"]), wav.shape[-1] // spec.hop, spec.sem_in)
@@ -252,3 +255,29 @@ def test_restatement20_matches_reference_modules():
         ac, sc = R20.encode(sd, wav, feat, spec)
         assert torch.equal(ac, ac_r) and torch.equal(sc, sc_r)
         assert float((R20.decode(sd, ac_r, sc_r, spec) - model.decode(ac_r, sc_r)).abs().max()) < 1e-5
+
+
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference is only mounted in the build container")
+def test_restatement20_causal_matches_reference_modules():
+    """`causal: true` in encoder_config / decoder_config of the H-Codec 2.0 YAML (codec_encoder.py:23, codec_decoder.py:25; shipped
+    false): causal Conv1d paddings of the embed / out / decoder-embed convolutions, the ConvNeXt depthwise and ResnetBlock k3, tril masks."""
+    import dataclasses
+
+    from oracle import hcodec20_ref as R20
+
+    spec = dataclasses.replace(_spec20_small(), causal=True)
+    sd = synth.hcodec20_state_dict(41, spec)
+    model = ref_shim.load_state(ref_shim.load_reference_codec("2.0", spec), sd)
+    wav = synth.synth_wav_fullband(42, 2, 3840 * 5)
+    feat = synth.synth_feat(43, 2, wav.shape[-1] // spec.hop, spec.sem_in)
+    with torch.no_grad():
+        emb_r = model.encoder(wav)
+        emb = R20.codec_encoder(sd, wav, spec)
+        assert float((emb - emb_r).abs().max()) < 2e-5 * float(emb_r.abs().max())
+        ac_r, sc_r = model.encode(wav, feat)
+        ac, sc = R20.encode(sd, wav, feat, spec)
+        assert torch.equal(ac, ac_r) and torch.equal(sc, sc_r)
+        w_r, w = model.decode(ac_r, sc_r), R20.decode(sd, ac_r, sc_r, spec)
+        assert float((w - w_r).abs().max()) < 1e-5 * max(1.0, float(w_r.abs().max()))
+        w_plain = R20.decode(sd, ac_r, sc_r, _spec20_small())
+    assert float((w - w_plain).abs().max()) > 1e-3 * float(w_r.abs().max())

@@ -530,17 +530,20 @@ int encoder20(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, float** emb_
     float* x = c.arena.alloc<float>(rows * d);
     float* t1 = c.arena.alloc<float>(rows * d);
     float* u = c.arena.alloc<float>(rows * sp.enc_inter);
-    QA_TRY(conv_op(c, feat, h->stft_ld, B, N50, h->enc_embed, t1, d, N50, 1, 1, 1, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, nullptr, 0,
-                   nullptr, ACT_NONE));
+    // vq/conv.py Conv1d (:39-47): zero padding (k - stride, 0) in the causal variant, (k / 2, k / 2) otherwise
+    const bool cz = sp.causal != 0;
+    QA_TRY(conv_op(c, feat, h->stft_ld, B, N50, h->enc_embed, t1, d, N50, 1, cz ? 2 : 1, cz ? 0 : 1, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr,
+                   nullptr, 0, nullptr, ACT_NONE));
     if (!c.dry) QA_TRY(launch_layernorm(t1, h->enc_norm_w, h->enc_norm_b, x, rows, d, 1e-6f, c.stream));
-    for (const ConvNeXtW& w : h->enc_cnx) QA_TRY(convnext_op(c, w, x, t1, u, B, N50, d));
+    for (const ConvNeXtW& w : h->enc_cnx) QA_TRY(convnext_op(c, w, x, t1, u, B, N50, d, cz));
     c.tap("enc.prior", x, rows * d);
-    QA_TRY(transformer_op(c, h->enc_tr, x, B, N50, "encoder.post_net.1"));
+    QA_TRY(transformer_op(c, h->enc_tr, x, B, N50, "encoder.post_net.1", cz));
     if (!c.dry) QA_TRY(launch_layernorm(x, h->enc_fnorm_w, h->enc_fnorm_b, t1, rows, d, 1e-6f, c.stream));
-    const int k = h->enc_out20.ksize, pad = k / 2, st = sp.frame_stride;
-    const int Nf = (N50 + 2 * pad - k) / st + 1;
+    const int k = h->enc_out20.ksize, st = sp.frame_stride;
+    const int pl = cz ? k - st : k / 2, pr = cz ? 0 : k / 2;
+    const int Nf = (N50 + pl + pr - k) / st + 1;
     float* emb = c.arena.alloc<float>((size_t)B * Nf * sp.code_dim);
-    QA_TRY(conv_op(c, t1, d, B, N50, h->enc_out20, emb, sp.code_dim, Nf, st, pad, pad, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, nullptr,
+    QA_TRY(conv_op(c, t1, d, B, N50, h->enc_out20, emb, sp.code_dim, Nf, st, pl, pr, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, nullptr,
                    0, nullptr, ACT_NONE));
     *emb_out = emb;
     *n50_out = N50;
@@ -704,8 +707,8 @@ int decode_tail(qa_hcodec* h, Ctx& c, const float* cat, int B, int N, float* wav
         // H-Codec 2.0 (codec_decoder.py:30-31,64-65): x.repeat_interleave(s) -> Conv1d k = s + 1, "same" zero padding.  The
         // repetition is folded into the implicit-GEMM gather (frame r reads row r / s), nothing is materialised.
         const int k = h->dec_embed20.ksize;
-        QA_TRY(conv_op(c, cat, 2 * sp.code_dim, B, N, h->dec_embed20, x, d, N50, 1, k / 2, k / 2, PAD_ZERO, ACT_NONE, ACT_NONE,
-                       nullptr, nullptr, 0, nullptr, ACT_NONE, sp.frame_stride));
+        QA_TRY(conv_op(c, cat, 2 * sp.code_dim, B, N, h->dec_embed20, x, d, N50, 1, cz ? k - 1 : k / 2, cz ? 0 : k / 2, PAD_ZERO, ACT_NONE,
+                       ACT_NONE, nullptr, nullptr, 0, nullptr, ACT_NONE, sp.frame_stride));
     } else {
         float* up = c.arena.alloc<float>(rows25 * 2 * d);
         QA_TRY(linear_op(c, cat, rows25, h->up, up));
@@ -840,7 +843,6 @@ int build(qa_hcodec* h, const HostTable& tab) {
     const bool v20 = sp.version == 20;
     QA_REQUIRE(sp.version == 0 || sp.version == 10 || sp.version == 15 || v20, "spec: unknown version %d", sp.version);
     QA_REQUIRE(!(v20 && sp.adaptive), "spec: H-Codec 2.0 has no adaptive frame rate");
-    QA_REQUIRE(!(v20 && sp.causal), "spec: the causal variant is built for the SEANet family (versions 0 / 10) only");
     QA_REQUIRE(sp.n_sem_strides >= 1 && sp.n_sem_strides <= 4, "spec: bad counts");
     QA_REQUIRE(v20 || (sp.n_ratios >= 1 && sp.n_ratios <= 8 && sp.n_filters % 32 == 0), "spec: bad SEANet ladder");
     QA_REQUIRE((v20 ? sp.enc_dim : sp.dimension) % 128 == 0 && sp.dec_dim % 128 == 0, "spec: transformer widths must be multiples of 128");

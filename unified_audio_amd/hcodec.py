@@ -140,7 +140,7 @@ def _spec_from_config(config: dict, device=None) -> HCodecSpec:
                       code_dim=qz["dim"], codebook_size=qz["codebook_size"], num_quantizers=qz["num_quantizers"],
                       dec_dim=dec["dim"], dec_inter=dec["intermediate_dim"], dec_heads=dec["dim"] // 64,
                       dec_layers=dec["transformer_layers"], convnext_layers=dec["convnext_layers"], n_fft=enc["n_fft"],
-                      hop=enc["hop_length"])
+                      hop=enc["hop_length"], causal=bool(enc.get("causal", False)))
 
 
 class Codec(torch.nn.Module):
