@@ -308,6 +308,36 @@ def bicodec_bench(dev, batch, reps=3):
                                    f"250 semantic + 32 global tokens -> {batch} x 80 000 samples @16 kHz", "dtype": "f32"}}
 
 
+def rvq_bench(dev, lib, n_vec, Q, K=1024, D=512, reps=5):
+    """The RVQ search by itself (qa_rvq_search = ResidualVQ.forward) at the shape of one stream of BASELINE configs[4]:
+    n_vec residual vectors x Q stages against K x D codebooks (codebooks scaled 0.5^q per stage like the synthetic checkpoints).
+    FLOPs = the distance products 2 K D per vector-stage; bytes = codebooks once + vectors in / residual update per stage."""
+    from unified_audio_amd import _lib
+
+    g = torch.Generator().manual_seed(2024)
+    cb = torch.stack([torch.randn(K, D, generator=g) * 0.5 ** q for q in range(Q)]).to(dev)
+    x = torch.randn(n_vec, D, generator=g).to(dev)
+    idx = torch.empty(n_vec, Q, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def run():
+        _lib.check(lib.qa_rvq_search(x.data_ptr(), n_vec, cb.data_ptr(), Q, K, D, idx.data_ptr(), None, C.c_void_p(stream)))
+
+    run()
+    torch.cuda.synchronize(dev)
+    assert int(idx.min()) >= 0 and int(idx.max()) < K
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / reps
+    flop = 2.0 * n_vec * Q * K * D
+    return {"metric": "RVQ search vectors/sec (qa_rvq_search)", "value": n_vec / dt, "unit": "vectors/sec", "ms_per_call": 1e3 * dt,
+            "tflops": flop / dt / 1e12, "frac_of_f32_mfma_peak": flop / dt / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "config": {"workload": f"{n_vec} vectors x {Q} stages x {K} codes x {D} dims (one of the two code streams), vectors resident in HBM",
+                       "dtype": "f32 distances, int64 indices"}}
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -519,6 +549,16 @@ def main():
             del codec10, feats10, rec10
         except Exception as e:  # noqa: BLE001
             extras["hcodec10_32x10s"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+
+    if rank == 0 and world == 1 and not args.lean and not args.no_extras:
+        try:
+            # (5) the RVQ search alone at configs[4]'s shape: 16 stages x 1024 x 512; 6 000 vectors = the per-GPU share
+            #     (16 clips x 375 frames), 48 000 = the whole configuration's 128 clips on one GPU
+            log("RVQ search at the configs[4] shape ...")
+            extras["rvq_search_6000x16"] = rvq_bench(dev, lib, 6000, 16)
+            extras["rvq_search_48000x16"] = rvq_bench(dev, lib, 48000, 16, reps=3)
+        except Exception as e:  # noqa: BLE001
+            extras["rvq_search_6000x16"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
 
     ssl_line = None
     if world == 1 and not args.lean and not args.no_ssl and args.model != "2.0":
