@@ -24,3 +24,6 @@ for i in range(REPS):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"B={B} generate {dt * 1e3:.1f} ms  {B * (33 + S) / dt:.0f} tok/s", flush=True)
+# checksum of the token streams: A/B builds that must not change a single token (tools/variants.py) are compared on it
+w = torch.arange(1, s.shape[1] + 1, device=s.device)
+print(f"ids checksum global {int((g * w[: g.shape[1]]).sum())} semantic {int((s * w).sum())}", flush=True)
