@@ -68,12 +68,17 @@ CASES_15_CAUSAL = [  # the YAML's `causal: true` + context windows for the aggre
 ]
 
 
-def run_case_15(name, seed, batch, samples, threshold, flags=None):
+CASES_15_FULL = [  # the published depth itself: 32-layer aggregators and bottleneck (654 M parameters), the reference's vq.Codec on CPU
+    ("hcodec15_b2_full_depth", 1520, 2, 640 * 48 + 50, 0.72, None, 32),
+]
+
+
+def run_case_15(name, seed, batch, samples, threshold, flags=None, layers=2):
     import dataclasses
 
     from . import hcodec15_ref  # noqa: F401  (same spec object the tests use)
 
-    spec = dataclasses.replace(R.SPEC_15, agg_layers=2, bt_layers=2, threshold=threshold, **(flags or {}))
+    spec = dataclasses.replace(R.SPEC_15, agg_layers=layers, bt_layers=layers, threshold=threshold, **(flags or {}))
     sd = synth.hcodec10_state_dict(seed, spec)
     model = ref_shim.load_state(ref_shim.load_reference_codec("1.5", spec), sd)
     wav = R.pad_wav(synth.synth_wav(seed + 1, batch, samples))
@@ -82,7 +87,7 @@ def run_case_15(name, seed, batch, samples, threshold, flags=None):
         codes = model.encode(wav.unsqueeze(1), feat)
         rec = model.decode(codes["acoustic_codes"], codes["semantic_codes"])
     np.savez_compressed(
-        os.path.join(OUT, name + ".npz"), seed=seed, batch=batch, samples=samples, threshold=threshold,
+        os.path.join(OUT, name + ".npz"), seed=seed, batch=batch, samples=samples, threshold=threshold, layers=layers,
         **{k: int(v) for k, v in (flags or {}).items()},
         acoustic_codes=codes["acoustic_codes"].numpy().astype(np.int32), semantic_codes=codes["semantic_codes"].numpy().astype(np.int32),
         wav_rec=rec.numpy().astype(np.float32))
@@ -93,11 +98,12 @@ SPEC20_SMALL = dict(enc_dim=256, enc_inter=512, enc_convnext_layers=2, enc_trans
                     codebook_size=64, num_quantizers=5, dec_dim=256, dec_inter=512, dec_convnext_layers=2, dec_transformer_layers=1)
 
 
-def run_case_20(name, seed, batch, samples, causal=False):
-    """H-Codec 2.0 built by the reference from a reduced YAML (same code path as the 1.28 B-parameter configuration)."""
+def run_case_20(name, seed, batch, samples, causal=False, full=False):
+    """H-Codec 2.0 built by the reference from a reduced YAML (same code path as the 1.28 B-parameter configuration), or - `full` -
+    from the shipped large_12.5hz_config.yaml shapes themselves (24 + 32 ConvNeXt blocks at width 1536, 16 + 16 codebooks)."""
     from . import hcodec20_ref as R20
 
-    spec = R20.HCodec20Spec(**SPEC20_SMALL, causal=causal)
+    spec = R20.HCodec20Spec(causal=causal) if full else R20.HCodec20Spec(**SPEC20_SMALL, causal=causal)
     sd = synth.hcodec20_state_dict(seed, spec)
     model = ref_shim.load_state(ref_shim.load_reference_codec("2.0", spec), sd)
     wav = R.pad_wav(synth.synth_wav_fullband(seed + 1, batch, samples), spec.frame_hop)
@@ -105,7 +111,7 @@ def run_case_20(name, seed, batch, samples, causal=False):
     with torch.no_grad():
         ac, sc = model.encode(wav, feat)
         rec = model.decode(ac, sc)
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, batch=batch, samples=samples, causal=int(causal),
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, batch=batch, samples=samples, causal=int(causal), full=int(full),
                         acoustic_codes=ac.numpy().astype(np.int16), semantic_codes=sc.numpy().astype(np.int16),
                         wav_rec=rec.numpy().astype(np.float32))
     print(name, tuple(ac.shape), tuple(rec.shape))
@@ -113,6 +119,13 @@ def run_case_20(name, seed, batch, samples, causal=False):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    import sys
+
+    if "--full" in sys.argv:  # the two published configurations at full size (minutes of CPU time, ~10 GB of host memory)
+        for c in CASES_15_FULL:
+            run_case_15(*c)
+        run_case_20("hcodec20_b1_full", 2010, 1, 3840 * 12 + 700, full=True)
+        return
     run_case_20("hcodec20_small_b2", 2000, 2, 3840 * 5 + 1000)
     run_case_20("hcodec20_small_b2_causal", 2001, 2, 3840 * 4 + 500, causal=True)
     for c in CASES:

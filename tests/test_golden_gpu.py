@@ -51,7 +51,8 @@ GOLDEN_15 = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file
 
 @pytest.mark.parametrize("path", GOLDEN_15, ids=[os.path.basename(p)[:-4] for p in GOLDEN_15])
 def test_hip_path_reproduces_reference_golden_15(qa_lib, gpu_device, path):
-    """H-Codec 1.5 (full width, 2-layer adaptive stacks) against vectors produced by the reference's vq.Codec."""
+    """H-Codec 1.5 (full width; 2-layer adaptive stacks, or - hcodec15_b2_full_depth - the published 32-layer stacks) against vectors
+    produced by the reference's vq.Codec."""
     import dataclasses
 
     import unified_audio_amd as qa
@@ -59,7 +60,8 @@ def test_hip_path_reproduces_reference_golden_15(qa_lib, gpu_device, path):
     g = np.load(path)
     seed = int(g["seed"])
     flags = {k: (bool(g[k]) if k.endswith("causal") else int(g[k])) for k in ("agg_causal", "agg_context", "bt_causal", "bt_context") if k in g.files}
-    ospec = dataclasses.replace(R.SPEC_15, agg_layers=2, bt_layers=2, threshold=float(g["threshold"]), **flags)
+    layers = int(g["layers"]) if "layers" in g.files else 2  # hcodec15_b2_full_depth: the published 32-layer stacks
+    ospec = dataclasses.replace(R.SPEC_15, agg_layers=layers, bt_layers=layers, threshold=float(g["threshold"]), **flags)
     sd = synth.hcodec10_state_dict(seed, ospec)
     kw = {f: getattr(ospec, f) for f in ospec.__dataclass_fields__}
     tok = qa.HCodecTokenizer(state_dict=sd, device=gpu_device, spec=qa.HCodecSpec(**kw))
@@ -84,16 +86,18 @@ def test_hip_path_reproduces_reference_golden_15(qa_lib, gpu_device, path):
     assert rms < 1e-3 and rms / float(np.sqrt(np.mean(g["wav_rec"] ** 2))) < 1e-4, rms
 
 
-@pytest.mark.parametrize("name", ["hcodec20_small_b2", "hcodec20_small_b2_causal"])
+@pytest.mark.parametrize("name", ["hcodec20_small_b2", "hcodec20_small_b2_causal", "hcodec20_b1_full"])
 def test_hip_path_reproduces_reference_golden_20(qa_lib, gpu_device, name):
-    """H-Codec 2.0 against vectors produced by the reference's vq.Codec built from a reduced YAML (the second with `causal: true`)."""
+    """H-Codec 2.0 against vectors produced by the reference's vq.Codec built from a reduced YAML (the second with `causal: true`) and -
+    hcodec20_b1_full - from the shipped large_12.5hz_config.yaml shapes (24 + 32 ConvNeXt blocks at width 1536, 1.17 G parameters)."""
     import unified_audio_amd as qa
     from oracle import hcodec20_ref as R20
     from oracle.gen_golden import SPEC20_SMALL
 
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
     causal = bool(int(g["causal"])) if "causal" in g.files else False
-    seed, o = int(g["seed"]), R20.HCodec20Spec(**SPEC20_SMALL, causal=causal)
+    full = bool(int(g["full"])) if "full" in g.files else False
+    seed, o = int(g["seed"]), (R20.HCodec20Spec(causal=causal) if full else R20.HCodec20Spec(**SPEC20_SMALL, causal=causal))
     sd = synth.hcodec20_state_dict(seed, o)
     pspec = qa.HCodecSpec(version=20, enc_dim=o.enc_dim, enc_inter=o.enc_inter, enc_convnext_layers=o.enc_convnext_layers,
                           enc_layers=o.enc_transformer_layers, frame_stride=o.stride, tr_inter_cap=o.tr_inter_cap, dimension=o.dimension,

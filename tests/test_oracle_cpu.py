@@ -135,6 +135,8 @@ def test_oracle15_reproduces_reference_golden(path):
     seed, spec = int(g["seed"]), _spec15(float(g["threshold"]))
     flags = {k: (bool(g[k]) if k.endswith("causal") else int(g[k])) for k in ("agg_causal", "agg_context", "bt_causal", "bt_context") if k in g.files}
     spec = dataclasses.replace(spec, **flags)  # hcodec15_b2_causal_stacks: the reference built from the YAML with causal: true
+    if "layers" in g.files:  # hcodec15_b2_full_depth: the published 32-layer stacks (654 M parameters), produced by the reference itself
+        spec = dataclasses.replace(spec, agg_layers=int(g["layers"]), bt_layers=int(g["layers"]))
     sd = synth.hcodec10_state_dict(seed, spec)
     wav = R.pad_wav(synth.synth_wav(seed + 1, int(g["batch"]), int(g["samples"])))
     feat = synth.synth_feat(seed + 2, int(g["batch"]), wav.shape[-1] // 320, spec.sem_in)
@@ -220,12 +222,14 @@ def _spec20_small():
     return R20.HCodec20Spec(**SPEC20_SMALL)
 
 
-@pytest.mark.parametrize("name", ["hcodec20_small_b2", "hcodec20_small_b2_causal"])
+@pytest.mark.parametrize("name", ["hcodec20_small_b2", "hcodec20_small_b2_causal", "hcodec20_b1_full"])
 def test_oracle20_reproduces_reference_golden(name):
     from oracle import hcodec20_ref as R20
 
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
     seed, spec = int(g["seed"]), _spec20_small()
+    if "full" in g.files and int(g["full"]):  # hcodec20_b1_full: the shipped large_12.5hz_config.yaml shapes (1.17 G parameters)
+        spec = R20.HCodec20Spec()
     if "causal" in g.files and int(g["causal"]):
         spec = dataclasses.replace(spec, causal=True)
     sd = synth.hcodec20_state_dict(seed, spec)
