@@ -24,6 +24,8 @@ WIDE = dict(vocos_layers=2)
 CASES = {  # name -> (spec kwargs, seed, batch, frames)
     "bicodec_small": (SMALL, 3, 2, 9),
     "bicodec_wide": (WIDE, 4, 1, 6),
+    # the published configuration itself (12 AdaLN-Vocos blocks, 96 M parameters on the decode side), one segment of 1 s
+    "bicodec_published_1s": ({}, 5, 1, 50),
 }
 
 
