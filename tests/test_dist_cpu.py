@@ -65,3 +65,44 @@ def test_scatter_run_gather_gloo(world, n_clips):
         p.join(120)
         assert p.exitcode == 0
     assert q.get() == "ok"
+
+
+def _worker_ragged_tail(rank, world, port, q):
+    """H-Codec 1.5's shape problem: every rank's codes are [n_r, nq, G_r] with a data-dependent G_r."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        n_clips, K = 5, 1024
+        clips = torch.arange(n_clips * 4, dtype=torch.float32).view(n_clips, 4) if rank == 0 else None
+
+        def fake_adaptive(wav):  # G grows with the rank's first clip index: ranks disagree on the trailing extent
+            G = 2 + int(wav[0, 0].item()) // 4
+            codes = (wav[:, :1].to(torch.int64) + torch.arange(G)).view(-1, 1, G).expand(-1, 3, G).contiguous()
+            return codes, wav * 2
+
+        out = qd.run_sharded(fake_adaptive, [clips], dev, pad_values=[-K, 0.0])
+        if rank == 0:
+            codes, wav = out
+            assert torch.equal(wav, clips * 2)
+            g0, g1 = 2, 2 + 3  # rank 0 holds clips 0..2, rank 1 clips 3..4 (first clip index 3 -> wav[0, 0] = 12)
+            assert codes.shape == (n_clips, 3, g1)
+            assert torch.equal(codes[:3, :, :g0], (clips[:3, :1].to(torch.int64) + torch.arange(g0)).view(-1, 1, g0).expand(-1, 3, g0))
+            assert bool((codes[:3, :, g0:] == -K).all())  # padded groups: length 0 in the length-injected format
+            assert torch.equal(codes[3:], (clips[3:, :1].to(torch.int64) + torch.arange(g1)).view(-1, 1, g1).expand(-1, 3, g1))
+            q.put("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_pads_data_dependent_trailing_dims_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged_tail, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get() == "ok"

@@ -52,16 +52,21 @@ def scatter_clips(clips: Optional[torch.Tensor], device: torch.device, src: int 
     return out[: counts[rank]]
 
 
-def gather_ragged(local: torch.Tensor, dst: int = 0, group=None) -> Optional[torch.Tensor]:
-    """Concatenate per-rank results [n_r, ...] (n_r may differ, trailing dims equal) on rank `dst`, in rank order."""
+def gather_ragged(local: torch.Tensor, dst: int = 0, group=None, pad_value=0) -> Optional[torch.Tensor]:
+    """Concatenate per-rank results [n_r, ...] on rank `dst`, in rank order.  n_r may differ; trailing dimensions may differ too
+    (H-Codec 1.5: the number of groups G of a batch is data dependent, so every rank's codes are [n_r, nq, G_r]) - they are
+    right-padded with `pad_value` to the largest extent over the ranks (for length-injected codes pass -codebook_size: a group of
+    length 0, exactly what a batch's own shorter clips carry, codec_adaptive.py:68-80)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    counts = [int(s.item()) for s in sizes]
-    width = max(counts)
-    padded = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    padded[: local.shape[0]] = local
+    shp = torch.tensor(list(local.shape), dtype=torch.int64, device=local.device)
+    shapes = [torch.zeros_like(shp) for _ in range(world)]
+    dist.all_gather(shapes, shp, group=group)
+    shapes = [[int(v) for v in t.tolist()] for t in shapes]
+    counts = [t[0] for t in shapes]
+    # a rank with an empty shard has no trailing extents of its own (run_sharded builds them from another rank's signature)
+    full = tuple(max(t[i] for t in shapes) for i in range(local.dim()))
+    padded = torch.full(full, pad_value, dtype=local.dtype, device=local.device)
+    padded[tuple(slice(0, n) for n in local.shape)] = local
     bufs = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
     dist.gather(padded, bufs, dst=dst, group=group)
     if rank != dst:
@@ -70,9 +75,10 @@ def gather_ragged(local: torch.Tensor, dst: int = 0, group=None) -> Optional[tor
 
 
 def run_sharded(fn: Callable[..., Sequence[torch.Tensor]], inputs: Sequence[Optional[torch.Tensor]], device: torch.device,
-                src: int = 0, group=None) -> Optional[List[torch.Tensor]]:
+                src: int = 0, group=None, pad_values: Optional[Sequence] = None) -> Optional[List[torch.Tensor]]:
     """scatter every input from rank `src`, run `fn(*local_inputs)` (the per-GPU hot path, e.g. tokenize+detokenize),
-    gather every output back to `src`.  Ranks whose shard is empty skip `fn`."""
+    gather every output back to `src`.  Ranks whose shard is empty skip `fn`.  `pad_values[i]` fills output i where a rank's
+    trailing dimensions are shorter than another's (gather_ragged)."""
     local = [scatter_clips(t, device, src, group) for t in inputs]
     if local[0].shape[0] > 0:
         outs = list(fn(*local))
@@ -85,5 +91,6 @@ def run_sharded(fn: Callable[..., Sequence[torch.Tensor]], inputs: Sequence[Opti
     sig = next(s for s in sigs if s is not None)
     if outs is None:
         outs = [torch.empty((0,) + shp, dtype=dt, device=device) for shp, dt in sig]
-    gathered = [gather_ragged(o, src, group) for o in outs]
+    pads = list(pad_values) if pad_values is not None else [0] * len(outs)
+    gathered = [gather_ragged(o, src, group, pv) for o, pv in zip(outs, pads)]
     return gathered if dist.get_rank(group) == src else None
