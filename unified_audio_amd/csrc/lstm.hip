@@ -12,6 +12,17 @@
 // pre-permuted to (unit, gate) order at load time) for ALL batch rows, splits K = d over its 8 waves, runs
 // v_mfma_f32_16x16x4_f32 with batch as the M dimension, reduces the 8 partial tiles through LDS and applies the
 // cell update in the same kernel, so gates never touch HBM.
+//
+// Persistent variant (lstm_persistent_kernel, measured in tools/micro/lstm_persistent.hip: 14.7 -> 8.7 us per step at d = 1536 / B = 16,
+// 10.05 -> 9.1 at d = 1024 / B = 32, equal at 768, slower at 512): ONE launch for all T steps, d / U workgroups (<= CU count, all
+// co-resident), each holding its 4U rows of W_hh in its waves' REGISTERS for the whole call; h_t crosses CUs through write-through
+// (sc1) stores and sc1 loads (no fences: MI355X_MICROARCH.md "Valid forms"), every step ends in an XCD-hierarchical counter
+// barrier with BOUNDED spins.  What it removes is the per-step weight stream (37.7 MB at d = 1536), what it adds is the in-launch
+// barrier (~4 us) - so it is the default only where the stream dominates (d >= 1536: H-Codec 2.0); QA_LSTM_PERSISTENT=0 / 1 forces
+// it off / on for every supported width.  It needs every workgroup resident at once: two such kernels sharing the device (two
+// handles driven concurrently on two streams) starve each other until the spin bound trips; that sets an error word in pinned host
+// memory which the next launch_lstm call on the device reports (QA_ERR_HIP) - run concurrent handles with QA_LSTM_PERSISTENT=0.
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -179,6 +190,224 @@ static int lstm_launch_steps(const float* xw, const float* w_hh_ug, float* h_out
     return QA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ persistent recurrence
+namespace {
+// sync words, one per 128-byte line: grp_cnt[8] | top_cnt | top_gen | grp_gen[8] | err
+enum { SY_GRP_CNT = 0, SY_TOP_CNT = 8, SY_TOP_GEN = 9, SY_GRP_GEN = 10, SY_ERR = 18, SY_WORDS = 19, SY_STRIDE = 32 };
+constexpr unsigned LSTM_SPIN_LIMIT = 1u << 21;  // x (s_sleep + one L2 round trip) ~ seconds: then the barrier is declared broken
+constexpr int LSTM_SYNC_RING = 8;
+}  // namespace
+
+#define QA_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ bool lstm_spin_until(unsigned* word, unsigned want, unsigned* err, unsigned* err_host) {
+    for (unsigned spins = 0; spins < LSTM_SPIN_LIMIT; ++spins) {
+        if (__hip_atomic_load(word, QA_RLX) >= want) return true;
+        if ((spins & 1023u) == 1023u && __hip_atomic_load(err, QA_RLX) != 0u) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __hip_atomic_store(err, 1u, QA_RLX);
+    __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return false;
+}
+
+// 16-byte load that bypasses this CU's L1 (L2 / memory-side served).  A relaxed agent-scope __hip_atomic_load stops at 8 bytes and
+// hipcc waits for each one before issuing the next; an asm load is invisible to its scoreboard, so the caller waits by hand
+// (asm "s_waitcnt vmcnt(0)" with the destination as an in/out operand, which also pins every use behind the wait).
+__device__ __forceinline__ f32x4 lstm_load_sc1_b128(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// one lane per workgroup; epoch = steps completed (1-based).  The last arriver of a group (blockIdx % ngrp: the XCD a workgroup is
+// observed to land on - a speed assumption only) forwards to the top counter, the last group publishes top_gen, every group's
+// forwarder republishes it as its group's generation word, which is what the group's pollers read.
+__device__ __forceinline__ void lstm_barrier_arrive(unsigned* sy, int g, unsigned epoch, unsigned per_grp, unsigned ngrp, unsigned* err_host) {
+    const unsigned old = __hip_atomic_fetch_add(sy + (SY_GRP_CNT + g) * SY_STRIDE, 1u, QA_RLX);
+    if (old + 1u == per_grp * epoch) {
+        const unsigned o2 = __hip_atomic_fetch_add(sy + SY_TOP_CNT * SY_STRIDE, 1u, QA_RLX);
+        if (o2 + 1u == ngrp * epoch) __hip_atomic_store(sy + SY_TOP_GEN * SY_STRIDE, epoch, QA_RLX);
+        else if (!lstm_spin_until(sy + SY_TOP_GEN * SY_STRIDE, epoch, sy + SY_ERR * SY_STRIDE, err_host)) return;
+        __hip_atomic_store(sy + (SY_GRP_GEN + g) * SY_STRIDE, epoch, QA_RLX);
+    }
+}
+
+// MT batch tiles of 16 rows, NT column tiles of 16 W_hh rows (a workgroup owns R = 4 U <= 16 NT rows), NI = d / 128 K steps per wave
+template <int MT, int NT, int NI>
+__global__ __launch_bounds__(512) void lstm_persistent_kernel(const float* __restrict__ xw, const float* __restrict__ w_hh, float* h_out,
+                                                              float* __restrict__ c_state, int B, int T, int d, int U, unsigned* sy,
+                                                              int ngrp, int per_grp, unsigned* err_host) {
+    __shared__ float part[4][MT * NT][16][17];
+    __shared__ int s_ok;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int R = 4 * U, n0 = blockIdx.x * R;
+    const int grp = blockIdx.x % ngrp;
+    const int kw = d / 8, k0 = wave * kw;
+    // this wave's share of the workgroup's W_hh rows, resident in registers for all T steps
+    float4 wv[NT][NI];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int r = min(n * 16 + li, R - 1);  // columns past R repeat the last row and are never read back
+        const float* wrow = w_hh + (long long)(n0 + r) * d + k0 + 4 * kq;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wv[n][i] = *reinterpret_cast<const float4*>(wrow + i * 16);
+    }
+    const bool epi = tid < B * U;
+    const int eb = epi ? tid / U : 0, eu = epi ? tid - eb * U : 0;
+    const int unit = blockIdx.x * U + eu;
+    float c_reg = 0.f;
+    for (int t = 0; t < T; ++t) {
+        float4 xg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (epi) xg = *reinterpret_cast<const float4*>(xw + ((long long)eb * T + t) * 4 * d + (long long)unit * 4);
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {
+            if (tid == 0) s_ok = lstm_spin_until(sy + (SY_GRP_GEN + grp) * SY_STRIDE, (unsigned)t, sy + SY_ERR * SY_STRIDE, err_host) ? 1 : 0;
+            __syncthreads();
+            if (!s_ok) break;  // uniform: a broken barrier ends the call for everybody (the error words are set)
+            asm volatile("" ::: "memory");
+            // h_{t-1}: written by sc1 (write-through) stores on other CUs, read with sc1 loads, every load in flight at once
+            f32x4 hv[MT][NI];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                int b = m * 16 + li;
+                if (b >= B) b = B - 1;
+                const float* hrow = h_out + ((long long)b * T + (t - 1)) * d + k0 + 4 * kq;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) hv[m][i] = lstm_load_sc1_b128(hrow + i * 16);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[m][i])::"memory");
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[m][i].x, wv[n][i].x, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[m][i].y, wv[n][i].y, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[m][i].z, wv[n][i].z, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[m][i].w, wv[n][i].w, acc[m][n], 0, 0, 0);
+                    }
+        }
+        // K-split reduction in two rounds (4 slots of LDS): waves 4..7 park their tiles, waves 0..3 add them to their own
+        if (wave >= 4) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part[wave - 4][m * NT + n][4 * kq + r][li] = acc[m][n][r];
+        }
+        __syncthreads();
+        if (wave < 4) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part[wave][m * NT + n][4 * kq + r][li] += acc[m][n][r];
+        }
+        __syncthreads();
+        if (epi) {
+            float g4[4] = {xg.x, xg.y, xg.z, xg.w};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = eu * 4 + g;
+                float s = g4[g];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) s += part[w][(eb >> 4) * NT + (col >> 4)][eb & 15][col & 15];
+                g4[g] = s;
+            }
+            const float ig = sigmoid_f(g4[0]), fg = sigmoid_f(g4[1]), gg = tanhf(g4[2]), og = sigmoid_f(g4[3]);
+            c_reg = fg * c_reg + ig * gg;
+            // write-through store: the value has left this XCD's L2 once vmcnt drains
+            __hip_atomic_store(reinterpret_cast<unsigned*>(h_out + ((long long)eb * T + t) * d + unit), __float_as_uint(og * tanhf(c_reg)), QA_RLX);
+        }
+        if (t + 1 < T) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the workgroup reports the step done
+            __syncthreads();
+            if (tid == 0) lstm_barrier_arrive(sy, grp, (unsigned)(t + 1), (unsigned)per_grp, (unsigned)ngrp, err_host);
+        }
+    }
+    if (epi) c_state[(long long)eb * d + unit] = c_reg;
+}
+
+namespace {
+struct LstmPersistentDev {
+    unsigned* sync = nullptr;      // LSTM_SYNC_RING blocks of SY_WORDS * SY_STRIDE words (device)
+    unsigned* err_host = nullptr;  // pinned, mapped: written by a kernel whose barrier timed out
+    unsigned* err_dev = nullptr;   // device alias of err_host
+    int cus = 0, next = 0;
+};
+LstmPersistentDev g_lstm_p[16];
+
+// -1 auto (widths whose per-step weight stream dominates: d >= 1536), 0 off, 1 on for every supported width
+int lstm_persistent_mode() {
+    static const int mode = [] {
+        const char* e = std::getenv("QA_LSTM_PERSISTENT");
+        return e ? (e[0] == '0' ? 0 : 1) : -1;
+    }();
+    return mode;
+}
+}  // namespace
+
+// returns QA_OK and sets *done = true when the persistent kernel took the call; *done = false: shape / device not eligible
+static int launch_lstm_persistent(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d, hipStream_t s,
+                                  int dev, bool* done) {
+    *done = false;
+    const int mode = lstm_persistent_mode();
+    if (mode == 0 || (mode < 0 && d < 1536)) return QA_OK;
+    if (!(d == 1536 || d == 1024 || d == 768 || d == 512) || T < 2) return QA_OK;
+    LstmPersistentDev& P = g_lstm_p[dev];
+    if (!P.sync) {
+        QA_HIP(hipDeviceGetAttribute(&P.cus, hipDeviceAttributeMultiprocessorCount, dev));
+        QA_HIP(hipMalloc(reinterpret_cast<void**>(&P.sync), sizeof(unsigned) * LSTM_SYNC_RING * SY_WORDS * SY_STRIDE));
+        QA_HIP(hipHostMalloc(reinterpret_cast<void**>(&P.err_host), sizeof(unsigned), hipHostMallocMapped));
+        *P.err_host = 0u;
+        QA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&P.err_dev), P.err_host, 0));
+    }
+    if (*static_cast<volatile unsigned*>(P.err_host) != 0u) {
+        *P.err_host = 0u;
+        set_error("lstm: the grid barrier of an earlier persistent LSTM call on device %d timed out (its outputs are invalid): the kernel "
+                  "needs every workgroup resident at once - another persistent kernel was sharing the device; set QA_LSTM_PERSISTENT=0", dev);
+        return QA_ERR_HIP;
+    }
+    // U hidden units per workgroup: the fewest that keep d / U workgroups (a multiple of the 8 barrier groups) <= CU count
+    int U = 1;
+    while (U <= 8 && (d % U || d / U > P.cus || (d / U) % 8)) ++U;
+    const int NT = (4 * U + 15) / 16;
+    if (U > 8 || NT > 2 || (NT == 2 && d != 1536) || (NT == 1 && d == 1536)) return QA_OK;
+    const int nwg = d / U, ngrp = 8, per_grp = nwg / ngrp;
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        const int bn = std::min(32, B - b0);
+        const float* xw_b = xw + (long long)b0 * T * 4 * d;
+        float* h_b = h_out + (long long)b0 * T * d;
+        float* c_b = c_state + (long long)b0 * d;
+        unsigned* sy = P.sync + (size_t)P.next * SY_WORDS * SY_STRIDE;
+        P.next = (P.next + 1) % LSTM_SYNC_RING;
+        QA_HIP(hipMemsetAsync(sy, 0, sizeof(unsigned) * SY_WORDS * SY_STRIDE, s));  // every polled word, before EVERY launch
+#define QA_LP(MT, NT_, NI) \
+    hipLaunchKernelGGL((lstm_persistent_kernel<MT, NT_, NI>), dim3(nwg), dim3(512), 0, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, U, sy, ngrp, per_grp, P.err_dev)
+        const bool two = bn > 16;
+        if (d == 1536) { if (two) QA_LP(2, 2, 12); else QA_LP(1, 2, 12); }
+        else if (d == 1024) { if (two) QA_LP(2, 1, 8); else QA_LP(1, 1, 8); }
+        else if (d == 768) { if (two) QA_LP(2, 1, 6); else QA_LP(1, 1, 6); }
+        else { if (two) QA_LP(2, 1, 4); else QA_LP(1, 1, 4); }
+#undef QA_LP
+        QA_LAUNCH_CHECK();
+    }
+    *done = true;
+    return QA_OK;
+}
+
 // The T step launches of one call as a hipGraph: captured once per (buffers, shape) - the model graphs re-use the same arena
 // addresses call after call - and replayed, so the host issues one graph launch instead of T kernel launches (eager launches go
 // host-bound below ~3.5 us per kernel).  QA_LSTM_GRAPH=0 keeps the eager launches.
@@ -209,6 +438,11 @@ int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_st
     QA_HIP(hipGetDevice(&dev));
     QA_REQUIRE(dev >= 0 && dev < 16, "lstm: device index %d out of range", dev);
     std::lock_guard<std::mutex> lock(g_lstm_mu);
+    {
+        bool done = false;
+        QA_TRY(launch_lstm_persistent(xw, w_hh_ug, h_out, c_state, B, T, d, s, dev, &done));
+        if (done) return QA_OK;
+    }
     if (!g_lstm_side[dev]) {
         QA_HIP(hipStreamCreateWithFlags(&g_lstm_side[dev], hipStreamNonBlocking));
         QA_HIP(hipStreamCreateWithFlags(&g_lstm_cap_side[dev], hipStreamNonBlocking));
