@@ -9,6 +9,7 @@ import time
 
 import torch
 
+os.environ.setdefault("QA_LSTM_PERSISTENT", "0")  # concurrent handles on one GPU: no kernel that needs the whole device resident
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import unified_audio_amd as qa  # noqa: E402
 from unified_audio_amd import synth  # noqa: E402
