@@ -2,11 +2,11 @@
 // projection (reference: QuarkAudio-HCodec/HCodec-1.0/vq/encoder_modules/transformer.py:115,133).
 //
 // The input half (x W_ih^T + b_ih + b_hh) is one big batched GEMM done by conv_gemm; what remains is the strictly
-// sequential recurrence  gates_t = xw_t + h_{t-1} W_hh^T.  Structure: one launch per time step - every step is an all-to-all
-// seam (each gate needs the whole h_{t-1} of its batch row), the kernel boundary IS the cross-CU synchronisation and at
-// ~1.2-1.9 us (MI355X_MICROARCH price list, "boundary") it is cheaper than any in-launch exchange of a 64-128 KB state across
-// 256 CUs ("barrier-xcd" 4.1 us, "allgather" 2.9-4.2 us for 32 KB), so a persistent weights-in-LDS kernel would lose per step
-// what it saves in L2 weight reads.  What the step must not do is serialise its memory round trips: every load of a wave's K
+// sequential recurrence  gates_t = xw_t + h_{t-1} W_hh^T.  Default structure (d < 1536): one launch per time step - every step is an
+// all-to-all seam (each gate needs the whole h_{t-1} of its batch row), the kernel boundary IS the cross-CU synchronisation and at
+// ~1.2-1.9 us (MI355X_MICROARCH price list, "boundary") it is cheaper than an in-launch exchange of a 64-128 KB state across
+// 256 CUs ("barrier-xcd" 4.1 us + the fresh read) as long as the per-step stream of W_hh is short (d <= 1024: measured below).
+// What the step must not do is serialise its memory round trips: every load of a wave's K
 // share is issued before its first MFMA (NI template), and the T launches of a call are replayed from a cached hipGraph so the
 // host never limits the 3-4 us step.  d/4 workgroups per step.  A workgroup owns 4 hidden units x 4 gates = 16 rows of W_hh (rows
 // pre-permuted to (unit, gate) order at load time) for ALL batch rows, splits K = d over its 8 waves, runs
