@@ -366,8 +366,8 @@ class HCodecTokenizer(torch.nn.Module):
         HCodecTokenizer(config=dict)   (config['ckpt_path'], ...)  H-Codec 1.5   HCodec-1.5/audio_tokenizer.py:38-51
         HCodecTokenizer(pt_path, config_path, device)              H-Codec 2.0   HCodec-2.0/audio_tokenizer.py:19-46
 
-    plus keyword-only extras: `state_dict=` (instead of a checkpoint path), `spec=` (instead of a YAML config),
-    `feature_extractor=`.  The reference downloads its SSL model (`AutoModel.from_pretrained`: hubert_base / XLSR-53); there is
+    plus keyword-only extras: `state_dict=` (instead of a checkpoint path), `spec=` (instead of a YAML config), `model=` (an already
+    loaded `Codec`), `feature_extractor=`.  The reference downloads its SSL model (`AutoModel.from_pretrained`: hubert_base / XLSR-53); there is
     no network here, so the front-end is passed in: a `unified_audio_amd.SSLFeatureExtractor` (HuBERT / XLSR on the same HIP
     library - `tokenize(wav)` then never leaves the device path), or the reference's own PyTorch module
     (`feature_extractor(wav, output_hidden_states=True).hidden_states`), or precomputed features via `tokenize(wav, feats=...)`.
@@ -376,7 +376,7 @@ class HCodecTokenizer(torch.nn.Module):
     """
 
     def __init__(self, pt_path=None, config_path=None, device: str | torch.device = "cuda:0", *, config: Optional[dict] = None,
-                 state_dict=None, feature_extractor: Optional[Callable] = None, spec: Optional[HCodecSpec] = None, **kwargs):
+                 state_dict=None, feature_extractor: Optional[Callable] = None, spec: Optional[HCodecSpec] = None, model=None, **kwargs):
         super().__init__()
         self.config = config
         sampling_rate = 16000
@@ -391,17 +391,23 @@ class HCodecTokenizer(torch.nn.Module):
             sampling_rate = int(config.get("sampling_rate", 16000))
             if pt_path is None:
                 pt_path = config.get("ckpt_path")  # 1.5: load_sub_weights(config['ckpt_path'], prefix=None)
+        if spec is None and model is not None:
+            spec = getattr(model, "spec", None)
         spec = spec or SPEC_10
         if spec.version == 20 and sampling_rate == 16000:
             sampling_rate = 48000  # large_12.5hz_config.yaml:1
-        if state_dict is None:
-            if pt_path is None:
-                raise ValueError("HCodecTokenizer needs pt_path, config['ckpt_path'] or state_dict")
-            state_dict = torch.load(pt_path, map_location="cpu")  # audio_tokenizer.py:24
-            if isinstance(state_dict, dict) and "state_dict" in state_dict:  # HCodec-1.5/audio_tokenizer.py:20-25
-                state_dict = state_dict["state_dict"]
-        self.device = torch.device(device) if str(device) != "cpu" else torch.device("cuda:0")  # 2.0's default device='cpu': no CPU path
-        self.model = Codec(None, None, None, spec=spec, device=self.device).load_state_dict(state_dict)
+        if model is not None:  # an already loaded Codec (or any object with its spec / encode / decode): nothing to read from disk
+            self.device = torch.device(getattr(model, "device", device))
+            self.model = model
+        else:
+            if state_dict is None:
+                if pt_path is None:
+                    raise ValueError("HCodecTokenizer needs pt_path, config['ckpt_path'] or state_dict")
+                state_dict = torch.load(pt_path, map_location="cpu")  # audio_tokenizer.py:24
+                if isinstance(state_dict, dict) and "state_dict" in state_dict:  # HCodec-1.5/audio_tokenizer.py:20-25
+                    state_dict = state_dict["state_dict"]
+            self.device = torch.device(device) if str(device) != "cpu" else torch.device("cuda:0")  # 2.0's default device='cpu': no CPU path
+            self.model = Codec(None, None, None, spec=spec, device=self.device).load_state_dict(state_dict)
         self.feature_extractor = feature_extractor
         self.sampling_rate = sampling_rate
         self.hop_length = spec.enc_hop  # 640 = 25 Hz (audio_tokenizer.py:31); 3840 = 12.5 Hz at 48 kHz (2.0 :46)
