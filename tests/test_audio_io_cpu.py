@@ -40,3 +40,27 @@ def test_float_and_multichannel_and_24bit(tmp_path):
         f.write(b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 48000, 3, 24) + b"data" + struct.pack("<I", len(body)) + body)
     y, _ = A.read_wav(r)
     assert np.allclose(y[0].numpy(), vals / 8388608.0)
+
+
+def test_interoperates_with_scipy_wavfile(tmp_path):
+    """A second independent reader / writer (scipy.io.wavfile): float32 and PCM16 files cross both ways, PCM32 and extensible-format
+    headers written by scipy are read."""
+    from scipy.io import wavfile
+
+    g = np.random.default_rng(3)
+    x = (g.uniform(-0.9, 0.9, size=3001)).astype(np.float32)
+    p = str(tmp_path / "ours_float.wav")
+    A.write_wav(p, torch.from_numpy(x), 16000, subtype="FLOAT")
+    sr, y = wavfile.read(p)
+    assert sr == 16000 and y.dtype == np.float32 and np.array_equal(y, x)
+    p = str(tmp_path / "ours_pcm16.wav")
+    A.write_wav(p, torch.from_numpy(x), 22050)
+    sr, y = wavfile.read(p)
+    assert sr == 22050 and y.dtype == np.int16 and np.abs(y / 32768.0 - x).max() <= 0.5 / 32768 + 1e-7
+    for dt, scale in ((np.float32, 1.0), (np.int16, 32768.0), (np.int32, 2147483648.0)):
+        q = str(tmp_path / f"scipy_{np.dtype(dt).name}.wav")
+        data = x if dt is np.float32 else np.round(x * (scale - 1)).astype(dt)
+        wavfile.write(q, 48000, np.stack([data, data[::-1]], axis=1))  # stereo: channel 0 is taken
+        y, sr = A.read_wav(q)
+        assert sr == 48000 and y.shape == (1, 3001)
+        assert np.allclose(y[0].numpy(), data.astype(np.float64) / scale, atol=1e-7)
