@@ -215,6 +215,16 @@ int qa_profile_end(double* out, int32_t n_out);
  * profiler sees every kernel alone on the device; results are bit-identical either way.  Process-wide. */
 int qa_set_serial(int32_t on);
 
+/* ---- tuning knobs -------------------------------------------------------------------------------------------
+ * Every A/B switch of the library is one row of a table (csrc/knobs.h; INTEGRATION.md lists them): an integer whose initial
+ * value is the environment variable of the same name (e.g. QA_LSTM_PERSISTENT, QA_LM_UNFUSED) and which qa_set_knob()
+ * overrides at run time.  Knobs are read by the host-side launch code at launch (LM tile widths / QA_LM_UNFUSED: at
+ * qa_lm_create) time.  No knob changes results beyond fp32 summation order; none selects a CPU path.  Process-wide. */
+int qa_knob_count(void);
+int qa_knob_info(int32_t index, const char** name, int64_t* value, int64_t* default_value, const char** doc);
+int qa_set_knob(const char* name, int64_t value);
+int qa_get_knob(const char* name, int64_t* value);
+
 /* ---- SSL front-end ---------------------------------------------------------------------------
  * HCodecTokenizer.extract_wav2vec2_features (QuarkAudio-HCodec/HCodec-1.0/audio_tokenizer.py:35-48, HCodec-1.5/audio_tokenizer.py:53-67):
  * and UniSE's Model.extract_semantic_features (QuarkAudio-UniSE/model/model.py:38-51, microsoft/wavlm-base-plus, no compression):

@@ -26,6 +26,10 @@ CASES = {  # name -> (spec kwargs or None for the UniSE shape, weight seed, task
     "lm_small_rtse": (SMALL, 22, "rtse", 2, 6, 11, 7, 32),
     "lm_unise_se": (None, 33, "se", 4, 50, 0, 50, 32),        # 12 x 512, vocab 12291 (conf/config.yaml:131-146)
     "lm_unise_tse": (None, 34, "tse", 2, 30, 40, 30, 32),
+    # BASELINE configs[2] / configs[3] AT SIZE: 16 segments x 5 s (prompt 252, KV 535) and the per-GPU TSE share of 8
+    # segments with a 250-frame enrollment (prompt 503, KV 786): the shapes bench.py's tokens/s are quoted on
+    "lm_config3_se_b16": (None, 35, "se", 16, 250, 0, 250, 32),
+    "lm_config4_tse_b8": (None, 36, "tse", 8, 250, 250, 250, 32),
 }
 
 
@@ -47,9 +51,9 @@ def reference_generate(spec, sd, task, mix, enr, S_len, G, seed=None, **kw):
         return model.generate(task, None if enr is None else mel, enr, mel, mix, global_length=G, **kw)
 
 
-def main():
+def main(names=None):
     os.makedirs(GOLDEN, exist_ok=True)
-    for name in CASES:
+    for name in (names or CASES):
         spec, sd, task, mix, enr, S_len, G = case_tensors(name)
         g_ref, s_ref = reference_generate(spec, sd, task, mix, enr, S_len, G, do_sample=False)
         g_o, s_o, toks_o, _ = L.generate(sd, task, enr, mix, S_len, G, spec)
@@ -62,4 +66,6 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    import sys
+
+    main(sys.argv[1:] or None)

@@ -1,0 +1,237 @@
+"""Parity AT THE SIZES bench.py quotes (VERDICT r02 "next round" 1): every BASELINE config's per-GPU share through the product
+path against its oracle.  configs[1] (H-Codec 1.5, 32 x 10 s) lives in tests/test_properties_gpu.py and configs[2] / configs[3]
+(the UniSE LM at B = 16 / KV 535 and B = 8 / KV 786) in tests/test_llm_gpu.py; here:
+
+  * configs[4] share: H-Codec 2.0 (1.17 G parameters), 16 clips x 30 s @ 48 kHz, the persistent LSTM recurrence at d = 1536 and
+    T = 1 500 - oracle on two of the clips, persistent vs per-step kernels on all of them, every clip against its single-clip run;
+  * the persistent recurrence forced on for d = 512 / 768 / 1024 with B > 16;
+  * configs[2]'s other two stages at size: wavlm-base-plus and the published BiCodec on 16 x 5 s segments.
+"""
+import time
+
+import pytest
+import torch
+
+from oracle import hcodec_ref as R
+from oracle import synth
+from tests.util import audit_codes_bnq, rel_err
+
+pytestmark = pytest.mark.gpu
+
+STAGE_TOL = 5e-5
+
+
+def _rnn_names(spec):
+    return [f"encoder.post_net.1.layers.{l}.self_attn.rnn" for l in range(spec.enc_transformer_layers)], \
+           [f"decoder.prior_net.3.layers.{l}.self_attn.rnn" for l in range(spec.dec_transformer_layers)]
+
+
+def hcodec20_share_parity(device, B=16, seconds=30.0, oracle_clips=(0, 15), seed=1234, single_clips=None, verbose=print):
+    """H-Codec 2.0 at the published size on B clips x `seconds` s @ 48 kHz (ref: QuarkAudio-HCodec/HCodec-2.0/vq/codec.py:76-99).
+    Returns a report dict; raises on any parity failure."""
+    import unified_audio_amd as qa
+    from oracle import hcodec20_ref as R20
+    from unified_audio_amd import _lib
+
+    ospec = R20.SPEC_20
+    nq = ospec.num_quantizers
+    t0 = time.perf_counter()
+    sd = synth.hcodec20_state_dict(seed, ospec)
+    codec = qa.Codec(None, None, None, spec=qa.SPEC_20, device=device).load_state_dict(sd)
+    T = int(seconds * 48000) // ospec.frame_hop * ospec.frame_hop
+    wav = synth.synth_wav_fullband(seed + 1, B, T)
+    feat = synth.synth_feat(seed + 2, B, T // ospec.hop, ospec.sem_in)
+    wav_d, feat_d = wav.to(device), feat.to(device)
+    enc_rnn, dec_rnn = _rnn_names(ospec)
+    N50 = T // ospec.hop
+    assert _lib.get_knob("QA_LSTM_PERSISTENT") == -1, "the product default (persistent recurrence for d >= 1536) is what this test is about"
+
+    # ---- (1) the product path (persistent recurrence, one launch for all 1 500 steps of a layer) vs the per-step kernels
+    codec.enable_taps(True)
+    ac, sc = codec.encode(wav_d, feat_d)
+    rec = codec.decode(ac, sc)
+    torch.cuda.synchronize()
+    taps_p = {n: codec.tap(n).clone() for n in dec_rnn}
+    codec.encode(wav_d, feat_d)  # taps of the last call only: encode again for its rnn taps
+    taps_p.update({n: codec.tap(n).clone() for n in enc_rnn})
+    emb_g = {"enc.emb": codec.tap("enc.emb").clone(), "enc.sem": codec.tap("enc.sem").clone()}
+    old = _lib.set_knob("QA_LSTM_PERSISTENT", 0)
+    try:
+        ac_s, sc_s = codec.encode(wav_d, feat_d)
+        taps_s = {n: codec.tap(n).clone() for n in enc_rnn}
+        rec_s = codec.decode(ac, sc)
+        taps_s.update({n: codec.tap(n).clone() for n in dec_rnn})
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_knob("QA_LSTM_PERSISTENT", old)
+    ab = {n: rel_err(taps_p[n], taps_s[n]) for n in enc_rnn + dec_rnn}
+    assert all(torch.isfinite(t).all() for t in taps_p.values())
+    assert max(ab.values()) < 1e-5, ab  # same arithmetic, another K-split order
+    assert max(ab.values()) > 0.0, "bit-identical taps: the persistent kernel did not run (it reduces K in another order)"
+    ab["wav"] = rel_err(rec, rec_s)
+    assert ab["wav"] < 1e-5, ab
+    code_ab = float(((ac != ac_s).any(dim=1) | (sc != sc_s).any(dim=1)).float().mean())  # frames with any differing stage
+    assert code_ab < 0.02, code_ab
+    codec.enable_taps(False)
+    t1 = time.perf_counter()
+
+    # ---- (2) every clip alone == its row in the batch (integer codes and waveform bits)
+    for i in (range(B) if single_clips is None else single_clips):
+        a1, s1 = codec.encode(wav_d[i:i + 1], feat_d[i:i + 1])
+        assert torch.equal(a1[0], ac[i]) and torch.equal(s1[0], sc[i]), f"clip {i}: codes differ from its single-clip run"
+        assert torch.equal(codec.decode(a1, s1)[0], rec[i]), f"clip {i}: waveform differs from its single-clip run"
+    t2 = time.perf_counter()
+
+    # ---- (3) the oracle on `oracle_clips`
+    idx = torch.tensor(list(oracle_clips))
+    otaps, dtaps = {}, {}
+    with torch.no_grad():
+        ac_o, sc_o = R20.encode(sd, wav[idx], feat[idx], ospec, otaps)
+        wav_o = R20.decode(sd, ac_o, sc_o, ospec, dtaps)
+    t3 = time.perf_counter()
+    report = {}
+    d = ospec.enc_dim
+    for n in enc_rnn:
+        report[n] = rel_err(taps_p[n].view(B, N50, d)[idx.to(device)], otaps[n])
+    flips = max(audit_codes_bnq(otaps["enc.emb"], R.rvq_codebooks(sd, "quantizer", nq), ac[idx.to(device)], ac_o),
+                audit_codes_bnq(otaps["enc.sem"], R.rvq_codebooks(sd, "semantic_quantizer", nq), sc[idx.to(device)], sc_o))
+    report["enc.emb"] = rel_err(emb_g["enc.emb"].view(B, -1, ospec.dimension)[idx.to(device)], otaps["enc.emb"].transpose(1, 2))
+    report["enc.sem"] = rel_err(emb_g["enc.sem"].view(B, -1, ospec.dimension)[idx.to(device)], otaps["enc.sem"].transpose(1, 2))
+    # decode the ORACLE's codes (rows `idx` of the batch replaced) so that both sides start from identical integers
+    ac_m, sc_m = ac.clone(), sc.clone()
+    ac_m[idx.to(device)], sc_m[idx.to(device)] = ac_o.to(device), sc_o.to(device)
+    codec.enable_taps(True)
+    wav_g = codec.decode(ac_m, sc_m)
+    torch.cuda.synchronize()
+    for n in dec_rnn:
+        report[n] = rel_err(codec.tap(n).view(B, N50, ospec.dec_dim)[idx.to(device)], dtaps[n])
+    codec.enable_taps(False)
+    report["wav"] = rel_err(wav_g[idx.to(device)], wav_o)
+    rms = float((wav_g[idx.to(device)].cpu() - wav_o).pow(2).mean().sqrt())
+    assert all(v < 4 * STAGE_TOL for k, v in report.items() if k != "wav"), report  # 56 residual blocks deep: round-off accumulates
+    assert report["wav"] < 1e-4 and rms < 1e-3, (report["wav"], rms)
+    verbose(f"H-Codec 2.0 share parity: {B} x {T / 48000:.0f} s @48 kHz, LSTM T = {N50}, persistent vs per-step rnn taps {max(v for k, v in ab.items() if k != 'wav'):.1e} "
+            f"(frames with a code difference {code_ab:.4f}), oracle clips {list(oracle_clips)}: rnn taps {max(report[n] for n in enc_rnn + dec_rnn):.1e}, "
+            f"near-tie code flips {flips:.4f}, waveform rel {report['wav']:.1e} / RMS {rms:.1e}; "
+            f"GPU A/B {t1 - t0:.0f} s, single clips {t2 - t1:.0f} s, oracle {t3 - t2:.0f} s")
+    return dict(ab=ab, report=report, code_flips=flips, rms=rms)
+
+
+def test_hcodec20_config5_share_persistent_lstm_at_size(qa_lib, gpu_device):
+    """BASELINE configs[4], the per-GPU share: 16 clips x 30 s @ 48 kHz through H-Codec 2.0 with the persistent recurrence."""
+    hcodec20_share_parity(gpu_device)
+
+
+@pytest.mark.parametrize("d,B,T", [(512, 32, 500), (768, 20, 250), (1024, 32, 500), (512, 17, 64)])
+def test_persistent_lstm_forced_on_matches_per_step_and_torch(qa_lib, gpu_device, knob, d, B, T):
+    """QA_LSTM_PERSISTENT=1 at the widths where it is NOT the default (H-Codec 1.0 / 1.5: d = 512 / 768 / 1024) with B > 16 (two
+    16-row batch tiles per workgroup): the recurrence inside a real transformer layer of the codec - taps against the per-step
+    kernels and against torch.nn.LSTM through the oracle's transformer."""
+    import dataclasses
+
+    import unified_audio_amd as qa
+
+    heads = d // 64
+    ospec = dataclasses.replace(R.SPEC_10, dec_dim=d, dec_heads=heads, dec_layers=1, convnext_layers=1, dec_inter=2 * d)
+    sd = synth.hcodec10_state_dict(90 + d // 256, ospec)
+    kw = {f: getattr(ospec, f) for f in ospec.__dataclass_fields__}
+    codec = qa.Codec(None, None, None, spec=qa.HCodecSpec(**kw), device=gpu_device).load_state_dict(sd)
+    codec.enable_taps(True)
+    gen = torch.Generator().manual_seed(d + B)
+    ac = torch.randint(0, ospec.codebook_size, (B, ospec.num_quantizers, T // 2), generator=gen)
+    sc = torch.randint(0, ospec.codebook_size, (B, ospec.num_quantizers, T // 2), generator=gen)
+    name = "decoder.prior_net.3.layers.0.self_attn.rnn"
+    outs = {}
+    for mode in (1, 0):
+        knob("QA_LSTM_PERSISTENT", mode)
+        wav = codec.decode(ac.to(gpu_device), sc.to(gpu_device))
+        torch.cuda.synchronize()
+        outs[mode] = (codec.tap(name).clone(), wav.clone())
+    assert torch.isfinite(outs[1][0]).all()
+    assert rel_err(outs[1][0], outs[0][0]) < 1e-5 and rel_err(outs[1][1], outs[0][1]) < 1e-5
+    dtaps = {}
+    with torch.no_grad():
+        R.decode(sd, ac[:2], sc[:2], ospec, dtaps)
+    assert rel_err(outs[1][0].view(B, T, d)[:2], dtaps[name]) < STAGE_TOL
+
+
+def test_persistent_lstm_barrier_timeout_is_recovered_in_the_same_call(qa_lib, gpu_device, knob, capfd):
+    """a persistent-LSTM call whose grid barrier times out (the kernel needs every workgroup resident; a shared device
+    starves it) used to return garbage with QA_OK and report the error one LSTM call later.  Now the call that hit it waits for
+    its stream, sees the error word and re-runs on the per-step kernels.  QA_LSTM_FAULT makes the barrier wait for a workgroup that
+    does not exist; QA_LSTM_SPIN_LIMIT shortens the bounded spin from seconds to milliseconds."""
+    import dataclasses
+
+    import unified_audio_amd as qa
+
+    d = 512
+    ospec = dataclasses.replace(R.SPEC_10, dec_dim=d, dec_heads=8, dec_layers=1, convnext_layers=1, dec_inter=2 * d)
+    sd = synth.hcodec10_state_dict(92, ospec)
+    kw = {f: getattr(ospec, f) for f in ospec.__dataclass_fields__}
+    codec = qa.Codec(None, None, None, spec=qa.HCodecSpec(**kw), device=gpu_device).load_state_dict(sd)
+    gen = torch.Generator().manual_seed(3)
+    ac = torch.randint(0, 1024, (4, 4, 20), generator=gen).to(gpu_device)
+    sc = torch.randint(0, 1024, (4, 4, 20), generator=gen).to(gpu_device)
+    knob("QA_LSTM_PERSISTENT", 0)
+    want = codec.decode(ac, sc).clone()
+    knob("QA_LSTM_PERSISTENT", 1)
+    ok = codec.decode(ac, sc).clone()
+    assert rel_err(ok, want) < 1e-5
+    capfd.readouterr()
+    knob("QA_LSTM_FAULT", 1)
+    knob("QA_LSTM_SPIN_LIMIT", 4096)
+    got = codec.decode(ac, sc).clone()
+    torch.cuda.synchronize()
+    assert "re-running the call on the per-step kernels" in capfd.readouterr().err
+    assert torch.equal(got, want)  # the re-run IS the per-step path
+    knob("QA_LSTM_FAULT", 0)
+    assert torch.equal(codec.decode(ac, sc), ok)  # and the device is usable afterwards
+
+
+def test_wavlm_base_plus_16x5s_matches_oracle(qa_lib, gpu_device):
+    """configs[2], stage 1 at size: wavlm-base-plus (94 M parameters) on 16 segments x 5 s - mean of all 13 hidden states, no
+    compression (QuarkAudio-UniSE/model/model.py:38-51) - against oracle/ssl_ref.py on 3 of the segments, and batch invariance."""
+    import unified_audio_amd as qa
+    from oracle import ssl_ref as SR
+
+    ospec = SR.SPEC_WAVLM_BASE_PLUS
+    sd = SR.synth_state_dict(7, ospec, "wavlm")
+    fx = qa.SSLFeatureExtractor(qa.SPEC_WAVLM_BASE_PLUS, device=gpu_device).load_state_dict(sd)
+    B, T = 16, 80000
+    wav = synth.synth_wav(31, B, T)
+    got = fx(wav.to(gpu_device))
+    torch.cuda.synchronize()
+    assert got.shape == (B, 250, 768) and torch.isfinite(got).all()
+    idx = [0, 7, 15]
+    with torch.no_grad():
+        want = SR.extract_features(sd, wav[idx], ospec)
+    err = rel_err(got[idx], want)
+    assert err < STAGE_TOL, err
+    one = fx(wav[7:8].to(gpu_device))
+    assert torch.equal(one[0], got[7])
+
+
+def test_bicodec_published_16x5s_matches_oracle(qa_lib, gpu_device):
+    """configs[2], stage 3 at size: the published BiCodec (Spark-TTS shapes) detokenizing 16 segments x 5 s (250 semantic + 32
+    global tokens -> 80 000 samples each; QuarkAudio-UniSE/model/bicodec/bicodec.py:182-199) against oracle/bicodec_ref.py on 2
+    of the segments, and batch invariance."""
+    import unified_audio_amd as qa
+    from oracle import bicodec_ref as BR
+
+    ospec = BR.SPEC_BICODEC
+    sd = synth.bicodec_state_dict(11, ospec)
+    kw = {f: getattr(ospec, f) for f in ospec.__dataclass_fields__}
+    bc = qa.BiCodec(qa.BiCodecSpec(**kw), device=gpu_device).load_state_dict(sd)
+    B, S = 16, 250
+    sem, glob = synth.bicodec_tokens(12, B, S, ospec)
+    got = bc.detokenize(sem.to(gpu_device), glob.to(gpu_device))
+    torch.cuda.synchronize()
+    assert got.shape == (B, 1, S * ospec.hop) and torch.isfinite(got).all()
+    idx = [0, 15]
+    with torch.no_grad():
+        want = BR.detokenize(sd, sem[idx], glob[idx], ospec)
+    err = rel_err(got[idx], want)
+    rms = float((got[idx].cpu() - want).pow(2).mean().sqrt())
+    assert err < 2e-4 and rms < 1e-3, (err, rms)
+    one = bc.detokenize(sem[9:10].to(gpu_device), glob[9:10].to(gpu_device))
+    assert torch.equal(one[0], got[9])

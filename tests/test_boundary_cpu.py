@@ -45,6 +45,24 @@ def test_codec_is_an_inference_only_module(qa_lib):
         qa.HCodecTokenizer()
 
 
+def test_eval_reaches_a_pytorch_feature_extractor_and_training_flags_follow(qa_lib):
+    """the facades are nn.Modules - eval() must set `training` and recurse, so a HuBERT / XLSR module handed over in
+    train mode loses its dropout / layerdrop like the reference's (audio_tokenizer.py:28-29 calls .eval() on it)."""
+    import unified_audio_amd as qa
+
+    fx = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Dropout(0.5))
+    fx.train()
+    codec = qa.Codec(None, None, None)
+    assert codec.eval().training is False
+    tok = qa.HCodecTokenizer(model=codec, feature_extractor=fx)
+    assert fx.training is False and fx[1].training is False  # put in eval mode at construction
+    fx.train()
+    assert tok.eval() is tok and tok.training is False and fx[1].training is False and codec.training is False
+    with pytest.raises(qa.QuarkAudioError):
+        tok.train()
+    assert qa.BiCodec().eval().training is False
+
+
 def test_tensor_table_accepts_reduced_precision_checkpoints_and_skips_integer_buffers(qa_lib):
     from unified_audio_amd import _lib
 

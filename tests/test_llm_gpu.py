@@ -63,11 +63,8 @@ def test_unise_lm_full_size_generate(qa_lib, gpu_device):
     assert near_ties > 0 or free_match == 1.0
 
 
-@pytest.mark.parametrize("name", ["lm_small_se", "lm_small_tse", "lm_small_rtse", "lm_unise_se", "lm_unise_tse"])
-def test_generate_matches_reference_token_goldens(qa_lib, gpu_device, name):
-    """Token streams produced by the reference's OWN LLM_SFT.generate (oracle/gen_golden_lm.py): the HIP stream must be
-    identical up to the first step whose top-2 logit gap (stored with the golden) is below fp32 noise; whatever follows such
-    a step is audited teacher-forced against the oracle like every other stream."""
+def golden_stream_parity(name, device, audit=True, verbose=print):
+    """One case of oracle/gen_golden_lm.py through the HIP path (also called by __graft_entry__.smoke() for the config-3 case)."""
     import os
 
     import numpy as np
@@ -76,18 +73,51 @@ def test_generate_matches_reference_token_goldens(qa_lib, gpu_device, name):
 
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
     spec, sd, task, mix, enr, S, G = GG.case_tensors(name)
-    _, lm = _model(spec, GG.CASES[name][1], gpu_device)
+    _, lm = _model(spec, GG.CASES[name][1], device)
     mel = torch.zeros(mix.shape[0], S, 80)
-    gids, sids = lm.generate(task, None if enr is None else mel, None if enr is None else enr.to(gpu_device), mel,
-                             mix.to(gpu_device), global_length=G, do_sample=False)
+    gids, sids = lm.generate(task, None if enr is None else mel, None if enr is None else enr.to(device), mel,
+                             mix.to(device), global_length=G, do_sample=False)
     got = torch.cat([gids.cpu(), sids.cpu()], dim=1).numpy()
     want = np.concatenate([g["global_ids"], g["semantic_ids"]], axis=1).astype(np.int64)
     gaps = np.delete(g["gaps"], G, axis=1)  # drop the discarded 33rd global step: columns now line up with got / want
+    left = 0
     for b in range(got.shape[0]):
         diff = np.nonzero(got[b] != want[b])[0]
         if diff.size:
+            left += 1
             assert gaps[b, diff[0]] <= 2e-4, f"sequence {b} leaves the reference stream at step {diff[0]} (gap {gaps[b, diff[0]]:.2e})"
-    _audit(sd, spec, task, enr, mix, S, G, gids.cpu(), sids.cpu())
+    verbose(f"{name}: {got.shape[0]} sequences x {got.shape[1]} tokens, {left} left the reference stream at a near-tie, "
+            f"smallest gap of the golden {float(g['gaps'].min()):.2e}")
+    if audit or left:
+        _audit(sd, spec, task, enr, mix, S, G, gids.cpu(), sids.cpu())
+    return left
+
+
+@pytest.mark.parametrize("name", ["lm_small_se", "lm_small_tse", "lm_small_rtse", "lm_unise_se", "lm_unise_tse"])
+def test_generate_matches_reference_token_goldens(qa_lib, gpu_device, name):
+    """Token streams produced by the reference's OWN LLM_SFT.generate (oracle/gen_golden_lm.py): the HIP stream must be
+    identical up to the first step whose top-2 logit gap (stored with the golden) is below fp32 noise; whatever follows such
+    a step is audited teacher-forced against the oracle like every other stream."""
+    golden_stream_parity(name, gpu_device)
+
+
+@pytest.mark.parametrize("name", ["lm_config3_se_b16", "lm_config4_tse_b8"])
+def test_generate_at_baseline_size_matches_reference_goldens(qa_lib, gpu_device, name):
+    """BASELINE configs[2] / configs[3] AT SIZE - the shapes bench.py's tokens/s are quoted on: full UniSE width, 16 segments
+    x 5 s (prompt 252, 33 + 250 steps, KV 535: three-way key split of the decode attention) and the per-GPU TSE share of 8
+    segments with a 250-frame enrollment (prompt 503, KV 786: four-way split), against token streams of the reference's own
+    LLM_SFT.generate.  The goldens' smallest top-2 gap is 4.6e-4 / 3.2e-4, above the 2e-4 near-tie bar: the streams must be
+    IDENTICAL (the teacher-forced oracle audit only runs if one is not)."""
+    left = golden_stream_parity(name, gpu_device, audit=False)
+    assert left == 0
+
+
+@pytest.mark.parametrize("name", ["lm_unise_se", "lm_config4_tse_b8"])
+def test_unfused_decode_step_matches_reference_goldens(qa_lib, gpu_device, knob, name):
+    """QA_LM_UNFUSED=1: the per-op decode step (skinny GEMM + attention_decode kernels of csrc/lm_kernels.hip), the path a
+    spec takes when the fused step does not tile it - through the same reference goldens, incl. the KV-786 case."""
+    knob("QA_LM_UNFUSED", 1)  # read at qa_lm_create
+    golden_stream_parity(name, gpu_device, audit=False)
 
 
 def test_generate_argument_errors(qa_lib, gpu_device):
@@ -112,20 +142,20 @@ def _gen(lm, spec, device, B, Nm, S, G, **kw):
     return g.cpu(), s.cpu()
 
 
-def test_graph_replay_equals_eager_launches_and_is_deterministic(qa_lib, gpu_device, monkeypatch):
+def test_graph_replay_equals_eager_launches_and_is_deterministic(qa_lib, gpu_device, knob):
     """One captured step replayed per token (QA_LM_GRAPH, the default) against the same kernels launched eagerly: identical
     integers; repeated calls re-use the captured graphs and the workspace and stay identical; a second shape re-captures."""
     spec = L.SPEC_UNISE
     _, lm = _model(spec, 33, gpu_device)
     outs = []
     for graph in ("1", "0", "1"):
-        monkeypatch.setenv("QA_LM_GRAPH", graph)
+        knob("QA_LM_GRAPH", int(graph))
         outs.append(_gen(lm, spec, gpu_device, 5, 20, 24, 32, do_sample=False))
     for g, s in outs[1:]:
         assert torch.equal(g, outs[0][0]) and torch.equal(s, outs[0][1])
-    monkeypatch.setenv("QA_LM_GRAPH", "1")
+    knob("QA_LM_GRAPH", 1)
     a = _gen(lm, spec, gpu_device, 3, 11, 9, 4, do_sample=False)   # other shape: new workspace layout, new graphs
-    monkeypatch.setenv("QA_LM_GRAPH", "0")
+    knob("QA_LM_GRAPH", 0)
     b = _gen(lm, spec, gpu_device, 3, 11, 9, 4, do_sample=False)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 

@@ -72,6 +72,31 @@ def test_streaming_long_run_wide_heads(qa_lib, gpu_device):
     assert rel_err(y, ref) < TOL
 
 
+def test_streaming_forever_rolls_the_rope_window(qa_lib, gpu_device, knob):
+    """StreamingTransformer.streaming_forever(): the reference computes RoPE from the running offset and never stops
+    (mimi/module/rope.py:38-56).  Here positions beyond the static table come from a rolling window of it; QA_MIMI_ROPE_WINDOW
+    shrinks the table to 32 positions so that a 130-frame stream rolls the window several times (chunks straddle its end)."""
+    d, h, layers, ff, ctx = 256, 4, 2, 512, 16
+    sd = synth.mimi_state_dict(77, d, layers, ff)
+    x = torch.randn(2, 130, d, generator=torch.Generator().manual_seed(78))
+    chunks = (1,) * 100 + (7, 16, 3, 4)
+    st = R15.MimiStreamState(2, layers, h, d // h, ctx)
+    with torch.no_grad():
+        ref = stream_chunks(lambda c: R15.mimi_transformer(sd, "transformer", c, layers, h, True, ctx, st), x, chunks)
+    knob("QA_MIMI_ROPE_WINDOW", 32)
+    m = _model(sd, True, ctx, gpu_device, d=d, h=h, layers=layers, ff=ff)
+    with m.streaming(2):
+        y = stream_chunks(m, x.to(gpu_device), chunks)
+        assert m.streaming_offset == 130
+        m.reset_streaming()  # back inside the static table
+        y1 = stream_chunks(m, x[:, :5].to(gpu_device), (5,))
+    assert rel_err(y, ref) < TOL
+    st2 = R15.MimiStreamState(2, layers, h, d // h, ctx)
+    with torch.no_grad():
+        ref1 = R15.mimi_transformer(sd, "transformer", x[:, :5], layers, h, True, ctx, st2)
+    assert rel_err(y1, ref1) < TOL
+
+
 def test_streaming_errors(qa_lib, gpu_device):
     import unified_audio_amd as qa
 

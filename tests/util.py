@@ -60,6 +60,7 @@ def act_ref(v, code):
 # from it by < STAGE_TOL relative RMS, which moves a squared distance difference by at most ~ 2 |delta| |e1 - e2|, hence
 # the tolerance below (8 x the per-stage bar, relative to the mean squared norm of the inputs).
 CODE_TIE_TOL = 4e-4
+AUDIT_LOG = []  # (n_vectors, flip fraction, largest accepted relative gap, largest relative excess) per audit: printed by conftest's summary
 
 
 def audit_codes(emb, cb, got, want, rel_tol=CODE_TIE_TOL, max_flip_frac=0.02):
@@ -86,6 +87,15 @@ def audit_codes(emb, cb, got, want, rel_tol=CODE_TIE_TOL, max_flip_frac=0.02):
         assert (gap[differs, q] <= tol).all(), f"stage {q}: {int((gap[differs, q] > tol).sum())} decisive mismatches vs the oracle"
         diverged |= differs
     frac = float(diverged.mean())
+    scale = float((emb.astype(np.float64) ** 2).sum(1).mean())
+    first = np.zeros(got.shape[0], bool)
+    worst_gap = 0.0
+    for q in range(got.shape[1]):  # the gap at the stage where a vector first leaves the oracle's stream
+        d = (got[:, q] != want[:, q]) & ~first
+        if d.any():
+            worst_gap = max(worst_gap, float(gap[d, q].max()))
+        first |= d
+    AUDIT_LOG.append((int(got.shape[0]), frac, worst_gap / scale, float(excess.max()) / scale))
     assert frac <= max_flip_frac, f"{frac:.4f} of the vectors sit on a near-tie: tolerance too loose or embeddings off"
     return frac
 

@@ -1,0 +1,68 @@
+#!/bin/bash
+# ONE parameterised GPU-box session (replaces the per-experiment gpu_session_*.sh scripts of rounds 1-2).
+#   usage:  gpurun --timeout N -- 'bash tools/gpu_session.sh TAG STEP [STEP ...]'
+# Every step writes into gpurun_out/TAG/ (merged back by gpurun); summaries worth keeping are copied to profiles/ by hand.
+# Steps:
+#   tests[:EXPR]      pytest -m gpu (optionally -k EXPR, or a file path when EXPR contains ".py")
+#   bench[:ARGS]      python bench.py ARGS (default: the driver's default command) -> bench.json
+#   lm[:B[:REPS]]     tools/lm_bench.py (decode-step time of the UniSE LM, knobs from the environment)
+#   ab:KNOB=a,b[,c]:CMD   run CMD once per value of an environment knob, logs side by side (CMD: lm | bench-lean | hc10 | hc20)
+#   trace:NAME:CMD    rocprofv3 --kernel-trace --stats of CMD (lm | bench-lean | bench-serial | hc10 | hc20) -> NAME_kernel_stats.md
+#   pmc:NAME:CMD      three separate --pmc passes (FETCH_SIZE | WRITE_SIZE | MFMA busy) of CMD -> NAME_pmc_summary.{md,json}
+#   profiles          the round's standard evidence set (tools/collect_profiles.sh TAG)
+#   smoke             __graft_entry__.smoke()
+TAG=${1:?tag}; shift
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
+cd $R
+cmd_of() {
+  case "$1" in
+    lm) echo "python $R/tools/lm_bench.py 16 2" ;;
+    lm-tse) echo "python $R/tools/lm_bench.py 8 2 tse" ;;
+    bench-lean) echo "python $R/bench.py --steps 3 --warmup 1 --lean" ;;
+    bench-serial) echo "env QA_SERIAL=1 python $R/bench.py --steps 3 --warmup 1 --lean" ;;
+    hc10) echo "python $R/bench.py --steps 5 --warmup 2 --lean --model 1.0" ;;
+    hc20) echo "python $R/bench.py --steps 2 --warmup 1 --lean --model 2.0" ;;
+    *) echo "$1" ;;
+  esac
+}
+for step in "$@"; do
+  kind=${step%%:*}; rest=${step#*:}; [ "$rest" = "$step" ] && rest=""
+  echo "=== $step" | tee -a $O/session.log
+  case "$kind" in
+    tests)
+      sel=""; [ -n "$rest" ] && { case "$rest" in *.py*) sel="$rest" ;; *) sel="-k $rest" ;; esac; }
+      case "$sel" in *.py*) tgt="$sel" ;; *) tgt="tests $sel" ;; esac
+      ( time timeout 1500 python -m pytest $tgt -q -m gpu -x 2>&1 | tail -25 ) 2>&1 | tee -a $O/tests.log ;;
+    bench)
+      ( time timeout 900 python bench.py $rest > $O/bench.json 2> $O/bench.err ) 2>&1 | tail -3 | tee -a $O/session.log
+      python - <<PY 2>&1 | tee -a $O/session.log
+import json
+d = json.load(open("$O/bench.json")); lm = d.get("unise_lm") or {}
+print("value", d["value"], "ms", d["ms_per_step"], "frac", d["roofline"]["frac"], "isolated", (d["roofline"].get("isolated") or {}).get("frac"))
+print("lm", lm.get("value"), lm.get("ms_per_decode_step"), (lm.get("roofline") or {}).get("frac"), "e2e", lm.get("end_to_end_b16"))
+for k, v in (d.get("extras") or {}).items(): print(k, v.get("value", v.get("error")), v.get("ms_per_step"))
+PY
+      ;;
+    lm) IFS=: read -r b reps <<< "$rest"; timeout 300 python tools/lm_bench.py ${b:-16} ${reps:-3} 2>&1 | tail -6 | tee -a $O/lm.log ;;
+    ab)
+      IFS=: read -r kv what <<< "$rest"; k=${kv%%=*}; vals=${kv#*=}
+      for v in ${vals//,/ }; do
+        echo "--- $k=$v  ($what)" | tee -a $O/ab.log
+        env $k=$v timeout 600 $(cmd_of $what) 2>&1 | tail -4 | cut -c1-600 | tee -a $O/ab.log
+      done ;;
+    trace)
+      IFS=: read -r name what <<< "$rest"
+      ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_$name -o t -- $(cmd_of $what) > $O/${name}_trace.log 2>&1 )
+      python tools/rocpd_stats.py /tmp/tr_$name/t_results.db $O/${name}_kernel_stats.md 2>&1 | tail -2 ;;
+    pmc)
+      IFS=: read -r name what <<< "$rest"; i=0
+      for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+        i=$((i+1))
+        ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_${name}_$i -o b -- $(cmd_of $what) > $O/${name}_pmc$i.log 2>&1 )
+      done
+      python tools/pmc_summary.py $O/${name}_pmc_summary /tmp/pmc_${name}_1 /tmp/pmc_${name}_2 /tmp/pmc_${name}_3 2>&1 | tail -3 ;;
+    profiles) bash tools/collect_profiles.sh $TAG ;;
+    smoke) ( time timeout 900 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -8 ) 2>&1 | tee -a $O/smoke.log ;;
+    *) echo "unknown step $step" ;;
+  esac
+done

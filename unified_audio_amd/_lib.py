@@ -115,6 +115,10 @@ SYMBOLS = {
     "qa_profile_begin": (C.c_int, []),
     "qa_profile_end": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
     "qa_set_serial": (C.c_int, [C.c_int32]),
+    "qa_knob_count": (C.c_int, []),
+    "qa_knob_info": (C.c_int, [C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_char_p)]),
+    "qa_set_knob": (C.c_int, [C.c_char_p, C.c_int64]),
+    "qa_get_knob": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
     "qa_mimi_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(qa_mimi_spec), C.POINTER(qa_tensor), C.c_int64, C.c_char_p, C.c_int]),
     "qa_mimi_destroy": (None, [C.c_void_p]),
     "qa_mimi_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -172,6 +176,33 @@ def load_library() -> C.CDLL:
 def check(status: int) -> None:
     if status != 0:
         raise QuarkAudioError(status, load_library().qa_last_error().decode("utf-8", "replace"))
+
+
+def set_knob(name: str, value: int) -> int:
+    """Set a tuning knob (csrc/knobs.h) for this process; returns the previous value."""
+    lib = load_library()
+    old = C.c_int64()
+    check(lib.qa_get_knob(name.encode(), C.byref(old)))
+    check(lib.qa_set_knob(name.encode(), int(value)))
+    return int(old.value)
+
+
+def get_knob(name: str) -> int:
+    v = C.c_int64()
+    check(load_library().qa_get_knob(name.encode(), C.byref(v)))
+    return int(v.value)
+
+
+def knobs() -> dict:
+    """name -> (value, default, doc) of every knob the library has."""
+    lib = load_library()
+    out = {}
+    for i in range(lib.qa_knob_count()):
+        n, d = C.c_char_p(), C.c_char_p()
+        v, dv = C.c_int64(), C.c_int64()
+        check(lib.qa_knob_info(i, C.byref(n), C.byref(v), C.byref(dv), C.byref(d)))
+        out[n.value.decode()] = (int(v.value), int(dv.value), d.value.decode())
+    return out
 
 
 def require_device() -> None:

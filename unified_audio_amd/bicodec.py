@@ -99,7 +99,7 @@ class BiCodec(torch.nn.Module):
     def train(self, mode: bool = True):
         if mode:
             raise _lib.QuarkAudioError(-4, "unified_audio_amd.BiCodec is the inference path")
-        return self
+        return super().train(False)
 
     def remove_weight_norm(self):  # bicodec.py:113: weight norm is folded when the weights are loaded
         return self
@@ -118,12 +118,15 @@ class BiCodec(torch.nn.Module):
         if glob.shape[1] != self.spec.token_num:
             raise _lib.QuarkAudioError(-1, f"global_tokens must hold {self.spec.token_num} tokens per item, got {tuple(global_tokens.shape)}")
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        if self.check_tokens:  # F.embedding / the implicit FSQ codebook gather would refuse out-of-range ids: one sync for both
-            for name, t, lim in (("semantic_tokens", sem, self.spec.codebook_size), ("global_tokens", glob, self.spec.global_size)):
-                bad = C.c_int64(0)
-                _lib.check(self._lib.qa_codes_check(t.data_ptr(), t.numel(), lim, C.byref(bad), stream))
-                if bad.value:
-                    raise IndexError(f"{bad.value} {name} out of range [0, {lim})")
+        if self.check_tokens:  # F.embedding / the implicit FSQ codebook gather would refuse out-of-range ids: ONE check (one host
+            # sync) for both tensors - the global ids are scaled onto the semantic range so that a single limit serves
+            lim_s, lim_g = self.spec.codebook_size, self.spec.global_size
+            both = torch.cat([sem.reshape(-1), torch.where((glob >= 0) & (glob < lim_g), 0, lim_s).reshape(-1)])
+            bad = C.c_int64(0)
+            _lib.check(self._lib.qa_codes_check(both.data_ptr(), both.numel(), lim_s, C.byref(bad), stream))
+            if bad.value:
+                n_g = int(((glob < 0) | (glob >= lim_g)).sum())
+                raise IndexError(f"{bad.value - n_g} semantic_tokens out of range [0, {lim_s}), {n_g} global_tokens out of range [0, {lim_g})")
         wav = torch.empty((B, 1, T * self.spec.hop), dtype=torch.float32, device=self.device)
         _lib.check(self._lib.qa_bicodec_detokenize(self._handle, sem.data_ptr(), glob.data_ptr(), B, T, wav.data_ptr(), stream))
         return wav

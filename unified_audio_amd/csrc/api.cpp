@@ -6,9 +6,54 @@
 #include <cstdlib>
 #include <vector>
 
+#include <cstring>
+#include <mutex>
+
 #include "kernels.h"
+#include "knobs.h"
 
 namespace qa {
+// ---- the knob table (knobs.h): values start from the environment, qa_set_knob() overrides at run time
+namespace {
+struct KnobRow {
+    const char* name;
+    long long def;
+    const char* doc;
+};
+const KnobRow g_knob_rows[K_COUNT] = {
+#define QA_KNOB_ROW(id, name, def, doc) {name, (long long)(def), doc},
+    QA_KNOB_TABLE(QA_KNOB_ROW)
+#undef QA_KNOB_ROW
+};
+long long g_knob_val[K_COUNT];
+std::once_flag g_knob_once;
+void knob_init() {
+    for (int i = 0; i < K_COUNT; ++i) {
+        const char* e = getenv(g_knob_rows[i].name);
+        g_knob_val[i] = (e && *e) ? atoll(e) : g_knob_rows[i].def;
+    }
+}
+}  // namespace
+long long knob(Knob k) {
+    std::call_once(g_knob_once, knob_init);
+    return g_knob_val[k];
+}
+void knob_set(Knob k, long long v) {
+    std::call_once(g_knob_once, knob_init);
+    g_knob_val[k] = v;
+}
+int raise_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> done;  // (kernel, device) pairs already raised
+    int dev = 0;
+    QA_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto& kd : done)
+        if (kd.first == kernel && kd.second == dev) return QA_OK;
+    QA_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.emplace_back(kernel, dev);
+    return QA_OK;
+}
 static thread_local char g_err[1024] = "";
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -40,11 +85,7 @@ static hipEvent_t prof_event() {
     return e;
 }
 bool profile_enabled() { return g_prof_on; }
-static bool g_serial = [] {
-    const char* e = getenv("QA_SERIAL");
-    return e && *e && *e != '0';
-}();
-bool serial_mode() { return g_serial; }
+bool serial_mode() { return knob(K_SERIAL) != 0; }
 void profile_record_begin(int cfg, double flops, double bytes, hipStream_t s, const ConvParams* p) {
     ProfRec r{prof_event(), prof_event(), cfg, flops, bytes, 0, 0, 0, 0, 0};
     if (p) {
@@ -62,7 +103,40 @@ using namespace qa;
 extern "C" {
 
 int qa_set_serial(int on) {
-    g_serial = on != 0;
+    knob_set(K_SERIAL, on != 0);
+    return QA_OK;
+}
+
+int qa_knob_count(void) { return K_COUNT; }
+
+int qa_knob_info(int32_t index, const char** name, int64_t* value, int64_t* default_value, const char** doc) {
+    QA_REQUIRE(index >= 0 && index < K_COUNT, "qa_knob_info: index %d out of range", index);
+    if (name) *name = g_knob_rows[index].name;
+    if (value) *value = knob((Knob)index);
+    if (default_value) *default_value = g_knob_rows[index].def;
+    if (doc) *doc = g_knob_rows[index].doc;
+    return QA_OK;
+}
+
+static int knob_index(const char* name) {
+    if (name)
+        for (int i = 0; i < K_COUNT; ++i)
+            if (std::strcmp(name, g_knob_rows[i].name) == 0) return i;
+    set_error("unknown knob '%s' (qa_knob_info enumerates them)", name ? name : "(null)");
+    return -1;
+}
+
+int qa_set_knob(const char* name, int64_t value) {
+    const int i = knob_index(name);
+    if (i < 0) return QA_ERR_INVALID;
+    knob_set((Knob)i, value);
+    return QA_OK;
+}
+
+int qa_get_knob(const char* name, int64_t* value) {
+    const int i = knob_index(name);
+    if (i < 0 || !value) return QA_ERR_INVALID;
+    *value = knob((Knob)i);
     return QA_OK;
 }
 

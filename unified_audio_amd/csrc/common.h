@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 
+#include "knobs.h"
 #include "quarkaudio.h"
 
 namespace qa {
@@ -36,6 +37,10 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 #define QA_LAUNCH_CHECK() QA_HIP(hipGetLastError())
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: raise a kernel's dynamic-LDS limit once per
+// (kernel, device), thread-safe (api.cpp).  Call outside any stream capture.
+int raise_dynamic_lds(const void* kernel, int bytes);
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }

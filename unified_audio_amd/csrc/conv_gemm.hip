@@ -363,21 +363,12 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
     // other's barriers, prologues and epilogues: +10..25 % on the K = 512 layers of the aggregator stacks, +3..5 % on
     // K = 768..3072 (per-shape sweep, tools/gemm_bench.py with QA_GEMM_BK16=0 / default).  QA_GEMM_BK16 = largest K that
     // takes the BK = 16 variant.
-    static const int bk16_max_k = [] {
-        const char* e = getenv("QA_GEMM_BK16");
-        return e ? atoi(e) : 1 << 30;
-    }();
+    const long long bk16_max_k = knob(K_GEMM_BK16);
     // ... but only when the launch has enough tiles for that co-residency: with about one workgroup per CU nobody covers the
     // exposed latency of the next chunk's global loads, which a BK = 16 chunk's 0.45 us of MFMAs is too short to hide (measured: the
     // 144-tile RVQ distance GEMM 1056 x 1024 x 512 ran 37 us, 2.5 x its MFMA time).  QA_GEMM_BK16_MIN_TILES = fewest tiles that take BK = 16.
-    static const long long bk16_min_tiles = [] {
-        const char* e = getenv("QA_GEMM_BK16_MIN_TILES");
-        return e ? atoll(e) : 384LL;
-    }();
-    static const bool linear_on = [] {
-        const char* e = getenv("QA_GEMM_LINEAR");
-        return !e || atoi(e) != 0;
-    }();
+    const long long bk16_min_tiles = knob(K_GEMM_BK16_MIN_TILES);
+    const bool linear_on = knob(K_GEMM_LINEAR) != 0;
     const bool linear = linear_on && p.ksize == 1 && p.stride == 1 && p.pad_left == 0 && p.in_rep <= 1 && p.T_in == p.T_out &&
                         (p.dilation <= 1);
     const bool bk16 = BN >= 64 && p.prologue != ACT_ELU && ((p.K <= bk16_max_k && tiles >= bk16_min_tiles) || p.C_in % 32 != 0);
@@ -408,14 +399,8 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
     QA_REQUIRE(((uintptr_t)p.x % 16) == 0 && ((uintptr_t)p.w % 16) == 0, "conv_gemm: x / w must be 16-byte aligned");
     if (p.M <= 0 || p.N <= 0) return QA_OK;
     QA_REQUIRE(ceil_div(p.M, 64) * ceil_div(p.N, 32) < (1LL << 31), "conv_gemm: grid too large");
-    static const int forced = [] {
-        const char* e = getenv("QA_GEMM_CFG");
-        return e ? atoi(e) : -1;
-    }();
-    static const int swz = [] {
-        const char* e = getenv("QA_GEMM_XCD");
-        return e ? atoi(e) : 1;
-    }();
+    const int forced = (int)knob(K_GEMM_CFG);
+    const int swz = (int)knob(K_GEMM_XCD);
     ConvParams q = p;
     q.xcd_swizzle = swz;
     // frame / in_rep by multiply-high: exact for frame * in_rep < 2^32 (frames of one clip are < 2^31 / ldx)

@@ -51,6 +51,11 @@ struct MimiW {
 struct MimiStream {
     std::vector<float*> kc, vc;
     int B = 0, cap = 0, offset = 0;
+    // streaming_forever(): past the static RoPE table the step reads a rolling window of it (positions rope_base .. rope_base + len)
+    // rebuilt on the host whenever the stream leaves it, so the offset is unbounded like the reference's (module/rope.py computes
+    // the angles from the running offset)
+    float* rope_win = nullptr;
+    int rope_base = 0, rope_len = 0;
 };
 
 constexpr int MAX_POS = 8192;
@@ -127,6 +132,22 @@ namespace qa {
 namespace {
 
 // ---------------------------------------------------------------- weight folding (host)
+
+// apply_rope (mimi/module/rope.py:38-56): freqs = exp(i * (-ln(P) * 2 / D)), angle = freqs * t, all in fp32; (cos, sin) pairs of
+// positions pos0 .. pos0 + n - 1 as [n][hd/2][2]
+void mimi_rope_table(int hd, int pos0, int n, std::vector<float>* cs) {
+    const int half = hd / 2;
+    cs->resize((size_t)n * half * 2);
+    const float coef = (float)(-std::log(10000.0) * 2.0 / hd);
+    for (int i = 0; i < half; ++i) {
+        const float fr = std::exp((float)i * coef);
+        for (int t = 0; t < n; ++t) {
+            const float ang = fr * (float)(pos0 + t);
+            (*cs)[((size_t)t * half + i) * 2] = (float)std::cos((double)ang);
+            (*cs)[((size_t)t * half + i) * 2 + 1] = (float)std::sin((double)ang);
+        }
+    }
+}
 
 struct Folder {
     const HostTable& tab;
@@ -309,18 +330,8 @@ void build_mimi(Builder& b, MimiW* mw, const std::string& p, int d, int n_layers
         L.lin2.N = d; L.lin2.C_in = ff;
         b.vec(&L.lin2.w, lp + ".linear2.weight", (int64_t)ff * d);
     }
-    // apply_rope (mimi/module/rope.py:38-56): freqs = exp(i * (-ln(P) * 2 / D)), angle = freqs * t, all in fp32
-    const int hd = d / heads, half = hd / 2;
-    std::vector<float> cs((size_t)MAX_POS * half * 2);
-    const float coef = (float)(-std::log(10000.0) * 2.0 / hd);
-    for (int i = 0; i < half; ++i) {
-        const float fr = std::exp((float)i * coef);
-        for (int t = 0; t < MAX_POS; ++t) {
-            const float ang = fr * (float)t;
-            cs[((size_t)t * half + i) * 2] = (float)std::cos((double)ang);
-            cs[((size_t)t * half + i) * 2 + 1] = (float)std::sin((double)ang);
-        }
-    }
+    std::vector<float> cs;
+    mimi_rope_table(d / heads, 0, MAX_POS, &cs);
     b.raw(&mw->rope, cs);
 }
 
@@ -432,11 +443,14 @@ int mimi_layer(Ctx& c, const MimiW& mw, const MimiLayerW& L, float* x, const Mim
     const int d = mw.d, H = mw.heads, hd = d / H;
     const int64_t rows = (int64_t)B * N;
     const int pos0 = st ? st->offset : 0;
+    const bool win = st && st->rope_len > 0;  // RoPE angles from the rolling window (positions beyond the static table)
+    const float* rope = win ? st->rope_win : mw.rope;
+    const int rope_pos0 = win ? pos0 - st->rope_base : pos0;
     const float scale = 1.0f / std::sqrt((float)hd);
     QA_TRY(launch_layernorm(x, L.n1w, L.n1b, t.hn, rows, d, 1e-5f, c.stream));
     // fused QKV projection with the interleaved-pair RoPE of q and k applied in the GEMM epilogue (one launch less per layer)
     QA_TRY(conv_op(c, t.hn, d, 1, (int)rows, L.in_proj, t.qkv, 3 * d, (int)rows, 1, 0, 0, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, nullptr,
-                   3 * d, nullptr, ACT_NONE, 1, mw.rope, 2 * d, hd, N, pos0));
+                   3 * d, nullptr, ACT_NONE, 1, rope, 2 * d, hd, N, rope_pos0));
     if (st) {
         // RingKVCache.complete(): the chunk's keys / values are written first, then every query attends over the ring
         QA_TRY(launch_ring_append(t.qkv + d, t.qkv + 2 * d, 3 * d, st->kc[li], st->vc[li], B, N, d, st->cap, pos0, c.stream));
@@ -1058,6 +1072,28 @@ int build(qa_hcodec* h, const HostTable& tab) {
 }  // namespace
 }  // namespace qa
 
+// The non-dry pass of a model graph.  A call that launched the persistent LSTM recurrence (lstm.hip) waits for its stream before
+// returning and, should one of that kernel's grid barriers have timed out (it needs every workgroup resident at once: the device
+// was shared with another such kernel), runs the graph again on the per-step kernels - the call that hit the failure returns
+// valid results, and the device stops choosing the persistent kernel by itself.
+template <typename F>
+static int run_graph_checked(qa_hcodec* h, Ctx& c, F&& graph) {
+    const unsigned long long before = lstm_persistent_count(h->device);
+    QA_TRY(graph());
+    if (lstm_persistent_count(h->device) == before) return QA_OK;
+    bool failed = false;
+    QA_TRY(lstm_persistent_collect(h->device, c.stream, &failed));
+    if (!failed) return QA_OK;
+    std::fprintf(stderr, "libquarkaudio_hip: the grid barrier of the persistent LSTM recurrence timed out on device %d (shared device?); "
+                         "re-running the call on the per-step kernels\n", h->device);
+    lstm_force_per_step(true);
+    c.taps.clear();
+    c.arena.begin(h->ws, h->ws_cap);
+    const int st = graph();
+    lstm_force_per_step(false);
+    return st;
+}
+
 extern "C" {
 
 int qa_hcodec_create(qa_hcodec** out, const qa_hcodec_spec* spec, const qa_tensor* tensors, int64_t n_tensors, int device) {
@@ -1118,7 +1154,7 @@ int qa_hcodec_encode(qa_hcodec* h, const float* wav, int64_t B, int64_t T, const
     c.dry = false;
     c.taps.clear();
     c.arena.begin(h->ws, h->ws_cap);
-    return encode_graph(h, c, wav, (int)B, (int)T, feat, fsb, fsc, fst, (int)n_feat, (long long*)ac, (long long*)sc);
+    return run_graph_checked(h, c, [&] { return encode_graph(h, c, wav, (int)B, (int)T, feat, fsb, fsc, fst, (int)n_feat, (long long*)ac, (long long*)sc); });
 }
 
 int qa_hcodec_decode(qa_hcodec* h, const int64_t* ac, const int64_t* sc, int64_t B, int64_t N, float* wav_out, void* stream) {
@@ -1139,7 +1175,7 @@ int qa_hcodec_decode(qa_hcodec* h, const int64_t* ac, const int64_t* sc, int64_t
     c.dry = false;
     c.taps.clear();
     c.arena.begin(h->ws, h->ws_cap);
-    return decode_graph(h, c, (const long long*)ac, (const long long*)sc, (int)B, (int)N, wav_out);
+    return run_graph_checked(h, c, [&] { return decode_graph(h, c, (const long long*)ac, (const long long*)sc, (int)B, (int)N, wav_out); });
 }
 
 int qa_hcodec_encode_adaptive(qa_hcodec* h, const float* wav, int64_t B, int64_t T, const float* feat, int64_t fsb, int64_t fsc,
@@ -1167,7 +1203,9 @@ int qa_hcodec_encode_adaptive(qa_hcodec* h, const float* wav, int64_t B, int64_t
     c.dry = false;
     c.taps.clear();
     c.arena.begin(h->ws, h->ws_cap);
-    QA_TRY(encode_adaptive_graph(h, c, wav, (int)B, (int)T, feat, fsb, fsc, fst, (int)n_feat, (long long*)ac, (long long*)sc, &G, thr));
+    QA_TRY(run_graph_checked(h, c, [&] {
+        return encode_adaptive_graph(h, c, wav, (int)B, (int)T, feat, fsb, fsc, fst, (int)n_feat, (long long*)ac, (long long*)sc, &G, thr);
+    }));
     *n_groups = G;
     return QA_OK;
 }
@@ -1210,7 +1248,7 @@ int qa_hcodec_decode_adaptive(qa_hcodec* h, const int64_t* ac, const int64_t* sc
     c.dry = false;
     c.taps.clear();
     c.arena.begin(h->ws, h->ws_cap);
-    return decode_adaptive_graph(h, c, (const long long*)ac, (const long long*)sc, (int)B, (int)G, (int)frames, wav_out);
+    return run_graph_checked(h, c, [&] { return decode_adaptive_graph(h, c, (const long long*)ac, (const long long*)sc, (int)B, (int)G, (int)frames, wav_out); });
 }
 
 int qa_hcodec_enable_taps(qa_hcodec* h, int on) {
@@ -1284,6 +1322,7 @@ void qa_mimi_destroy(qa_mimi* m) {
     (void)hipDeviceSynchronize();
     m->store.release();
     if (m->ring) (void)hipFree(m->ring);
+    if (m->st.rope_win) (void)hipFree(m->st.rope_win);
     if (m->ws) (void)hipFree(m->ws);
     delete m;
 }
@@ -1349,6 +1388,7 @@ int qa_mimi_stream_begin(qa_mimi* m, int64_t B) {
     m->st.B = (int)B;
     m->st.cap = m->spec.context;
     m->st.offset = 0;
+    m->st.rope_len = 0;
     return QA_OK;
 }
 
@@ -1360,10 +1400,26 @@ int qa_mimi_stream_step(qa_mimi* m, const float* x, int64_t T, float* y, void* s
     QA_REQUIRE(m->st.B > 0, "qa_mimi_stream_step: not streaming (call qa_mimi_stream_begin)");
     QA_REQUIRE(T >= 1 && T <= m->st.cap, "qa_mimi_stream_step: a chunk of %lld frames does not fit the ring of %d (RingKVCache.complete "
                "would write one slot twice)", (long long)T, m->st.cap);
-    QA_REQUIRE((int64_t)m->st.offset + T <= MAX_POS, "qa_mimi_stream_step: offset %d + %lld exceeds the RoPE table (%d positions); "
-               "reset the stream", m->st.offset, (long long)T, MAX_POS);
+    QA_REQUIRE((int64_t)m->st.offset + T < (1LL << 31), "qa_mimi_stream_step: offset %d + %lld overflows", m->st.offset, (long long)T);
     QA_HIP(hipSetDevice(m->device));
-    QA_TRY(mimi_run(m, x, m->st.B, (int)T, y, static_cast<hipStream_t>(stream), true));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // positions beyond the static table (QA_MIMI_ROPE_WINDOW shrinks it, for tests): a rolling window of the same table
+    MimiStream& st = m->st;
+    const int table = (int)std::min<long long>(MAX_POS, std::max<long long>(st.cap, knob(K_MIMI_ROPE_WINDOW)));
+    const long long end = (long long)st.offset + T;
+    if (end <= table) {
+        st.rope_len = 0;
+    } else if (st.rope_len == 0 || st.offset < st.rope_base || end > (long long)st.rope_base + st.rope_len) {
+        const int hd = m->w.d / m->w.heads;
+        if (!st.rope_win) QA_HIP(hipMalloc(reinterpret_cast<void**>(&st.rope_win), sizeof(float) * (size_t)MAX_POS * hd));
+        std::vector<float> cs;
+        mimi_rope_table(hd, st.offset, table, &cs);
+        QA_HIP(hipStreamSynchronize(s));  // earlier steps may still read the old window; `cs` is a stack-lifetime host buffer
+        QA_HIP(hipMemcpy(st.rope_win, cs.data(), sizeof(float) * cs.size(), hipMemcpyHostToDevice));
+        st.rope_base = st.offset;
+        st.rope_len = table;
+    }
+    QA_TRY(mimi_run(m, x, m->st.B, (int)T, y, s, true));
     m->st.offset += (int)T;
     return QA_OK;
 }
@@ -1375,6 +1431,7 @@ int qa_mimi_stream_reset(qa_mimi* m) {
     }
     QA_REQUIRE(m->st.B > 0, "qa_mimi_stream_reset: Trying to reset streaming, but the transformer wasn't streaming (streaming.py:118-121)");
     m->st.offset = 0;  // RingKVCache.reset(): the caches keep their contents, end_offset = 0 alone invalidates them
+    m->st.rope_len = 0;
     return QA_OK;
 }
 
@@ -1389,6 +1446,7 @@ int qa_mimi_stream_end(qa_mimi* m) {
         (void)hipFree(m->ring);
     }
     m->ring = nullptr;
+    if (m->st.rope_win) (void)hipFree(m->st.rope_win);
     m->st = MimiStream{};
     return QA_OK;
 }

@@ -68,6 +68,11 @@ int launch_ring_append(const float* k, const float* v, long long ld, float* kc, 
 //   w_hh [4d, d] rows permuted the same way.  h_out [B, T, d].  c_state [B, d] scratch.
 int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d,
                 hipStream_t s);
+// persistent-recurrence bookkeeping for the model graphs: launches so far on `dev`; wait for `s` and report (and clear) a barrier
+// time-out; make this thread's next launch_lstm calls take the per-step kernels
+unsigned long long lstm_persistent_count(int dev);
+int lstm_persistent_collect(int dev, hipStream_t s, bool* failed);
+void lstm_force_per_step(bool on);
 
 // rvq.hip
 // scratch: rvq_scratch_floats(n_vec, K, D) floats of device workspace (residuals, distance products, norms of one chunk)

@@ -1,0 +1,50 @@
+// knobs.h - every tuning / A-B switch of libquarkaudio_hip in ONE table (INTEGRATION.md lists the same rows).
+//
+// A knob is an integer.  Its initial value comes from the environment variable of the same name (read once, at the first
+// use of any knob); qa_set_knob() changes it at run time, so tests and A/B sessions flip a switch inside one process
+// instead of re-spawning with another environment.  Kernels never read knobs: only the host-side launch code does, at
+// launch (or handle-creation) time.
+#pragma once
+#include <cstdint>
+
+namespace qa {
+
+#define QA_KNOB_TABLE(X)                                                                                                           \
+    X(SERIAL, "QA_SERIAL", 0, "1: no internal stream concurrency (every kernel alone on the device; = qa_set_serial)")           \
+    X(GEMM_CFG, "QA_GEMM_CFG", -1, "force the conv_gemm tile: 0 = 128x32, 1 = 128x64, 2 = 128x128 (-1: cost model)")             \
+    X(GEMM_BK16, "QA_GEMM_BK16", 1 << 30, "largest K that takes the BK = 16 K-chunk variant")                                     \
+    X(GEMM_BK16_MIN_TILES, "QA_GEMM_BK16_MIN_TILES", 384, "fewest tiles of a launch that take BK = 16")                          \
+    X(GEMM_LINEAR, "QA_GEMM_LINEAR", 1, "table-free K loop for ksize-1 layers")                                                  \
+    X(GEMM_XCD, "QA_GEMM_XCD", 1, "XCD-aware tile order")                                                                        \
+    X(GEMM_GROUPED, "QA_GEMM_GROUPED", 1, "H-Codec 1.5: the two aggregator stacks as ONE grouped launch per layer op (0: two streams)") \
+    X(SEANET_FUSED, "QA_SEANET_FUSED", 1, "fused conv0 + first SEANet residual block")                                           \
+    X(MIMI_ROPE_WINDOW, "QA_MIMI_ROPE_WINDOW", 8192, "mimi streaming: positions covered by the RoPE table before the rolling window takes over (tests shrink it)") \
+    X(RVQ_LEGACY, "QA_RVQ_LEGACY", 0, "1: the single-launch RVQ search kernel instead of distance GEMM + pick")                   \
+    X(LSTM_GRAPH, "QA_LSTM_GRAPH", 1, "replay the T step launches of an LSTM call from a cached hipGraph")                       \
+    X(LSTM_SPLIT, "QA_LSTM_SPLIT", 0, "1: two concurrent half-batch step chains (measured slower)")                              \
+    X(LSTM_PERSISTENT, "QA_LSTM_PERSISTENT", -1, "persistent recurrence kernel: -1 auto (d >= 1536), 0 off, 1 on for every supported width") \
+    X(LSTM_SPIN_LIMIT, "QA_LSTM_SPIN_LIMIT", 1 << 21, "persistent recurrence: polls of a barrier word before the barrier is declared broken") \
+    X(LSTM_FAULT, "QA_LSTM_FAULT", 0, "1 (tests): the persistent kernel's barrier waits for a workgroup that does not exist, like a starved launch") \
+    X(LM_GRAPH, "QA_LM_GRAPH", 0, "1: replay one captured decode step per token")                                                \
+    X(LM_UNFUSED, "QA_LM_UNFUSED", 0, "1: the per-op decode step (skinny GEMM + attention_decode kernels) instead of the fused one") \
+    X(LM_MFMA16, "QA_LM_MFMA16", 0, "1: narrow GEMV tiles on the 16x16x4 MFMA instead of the 4x4x1")                             \
+    X(LM_NT_QKV, "QA_LM_NT_QKV", 0, "column-tile width of the qkv GEMV (4 / 8 / 16; 0: lm_pick_nt)")                             \
+    X(LM_NT_O, "QA_LM_NT_O", 0, "column-tile width of the o_proj GEMV")                                                          \
+    X(LM_NT_GU, "QA_LM_NT_GU", 0, "column-tile width of the gate/up GEMV")                                                       \
+    X(LM_NT_DOWN, "QA_LM_NT_DOWN", 0, "column-tile width of the down GEMV")                                                      \
+    X(LM_MLP_FUSED, "QA_LM_MLP_FUSED", 1, "decode step: gate/up + SwiGLU + down in one launch emitting K-slice partials, summed by a reduce launch (0: gate/up and down launches)") \
+    X(LM_PICK_FOLD, "QA_LM_PICK_FOLD", 1, "decode step: greedy pick folded into the next step's first launch")                   \
+    X(LM_ATT_SPLIT, "QA_LM_ATT_SPLIT", 0, "decode step: keys per attention split (0: 256)")                                      \
+    X(LM_CHAINS, "QA_LM_CHAINS", 0, "generate: number of concurrent sub-batch chains for B > 32 (0: auto)")
+
+enum Knob {
+#define QA_KNOB_ENUM(id, name, def, doc) K_##id,
+    QA_KNOB_TABLE(QA_KNOB_ENUM)
+#undef QA_KNOB_ENUM
+        K_COUNT
+};
+
+long long knob(Knob k);
+void knob_set(Knob k, long long v);
+
+}  // namespace qa

@@ -113,17 +113,16 @@ int build_lm(qa_lm* lm, const HostTable& tab) {
     QA_REQUIRE(hd == 32 || hd == 64 || hd == 128, "lm spec: head_dim %d unsupported", hd);
     QA_REQUIRE(d % 32 == 0 && I % 32 == 0 && sp.feats_dim % 32 == 0, "lm spec: widths must be multiples of 32");
     // fused decode step: K of every GEMV a multiple of 256, every N a multiple of its tile width, rotary pairs inside a tile
-    auto tile_width = [](const char* env, int n) {  // QA_LM_NT_{QKV,O,GU,DOWN}: tuning override of the column-tile width
-        const char* e = std::getenv(env);
-        const int v = e ? std::atoi(e) : 0;
+    auto tile_width = [](Knob k, int n) {  // QA_LM_NT_{QKV,O,GU,DOWN}: tuning override of the column-tile width
+        const int v = (int)knob(k);
         return (v == 4 || v == 8 || v == 16) ? v : lm_pick_nt(n);
     };
-    lm->nt_qkv = tile_width("QA_LM_NT_QKV", 3 * d);
-    lm->nt_o = tile_width("QA_LM_NT_O", d);
-    lm->nt_gu = tile_width("QA_LM_NT_GU", 2 * I);
-    lm->nt_down = tile_width("QA_LM_NT_DOWN", d);
+    lm->nt_qkv = tile_width(K_LM_NT_QKV, 3 * d);
+    lm->nt_o = tile_width(K_LM_NT_O, d);
+    lm->nt_gu = tile_width(K_LM_NT_GU, 2 * I);
+    lm->nt_down = tile_width(K_LM_NT_DOWN, d);
     lm->fused_ok = lm_gemv_supported(d, I) && d % lm->nt_qkv == 0 && hd % lm->nt_qkv == 0 && d % lm->nt_o == 0 &&
-                   (2 * I) % lm->nt_gu == 0 && hd % 8 == 0 && std::getenv("QA_LM_UNFUSED") == nullptr;
+                   (2 * I) % lm->nt_gu == 0 && hd % 8 == 0 && knob(K_LM_UNFUSED) == 0;
     WeightStore& st = lm->store;
     bool ok = true;
     std::vector<std::pair<const float**, size_t>> pend;
@@ -379,10 +378,7 @@ uint64_t mix_key(uint64_t h, uint64_t v) {
 // QA_LM_GRAPH=1: replay one captured step per token instead of launching its kernels from the host.  Measured equal within 1 %
 // on MI355X (the step is bound by its ~62 dependent kernels, not by the host), and a replayed step must read the position from
 // device memory - one more dependent load per kernel - and cannot size the attention grid to the current key count: off by default.
-bool use_graphs() {
-    const char* e = std::getenv("QA_LM_GRAPH");
-    return e && e[0] == '1';
-}
+bool use_graphs() { return knob(K_LM_GRAPH) != 0; }
 
 int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, const float* mix, int Nm, int B, int G,
                    int S, long long* gids, long long* sids, const SampleCfg& sc) {

@@ -449,10 +449,7 @@ int lm_pick_nt(int N) {
 }
 
 // QA_LM_MFMA16=1: narrow tiles on the 16x16x4 kernel too (A/B switch for tests and measurements)
-static bool narrow_on_4x4() {
-    static const bool v = std::getenv("QA_LM_MFMA16") == nullptr;
-    return v;
-}
+static bool narrow_on_4x4() { return knob(K_LM_MFMA16) == 0; }
 
 // 32-wide chunks per batch of the 16x16x4 kernel for a given K: the whole per-wave share when it is at most 8 chunks (K <= 2048)
 static int gemv_nb(int K) {
@@ -896,16 +893,9 @@ __global__ __launch_bounds__(1024) void lm_sample_kernel(const float* __restrict
     }
 }
 
-// the sampler sorts up to 16384 64-bit keys in LDS (128 KiB): raise the kernel's dynamic-LDS limit once per process, outside
+// the sampler sorts up to 16384 64-bit keys in LDS (128 KiB): raise the kernel's dynamic-LDS limit once per device, outside
 // any stream capture
-int lm_sample_prepare() {
-    static bool done = false;
-    if (!done) {
-        QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lm_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
-        done = true;
-    }
-    return QA_OK;
-}
+int lm_sample_prepare() { return raise_dynamic_lds(reinterpret_cast<const void*>(lm_sample_kernel), 16384 * 8); }
 
 int launch_lm_sample(const float* logits, long long ldl, int width, int B, int lo, int top_k, float top_p, float temperature,
                      int do_sample, long long* tok, long long* ids, long long ids_ld, int keep, const int* state, hipStream_t s) {

@@ -161,10 +161,7 @@ static void lstm_chain(const float* xw_b, const float* w_hh_ug, float* h_b, floa
 // overlap too little to pay for that (147.4 vs 144.9 ms per step), so one chain stays the default.
 static int lstm_launch_steps(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d, hipStream_t s,
                              hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
-    static const bool split_ok = [] {
-        const char* e = std::getenv("QA_LSTM_SPLIT");
-        return e && e[0] == '1';
-    }();
+    const bool split_ok = knob(K_LSTM_SPLIT) != 0;
     for (int b0 = 0; b0 < B; b0 += 64) {
         const int bn = std::min(64, B - b0);
         const float* xw_b = xw + (long long)b0 * T * 4 * d;
@@ -194,14 +191,14 @@ static int lstm_launch_steps(const float* xw, const float* w_hh_ug, float* h_out
 namespace {
 // sync words, one per 128-byte line: grp_cnt[8] | top_cnt | top_gen | grp_gen[8] | err
 enum { SY_GRP_CNT = 0, SY_TOP_CNT = 8, SY_TOP_GEN = 9, SY_GRP_GEN = 10, SY_ERR = 18, SY_WORDS = 19, SY_STRIDE = 32 };
-constexpr unsigned LSTM_SPIN_LIMIT = 1u << 21;  // x (s_sleep + one L2 round trip) ~ seconds: then the barrier is declared broken
+// spin bound of the barrier polls: QA_LSTM_SPIN_LIMIT, default 2^21 x (s_sleep + one L2 round trip) ~ seconds, then the barrier is declared broken
 constexpr int LSTM_SYNC_RING = 8;
 }  // namespace
 
 #define QA_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-__device__ __forceinline__ bool lstm_spin_until(unsigned* word, unsigned want, unsigned* err, unsigned* err_host) {
-    for (unsigned spins = 0; spins < LSTM_SPIN_LIMIT; ++spins) {
+__device__ __forceinline__ bool lstm_spin_until(unsigned* word, unsigned want, unsigned* err, unsigned* err_host, unsigned limit) {
+    for (unsigned spins = 0; spins < limit; ++spins) {
         if (__hip_atomic_load(word, QA_RLX) >= want) return true;
         if ((spins & 1023u) == 1023u && __hip_atomic_load(err, QA_RLX) != 0u) return false;
         __builtin_amdgcn_s_sleep(1);
@@ -223,12 +220,13 @@ __device__ __forceinline__ f32x4 lstm_load_sc1_b128(const float* p) {
 // one lane per workgroup; epoch = steps completed (1-based).  The last arriver of a group (blockIdx % ngrp: the XCD a workgroup is
 // observed to land on - a speed assumption only) forwards to the top counter, the last group publishes top_gen, every group's
 // forwarder republishes it as its group's generation word, which is what the group's pollers read.
-__device__ __forceinline__ void lstm_barrier_arrive(unsigned* sy, int g, unsigned epoch, unsigned per_grp, unsigned ngrp, unsigned* err_host) {
+__device__ __forceinline__ void lstm_barrier_arrive(unsigned* sy, int g, unsigned epoch, unsigned per_grp, unsigned ngrp, unsigned* err_host,
+                                                    unsigned limit) {
     const unsigned old = __hip_atomic_fetch_add(sy + (SY_GRP_CNT + g) * SY_STRIDE, 1u, QA_RLX);
     if (old + 1u == per_grp * epoch) {
         const unsigned o2 = __hip_atomic_fetch_add(sy + SY_TOP_CNT * SY_STRIDE, 1u, QA_RLX);
         if (o2 + 1u == ngrp * epoch) __hip_atomic_store(sy + SY_TOP_GEN * SY_STRIDE, epoch, QA_RLX);
-        else if (!lstm_spin_until(sy + SY_TOP_GEN * SY_STRIDE, epoch, sy + SY_ERR * SY_STRIDE, err_host)) return;
+        else if (!lstm_spin_until(sy + SY_TOP_GEN * SY_STRIDE, epoch, sy + SY_ERR * SY_STRIDE, err_host, limit)) return;
         __hip_atomic_store(sy + (SY_GRP_GEN + g) * SY_STRIDE, epoch, QA_RLX);
     }
 }
@@ -237,7 +235,7 @@ __device__ __forceinline__ void lstm_barrier_arrive(unsigned* sy, int g, unsigne
 template <int MT, int NT, int NI>
 __global__ __launch_bounds__(512) void lstm_persistent_kernel(const float* __restrict__ xw, const float* __restrict__ w_hh, float* h_out,
                                                               float* __restrict__ c_state, int B, int T, int d, int U, unsigned* sy,
-                                                              int ngrp, int per_grp, unsigned* err_host) {
+                                                              int ngrp, int per_grp, unsigned* err_host, unsigned spin_limit) {
     __shared__ float part[4][MT * NT][16][17];
     __shared__ int s_ok;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -267,7 +265,7 @@ __global__ __launch_bounds__(512) void lstm_persistent_kernel(const float* __res
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (t > 0) {
-            if (tid == 0) s_ok = lstm_spin_until(sy + (SY_GRP_GEN + grp) * SY_STRIDE, (unsigned)t, sy + SY_ERR * SY_STRIDE, err_host) ? 1 : 0;
+            if (tid == 0) s_ok = lstm_spin_until(sy + (SY_GRP_GEN + grp) * SY_STRIDE, (unsigned)t, sy + SY_ERR * SY_STRIDE, err_host, spin_limit) ? 1 : 0;
             __syncthreads();
             if (!s_ok) break;  // uniform: a broken barrier ends the call for everybody (the error words are set)
             asm volatile("" ::: "memory");
@@ -334,7 +332,7 @@ __global__ __launch_bounds__(512) void lstm_persistent_kernel(const float* __res
         if (t + 1 < T) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the workgroup reports the step done
             __syncthreads();
-            if (tid == 0) lstm_barrier_arrive(sy, grp, (unsigned)(t + 1), (unsigned)per_grp, (unsigned)ngrp, err_host);
+            if (tid == 0) lstm_barrier_arrive(sy, grp, (unsigned)(t + 1), (unsigned)per_grp, (unsigned)ngrp, err_host, spin_limit);
         }
     }
     if (epi) c_state[(long long)eb * d + unit] = c_reg;
@@ -346,17 +344,15 @@ struct LstmPersistentDev {
     unsigned* err_host = nullptr;  // pinned, mapped: written by a kernel whose barrier timed out
     unsigned* err_dev = nullptr;   // device alias of err_host
     int cus = 0, next = 0;
+    unsigned long long launches = 0;  // persistent launches so far (the model graphs compare it around a call)
+    bool degraded = false;            // a barrier timed out on this device: the auto mode stops choosing the persistent kernel
 };
 LstmPersistentDev g_lstm_p[16];
+std::mutex g_lstm_mu;  // guards the persistent-device table and the step-graph cache
+thread_local bool t_lstm_per_step = false;  // lstm_force_per_step(): the re-run of a call whose persistent recurrence failed
 
 // -1 auto (widths whose per-step weight stream dominates: d >= 1536), 0 off, 1 on for every supported width
-int lstm_persistent_mode() {
-    static const int mode = [] {
-        const char* e = std::getenv("QA_LSTM_PERSISTENT");
-        return e ? (e[0] == '0' ? 0 : 1) : -1;
-    }();
-    return mode;
-}
+int lstm_persistent_mode() { return (int)knob(K_LSTM_PERSISTENT); }
 }  // namespace
 
 // returns QA_OK and sets *done = true when the persistent kernel took the call; *done = false: shape / device not eligible
@@ -364,9 +360,9 @@ static int launch_lstm_persistent(const float* xw, const float* w_hh_ug, float* 
                                   int dev, bool* done) {
     *done = false;
     const int mode = lstm_persistent_mode();
-    if (mode == 0 || (mode < 0 && d < 1536)) return QA_OK;
-    if (!(d == 1536 || d == 1024 || d == 768 || d == 512) || T < 2) return QA_OK;
     LstmPersistentDev& P = g_lstm_p[dev];
+    if (t_lstm_per_step || mode == 0 || (mode < 0 && (d < 1536 || P.degraded))) return QA_OK;
+    if (!(d == 1536 || d == 1024 || d == 768 || d == 512) || T < 2) return QA_OK;
     if (!P.sync) {
         QA_HIP(hipDeviceGetAttribute(&P.cus, hipDeviceAttributeMultiprocessorCount, dev));
         QA_HIP(hipMalloc(reinterpret_cast<void**>(&P.sync), sizeof(unsigned) * LSTM_SYNC_RING * SY_WORDS * SY_STRIDE));
@@ -374,8 +370,9 @@ static int launch_lstm_persistent(const float* xw, const float* w_hh_ug, float* 
         *P.err_host = 0u;
         QA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&P.err_dev), P.err_host, 0));
     }
-    if (*static_cast<volatile unsigned*>(P.err_host) != 0u) {
+    if (*static_cast<volatile unsigned*>(P.err_host) != 0u) {  // backstop: a caller that did not collect (lstm_persistent_collect)
         *P.err_host = 0u;
+        P.degraded = true;
         set_error("lstm: the grid barrier of an earlier persistent LSTM call on device %d timed out (its outputs are invalid): the kernel "
                   "needs every workgroup resident at once - another persistent kernel was sharing the device; set QA_LSTM_PERSISTENT=0", dev);
         return QA_ERR_HIP;
@@ -385,7 +382,9 @@ static int launch_lstm_persistent(const float* xw, const float* w_hh_ug, float* 
     while (U <= 8 && (d % U || d / U > P.cus || (d / U) % 8)) ++U;
     const int NT = (4 * U + 15) / 16;
     if (U > 8 || NT > 2 || (NT == 2 && d != 1536) || (NT == 1 && d == 1536)) return QA_OK;
-    const int nwg = d / U, ngrp = 8, per_grp = nwg / ngrp;
+    // QA_LSTM_FAULT (tests): the barrier waits for one workgroup more than exists, i.e. what a starved launch looks like
+    const int nwg = d / U, ngrp = 8, per_grp = nwg / ngrp + (knob(K_LSTM_FAULT) ? 1 : 0);
+    const unsigned spin_limit = (unsigned)std::max<long long>(64, std::min<long long>(knob(K_LSTM_SPIN_LIMIT), 1LL << 30));
     for (int b0 = 0; b0 < B; b0 += 32) {
         const int bn = std::min(32, B - b0);
         const float* xw_b = xw + (long long)b0 * T * 4 * d;
@@ -395,7 +394,7 @@ static int launch_lstm_persistent(const float* xw, const float* w_hh_ug, float* 
         P.next = (P.next + 1) % LSTM_SYNC_RING;
         QA_HIP(hipMemsetAsync(sy, 0, sizeof(unsigned) * SY_WORDS * SY_STRIDE, s));  // every polled word, before EVERY launch
 #define QA_LP(MT, NT_, NI) \
-    hipLaunchKernelGGL((lstm_persistent_kernel<MT, NT_, NI>), dim3(nwg), dim3(512), 0, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, U, sy, ngrp, per_grp, P.err_dev)
+    hipLaunchKernelGGL((lstm_persistent_kernel<MT, NT_, NI>), dim3(nwg), dim3(512), 0, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, U, sy, ngrp, per_grp, P.err_dev, spin_limit)
         const bool two = bn > 16;
         if (d == 1536) { if (two) QA_LP(2, 2, 12); else QA_LP(1, 2, 12); }
         else if (d == 1024) { if (two) QA_LP(2, 1, 8); else QA_LP(1, 1, 8); }
@@ -403,10 +402,35 @@ static int launch_lstm_persistent(const float* xw, const float* w_hh_ug, float* 
         else { if (two) QA_LP(2, 1, 4); else QA_LP(1, 1, 4); }
 #undef QA_LP
         QA_LAUNCH_CHECK();
+        ++P.launches;
     }
     *done = true;
     return QA_OK;
 }
+
+// ---- what the model graphs (hcodec.cpp) do about a timed-out barrier: a call that launched the persistent kernel waits for its
+// stream before returning, reads the error word, and - if a barrier broke - runs itself again on the per-step kernels, so the
+// call that HIT the failure still returns valid results (the error used to surface one call late, or never).
+unsigned long long lstm_persistent_count(int dev) {
+    std::lock_guard<std::mutex> lock(g_lstm_mu);
+    return (dev >= 0 && dev < 16) ? g_lstm_p[dev].launches : 0ull;
+}
+
+int lstm_persistent_collect(int dev, hipStream_t s, bool* failed) {
+    *failed = false;
+    QA_HIP(hipStreamSynchronize(s));
+    std::lock_guard<std::mutex> lock(g_lstm_mu);
+    if (dev < 0 || dev >= 16) return QA_OK;
+    LstmPersistentDev& P = g_lstm_p[dev];
+    if (P.err_host && *static_cast<volatile unsigned*>(P.err_host) != 0u) {
+        *P.err_host = 0u;
+        if (knob(K_LSTM_FAULT) == 0) P.degraded = true;  // an injected fault (tests) says nothing about the device
+        *failed = true;
+    }
+    return QA_OK;
+}
+
+void lstm_force_per_step(bool on) { t_lstm_per_step = on; }
 
 // The T step launches of one call as a hipGraph: captured once per (buffers, shape) - the model graphs re-use the same arena
 // addresses call after call - and replayed, so the host issues one graph launch instead of T kernel launches (eager launches go
@@ -419,7 +443,6 @@ struct LstmGraph {
     hipGraphExec_t exec;
     unsigned long long stamp;
 };
-std::mutex g_lstm_mu;
 std::vector<LstmGraph> g_lstm_graphs;
 hipStream_t g_lstm_cap[16] = {}, g_lstm_side[16] = {}, g_lstm_cap_side[16] = {};
 hipEvent_t g_lstm_ev[16][2] = {};
@@ -430,10 +453,7 @@ constexpr size_t LSTM_GRAPH_CACHE = 24;
 int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d,
                 hipStream_t s) {
     QA_REQUIRE(d % 128 == 0, "lstm: hidden size %d must be a multiple of 128", d);
-    static const bool use_graph = [] {
-        const char* e = std::getenv("QA_LSTM_GRAPH");
-        return !(e && e[0] == '0');
-    }();
+    const bool use_graph = knob(K_LSTM_GRAPH) != 0;
     int dev = 0;
     QA_HIP(hipGetDevice(&dev));
     QA_REQUIRE(dev >= 0 && dev < 16, "lstm: device index %d out of range", dev);

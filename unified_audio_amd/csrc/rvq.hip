@@ -259,7 +259,7 @@ int launch_rvq_search(const float* x, long long n_vec, const float* codebooks, c
     QA_REQUIRE(D % 8 == 0 && D >= 8, "rvq_search: D=%d must be a multiple of 8", D);
     QA_REQUIRE(Q >= 1 && K >= 1, "rvq_search: Q=%d K=%d", Q, K);
     if (n_vec <= 0) return QA_OK;
-    if (rvq_gemm_ok(K, D) && std::getenv("QA_RVQ_LEGACY") == nullptr) {
+    if (rvq_gemm_ok(K, D) && knob(K_RVQ_LEGACY) == 0) {
         QA_REQUIRE(scratch != nullptr, "rvq_search: the GEMM path needs rvq_scratch_floats() floats of workspace");
         const long long ch = std::min(n_vec, RVQ_CHUNK);
         float* R = scratch;                  // [ch, D] residuals
@@ -288,12 +288,7 @@ int launch_rvq_search(const float* x, long long n_vec, const float* codebooks, c
     } else {
         const size_t lds = (size_t)(32 * (D + 4) + 32 + 4 * 32) * sizeof(float) + (4 * 32 + 32) * sizeof(int);
         QA_REQUIRE(lds <= 160 * 1024, "rvq_search: D=%d needs %zu B of LDS", D, lds);
-        static bool attr_set = false;
-        if (!attr_set) {
-            QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_search_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        QA_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(rvq_search_kernel), 160 * 1024));
         hipLaunchKernelGGL(rvq_search_kernel, dim3((unsigned)ceil_div(n_vec, 32)), dim3(256), lds, s, x, n_vec, codebooks,
                            e2, Q, K, D, indices);
         QA_LAUNCH_CHECK();

@@ -221,10 +221,7 @@ static size_t seanet_block_lds_bytes(int C) {
 }
 
 bool seanet_front_supported(int C, int hid, int L) {
-    static const bool on = [] {
-        const char* e = getenv("QA_SEANET_FUSED");
-        return !e || atoi(e) != 0;
-    }();
+    const bool on = knob(K_SEANET_FUSED) != 0;
     // L >= 8: both reflect pads stay in their plain regime (no zero extension of a short clip)
     return on && C == 32 && hid >= 1 && hid <= 32 && L >= 8;
 }
@@ -246,11 +243,7 @@ int launch_seanet_front(const float* wav, const float* w0, const float* b0, cons
     const size_t lds = seanet_block_lds_bytes(C);
     const long long n_tiles = (long long)B * ceil_div(L, 128);
     const unsigned grid = (unsigned)std::min<long long>(n_tiles, 512);  // persistent: two workgroups per CU, weights staged once each
-    static bool attr_set = false;
-    if (!attr_set) {
-        QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_block_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    QA_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(seanet_block_kernel<32>), (int)lds));
     hipLaunchKernelGGL((seanet_block_kernel<32>), dim3(grid), dim3(256), lds, s, p);
     QA_LAUNCH_CHECK();
     return QA_OK;

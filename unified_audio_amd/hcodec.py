@@ -200,7 +200,7 @@ class Codec(torch.nn.Module):
     def train(self, mode: bool = True):
         if mode:
             raise _lib.QuarkAudioError(-4, "unified_audio_amd.Codec is the inference path (the reference calls .eval(), audio_tokenizer.py:26)")
-        return self
+        return super().train(False)  # nn.Module bookkeeping: self.training = False, recursion into (no) children
 
     def to(self, *args, **kwargs):
         device = kwargs.get("device")
@@ -409,6 +409,8 @@ class HCodecTokenizer(torch.nn.Module):
             self.device = torch.device(device) if str(device) != "cpu" else torch.device("cuda:0")  # 2.0's default device='cpu': no CPU path
             self.model = Codec(None, None, None, spec=spec, device=self.device).load_state_dict(state_dict)
         self.feature_extractor = feature_extractor
+        if isinstance(feature_extractor, torch.nn.Module):
+            feature_extractor.eval()  # audio_tokenizer.py:28-29: the reference puts its SSL model in eval mode at construction
         self.sampling_rate = sampling_rate
         self.hop_length = spec.enc_hop  # 640 = 25 Hz (audio_tokenizer.py:31); 3840 = 12.5 Hz at 48 kHz (2.0 :46)
         # hidden states averaged by extract_wav2vec2_features when the extractor is the reference's own PyTorch module
@@ -423,7 +425,15 @@ class HCodecTokenizer(torch.nn.Module):
         return self
 
     def train(self, mode: bool = True):
-        self.model.train(mode)
+        """eval() must reach a PyTorch feature_extractor registered as a submodule (dropout / layerdrop of a HuBERT built in train
+        mode); train(True) is refused like Codec's."""
+        if mode:
+            raise _lib.QuarkAudioError(-4, "unified_audio_amd.HCodecTokenizer is the inference path (the reference calls .eval())")
+        return super().train(False)
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """The tokenizer's weights are the codec's (audio_tokenizer.py:24-25 loads them into self.model): forward to it."""
+        self.model.load_state_dict(state_dict)
         return self
 
     def resample(self, wavs: torch.Tensor) -> torch.Tensor:
