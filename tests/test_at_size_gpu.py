@@ -148,11 +148,14 @@ def test_persistent_lstm_forced_on_matches_per_step_and_torch(qa_lib, gpu_device
         torch.cuda.synchronize()
         outs[mode] = (codec.tap(name).clone(), wav.clone())
     assert torch.isfinite(outs[1][0]).all()
-    assert rel_err(outs[1][0], outs[0][0]) < 1e-5 and rel_err(outs[1][1], outs[0][1]) < 1e-5
+    ab = (rel_err(outs[1][0], outs[0][0]), rel_err(outs[1][1], outs[0][1]))
+    assert max(ab) < 1e-5, ab
     dtaps = {}
     with torch.no_grad():
         R.decode(sd, ac[:2], sc[:2], ospec, dtaps)
-    assert rel_err(outs[1][0].view(B, T, d)[:2], dtaps[name]) < STAGE_TOL
+    errs = (rel_err(outs[1][0].view(B, T, d)[:2], dtaps[name]), rel_err(outs[0][0].view(B, T, d)[:2], dtaps[name]),
+            rel_err(codec.tap("dec.prior_res1").view(B, T, d)[:2], dtaps["dec.prior_res1"].transpose(1, 2)))
+    assert errs[0] < STAGE_TOL, errs
 
 
 def test_persistent_lstm_barrier_timeout_is_recovered_in_the_same_call(qa_lib, gpu_device, knob, capfd):
@@ -219,11 +222,13 @@ def test_bicodec_published_16x5s_matches_oracle(qa_lib, gpu_device):
     from oracle import bicodec_ref as BR
 
     ospec = BR.SPEC_BICODEC
-    sd = synth.bicodec_state_dict(11, ospec)
+    from unified_audio_amd import synth as psynth  # BiCodec weight / token generators live on the product side only
+
+    sd = psynth.bicodec_state_dict(11, ospec)
     kw = {f: getattr(ospec, f) for f in ospec.__dataclass_fields__}
     bc = qa.BiCodec(qa.BiCodecSpec(**kw), device=gpu_device).load_state_dict(sd)
     B, S = 16, 250
-    sem, glob = synth.bicodec_tokens(12, B, S, ospec)
+    sem, glob = psynth.bicodec_tokens(12, B, S, ospec)
     got = bc.detokenize(sem.to(gpu_device), glob.to(gpu_device))
     torch.cuda.synchronize()
     assert got.shape == (B, 1, S * ospec.hop) and torch.isfinite(got).all()

@@ -10,6 +10,7 @@
 #   trace:NAME:CMD    rocprofv3 --kernel-trace --stats of CMD (lm | bench-lean | bench-serial | hc10 | hc20) -> NAME_kernel_stats.md
 #   pmc:NAME:CMD      three separate --pmc passes (FETCH_SIZE | WRITE_SIZE | MFMA busy) of CMD -> NAME_pmc_summary.{md,json}
 #   profiles          the round's standard evidence set (tools/collect_profiles.sh TAG)
+#   run:CMD           any shell command (log tail kept in run.log)
 #   smoke             __graft_entry__.smoke()
 TAG=${1:?tag}; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
@@ -32,7 +33,7 @@ for step in "$@"; do
     tests)
       sel=""; [ -n "$rest" ] && { case "$rest" in *.py*) sel="$rest" ;; *) sel="-k $rest" ;; esac; }
       case "$sel" in *.py*) tgt="$sel" ;; *) tgt="tests $sel" ;; esac
-      ( time timeout 1500 python -m pytest $tgt -q -m gpu -x 2>&1 | tail -25 ) 2>&1 | tee -a $O/tests.log ;;
+      ( time timeout 1500 python -m pytest $tgt -q -m gpu 2>&1 | tail -25 ) 2>&1 | tee -a $O/tests.log ;;
     bench)
       ( time timeout 900 python bench.py $rest > $O/bench.json 2> $O/bench.err ) 2>&1 | tail -3 | tee -a $O/session.log
       python - <<PY 2>&1 | tee -a $O/session.log
@@ -61,6 +62,7 @@ PY
         ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_${name}_$i -o b -- $(cmd_of $what) > $O/${name}_pmc$i.log 2>&1 )
       done
       python tools/pmc_summary.py $O/${name}_pmc_summary /tmp/pmc_${name}_1 /tmp/pmc_${name}_2 /tmp/pmc_${name}_3 2>&1 | tail -3 ;;
+    run) echo "$rest" >> $O/run.log; ( timeout 900 bash -c "$rest" 2>&1 | tail -${TAIL:-60} ) | tee -a $O/run.log ;;
     profiles) bash tools/collect_profiles.sh $TAG ;;
     smoke) ( time timeout 900 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -8 ) 2>&1 | tee -a $O/smoke.log ;;
     *) echo "unknown step $step" ;;

@@ -33,14 +33,21 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
                                                         long long ldkv, long long kv_bstride, float* __restrict__ out,
                                                         long long ldo, int n_q, int n_keys, float scale, int causal,
                                                         const float* __restrict__ gate, const float* __restrict__ relbias, int R,
-                                                        int context, int q_pos0, int ring_end) {
+                                                        int context, int q_pos0, int ring_end, int dbg) {
     constexpr int LD = HD + 4;
     constexpr int DT = HD / 32;
     constexpr int NG = HD / 8;
     __shared__ __attribute__((aligned(16))) float sK[32 * LD];
     __shared__ __attribute__((aligned(16))) float sV[32 * LD];
 
+    // `wave` through readfirstlane: every wave-level test below (tile skips, mask tests) is then a SCALAR branch.  As a VGPR value
+    // hipcc lowers them to exec-masked regions, and exec-masked VMEM next to register-staged prefetches is where ROCm 7.2 mis-tracks
+    // outstanding loads (see fetch()).
+#ifdef QA_ATT_OLD
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#else
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
     const int ql = lane & 31, hh = lane >> 5;
     const int b = blockIdx.z, head = blockIdx.y;
     const int q_blk0 = blockIdx.x * 128;
@@ -95,6 +102,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 
     // K / V tiles go global -> registers -> LDS; the loads of tile kt + 1 are issued right after tile kt is in LDS and stay in
     // flight under its 64 MFMAs (the first version loaded synchronously: one exposed L2 / HBM round trip per 32 keys)
+    // Rows past n_keys re-read the last valid row instead of being predicated off: their scores are masked to -inf below (need_mask
+    // is set on any tile that reaches n_keys) and their probability is exactly 0, so a finite stand-in row changes nothing - and
+    // every load of the kernel is UNCONDITIONAL.  The round-2 form (`if (key < n_keys) load; else zeros`) put the prefetch into an
+    // exec-masked region; with it hipcc (ROCm 7.2) re-used the staging registers while the loads were still in flight for
+    // HD = 64 at n_keys = 1500: half of all outputs differed from run to run (tools/diag_attention.py on the -DQA_ATT_OLD build,
+    // profiles/r03_attention_determinism.txt).  Caught by the at-size parity test of H-Codec 2.0 (tests/test_at_size_gpu.py).
     constexpr int NLD = HD / 32;  // float4 per thread per operand: 32 keys x HD floats over 256 threads
     float4 kreg[NLD], vreg[NLD];
     auto fetch = [&](int kt) {
@@ -102,13 +115,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         for (int j = 0; j < NLD; ++j) {
             const int i = tid + 256 * j;
             const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
+#ifdef QA_ATT_OLD  // diagnostic build only (tools/variants.py): the round-2 predicated prefetch
             const int key = kt * 32 + row;
             kreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             vreg[j] = kreg[j];
-            if (key < n_keys) {  // zero-filled past n_keys
+            if (key < n_keys) {
                 kreg[j] = *reinterpret_cast<const float4*>(kb + (long long)key * ldkv + c4);
                 vreg[j] = *reinterpret_cast<const float4*>(vb + (long long)key * ldkv + c4);
             }
+#else
+            const int key = min(kt * 32 + row, n_keys - 1);
+            kreg[j] = *reinterpret_cast<const float4*>(kb + (long long)key * ldkv + c4);
+            vreg[j] = *reinterpret_cast<const float4*>(vb + (long long)key * ldkv + c4);
+#endif
         }
     };
     fetch(kt0);
@@ -123,9 +142,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         }
         __syncthreads();
         if (kt + 1 < n_tiles) fetch(kt + 1);
+        if (dbg & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // wave-uniform skips: the whole tile is masked for this wave, or the wave owns no query at all (the last query block of a
         // sequence that is not a multiple of 128: at N = 283 three of the four waves of block 3 would multiply clamped rows)
+#ifdef QA_ATT_OLD  // diagnostic build: the round-2 form of the two wave-level tests (tools/variants.py)
         if (kt * 32 > wave_last_key || kt * 32 + 31 < wave_first_key || q_blk0 + wave * 32 >= n_q) continue;
+#else
+        if (!(dbg & 8) && (kt * 32 > wave_last_key || kt * 32 + 31 < wave_first_key || q_blk0 + wave * 32 >= n_q)) continue;
+#endif
 
         // S^T = K Q^T
         f32x16 s;
@@ -143,7 +167,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         // online softmax in base 2 (per lane = per query; the two halves of the wave hold interleaved key groups).  Masks are
         // evaluated only on tiles that can contain a hidden key for some query of this wave (wave-uniform test).
         const int q_first = q_blk0 + wave * 32, q_last = q_first + 31;
+#ifdef QA_ATT_OLD
         const bool need_mask = ring || kt * 32 + 31 >= n_keys ||
+#else
+        const bool need_mask = (dbg & 16) || ring || kt * 32 + 31 >= n_keys ||
+#endif
                                (lin_causal && (kt * 32 + 31 > q_first + off || (context > 0 && kt * 32 < q_last + off - context + 1)));
         float tmax = -INFINITY;
         if (BIAS || need_mask) {
@@ -179,7 +207,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * alpha + psum;
         m_run = m_new;
-        if (__any(alpha != 1.f)) {  // the running maximum moved for some query of the wave: rescale (rare after the first tiles)
+        if ((dbg & 1) || __any(alpha != 1.f)) {  // the running maximum moved for some query of the wave: rescale (rare after the first tiles)
 #pragma unroll
             for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -193,6 +221,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
             for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * t], s[st], o[t], 0, 0, 0);
         }
+        if (dbg & 2) __syncthreads();
     }
 
     if (qi < n_q) {
@@ -225,13 +254,14 @@ int launch_attention(const float* q, long long ldq, const float* k, const float*
     QA_REQUIRE((gate == nullptr) == (relbias == nullptr) && (!gate || (R >= 0 && !causal && n_q == n_keys)),
                "attention: gate and relbias come together, for non-causal self-attention");
     dim3 grid((unsigned)ceil_div(n_q, 128), H, B);
+    const int dbg = (int)knob(K_ATT_DEBUG);
 #define QA_ATT(HD)                                                                                                          \
     if (gate)                                                                                                                \
         hipLaunchKernelGGL((attention_kernel<HD, true>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, \
-                           n_keys, scale, causal, gate, relbias, R, context, q_pos0, ring_end);                             \
+                           n_keys, scale, causal, gate, relbias, R, context, q_pos0, ring_end, dbg);                             \
     else                                                                                                                     \
         hipLaunchKernelGGL((attention_kernel<HD, false>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, \
-                           n_keys, scale, causal, nullptr, nullptr, 0, context, q_pos0, ring_end)
+                           n_keys, scale, causal, nullptr, nullptr, 0, context, q_pos0, ring_end, dbg)
     switch (hd) {
         case 32: QA_ATT(32); break;
         case 64: QA_ATT(64); break;
@@ -245,3 +275,10 @@ int launch_attention(const float* q, long long ldq, const float* k, const float*
 }
 
 }  // namespace qa
+
+// test / diagnostic hook (not part of the public header): the attention kernel alone on caller-provided buffers
+extern "C" int qa_debug_attention(const float* q, long long ldq, const float* k, const float* v, long long ldkv, float* out, long long ldo,
+                                  int B, int n_q, int n_keys, long long kv_bstride, int H, int hd, float scale, int causal, void* stream) {
+    return qa::launch_attention(q, ldq, k, v, ldkv, out, ldo, B, n_q, n_keys, kv_bstride, H, hd, scale, causal,
+                                static_cast<hipStream_t>(stream));
+}

@@ -403,24 +403,29 @@ int transformer_op(Ctx& c, const TransformerW& tw, float* x, int B, int N, const
     float* qkv = c.arena.alloc<float>(rows * 3 * d);
     float* att = c.arena.alloc<float>(rows * d);
     float* cst = c.arena.alloc<float>((size_t)B * d);
+    // taps allocate from the arena: they are issued in the planning pass too (RUN skips only the launches there)
+#define RUN(expr) do { if (!c.dry) QA_TRY(expr); } while (0)
     for (size_t l = 0; l < tw.layers.size(); ++l) {
         const TransformerLayerW& L = tw.layers[l];
-        if (!c.dry) {
-            QA_TRY(launch_rmsnorm(x, L.ln1, hn, rows, d, 1e-6f, c.stream));
-            QA_TRY(linear_op(c, hn, rows, L.ih, big));
-            QA_TRY(launch_lstm(big, L.w_hh, hl, cst, B, N, d, c.stream));
-            c.tap(tap_prefix + ".layers." + std::to_string(l) + ".self_attn.rnn", hl, rows * d);
-            QA_TRY(linear_op(c, hl, rows, L.qkv, qkv));
-            QA_TRY(launch_rope(qkv, tw.rope, B, N, H, hd, 3 * d, 0, c.stream));
-            QA_TRY(launch_attention(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, B, N, N, (long long)N * 3 * d, H, hd,
-                                    1.0f / std::sqrt((float)hd), causal ? 1 : 0, c.stream));
-            QA_TRY(linear_op(c, att, rows, L.o, x, ACT_NONE, x));
-            QA_TRY(launch_rmsnorm(x, L.ln2, hn, rows, d, 1e-6f, c.stream));
-            QA_TRY(linear_op(c, hn, rows, L.w1, big));
-            QA_TRY(linear_op(c, hn, rows, L.w3, big2, ACT_NONE, nullptr, big));
-            QA_TRY(linear_op(c, big2, rows, L.w2, x, ACT_NONE, x));
-        }
+        const std::string lp = tap_prefix + ".layers." + std::to_string(l);
+        RUN(launch_rmsnorm(x, L.ln1, hn, rows, d, 1e-6f, c.stream));
+        RUN(linear_op(c, hn, rows, L.ih, big));
+        RUN(launch_lstm(big, L.w_hh, hl, cst, B, N, d, c.stream));
+        c.tap(lp + ".self_attn.rnn", hl, rows * d);
+        RUN(linear_op(c, hl, rows, L.qkv, qkv));
+        RUN(launch_rope(qkv, tw.rope, B, N, H, hd, 3 * d, 0, c.stream));
+        RUN(launch_attention(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, B, N, N, (long long)N * 3 * d, H, hd,
+                             1.0f / std::sqrt((float)hd), causal ? 1 : 0, c.stream));
+        c.tap(lp + ".att", att, rows * d);
+        RUN(linear_op(c, att, rows, L.o, x, ACT_NONE, x));
+        c.tap(lp + ".x_attn", x, rows * d);
+        RUN(launch_rmsnorm(x, L.ln2, hn, rows, d, 1e-6f, c.stream));
+        RUN(linear_op(c, hn, rows, L.w1, big));
+        RUN(linear_op(c, hn, rows, L.w3, big2, ACT_NONE, nullptr, big));
+        RUN(linear_op(c, big2, rows, L.w2, x, ACT_NONE, x));
+        c.tap(lp + ".x_mlp", x, rows * d);
     }
+#undef RUN
     c.arena.release(mark);
     return QA_OK;
 }

@@ -76,6 +76,7 @@ class Arena {
         cap_ = cap;
         off_ = 0;
         peak_ = 0;
+        floor_ = 0;
     }
     template <typename T>
     T* alloc(size_t n) {
@@ -86,13 +87,15 @@ class Arena {
         return base_ ? reinterpret_cast<T*>(base_ + at) : reinterpret_cast<T*>(uintptr_t(4096) + at);
     }
     size_t mark() const { return off_; }
-    void release(size_t m) { off_ = m; }
+    void release(size_t m) { off_ = m > floor_ ? m : floor_; }
+    // everything allocated so far survives later release() calls (test taps snapshot buffers inside a mark / release region)
+    void pin() { floor_ = off_; }
     size_t peak() const { return peak_; }
     bool planning() const { return base_ == nullptr; }
 
    private:
     char* base_ = nullptr;
-    size_t cap_ = 0, off_ = 0, peak_ = 0;
+    size_t cap_ = 0, off_ = 0, peak_ = 0, floor_ = 0;
 };
 
 struct Tap {
@@ -109,6 +112,7 @@ struct Ctx {
     void tap(const std::string& name, const float* p, int64_t n) {
         if (!capture) return;
         float* copy = arena.alloc<float>((size_t)n);
+        arena.pin();  // the snapshot must outlive the mark / release region it was taken in
         if (dry) return;
         (void)hipMemcpyAsync(copy, p, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, stream);
         taps[name] = Tap{copy, n};

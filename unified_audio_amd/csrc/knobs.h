@@ -17,6 +17,7 @@ namespace qa {
     X(GEMM_LINEAR, "QA_GEMM_LINEAR", 1, "table-free K loop for ksize-1 layers")                                                  \
     X(GEMM_XCD, "QA_GEMM_XCD", 1, "XCD-aware tile order")                                                                        \
     X(GEMM_GROUPED, "QA_GEMM_GROUPED", 1, "H-Codec 1.5: the two aggregator stacks as ONE grouped launch per layer op (0: two streams)") \
+    X(ATT_DEBUG, "QA_ATT_DEBUG", 0, "attention_kernel debug bits: 1 always rescale, 2 extra barrier per tile, 4 wait for the prefetch at once") \
     X(SEANET_FUSED, "QA_SEANET_FUSED", 1, "fused conv0 + first SEANet residual block")                                           \
     X(MIMI_ROPE_WINDOW, "QA_MIMI_ROPE_WINDOW", 8192, "mimi streaming: positions covered by the RoPE table before the rolling window takes over (tests shrink it)") \
     X(RVQ_LEGACY, "QA_RVQ_LEGACY", 0, "1: the single-launch RVQ search kernel instead of distance GEMM + pick")                   \
