@@ -250,6 +250,27 @@ def lm_bench(dev, rank, world, dist, batch, reps=2, task="se", n_enroll=0):
         short = min(short, time.perf_counter() - t0)
     ms_decode = 1e3 * (best - short) / (283 - 2)
     ms_prefill = 1e3 * short - 2 * ms_decode
+    # the prefill's dense GEMMs (adapter + 12 layers of QKV / O / SwiGLU over B x prompt rows) against the fp32 matrix peak - north_star's
+    # "MFMA utilisation for the LM GEMMs": per-launch HIP events inside the library around a generate of 1 + 0 tokens
+    import ctypes as C
+
+    lib = qa.load_library()
+    mel0 = torch.zeros(batch, 0, 80)
+    lib.qa_profile_begin()
+    lm.generate(task, mel0 if enr is not None else None, enr, mel0, mix, global_length=0, do_sample=False)
+    torch.cuda.synchronize(dev)
+    prof = (C.c_double * 12)()
+    lib.qa_profile_end(prof, 12)
+    g_flop = sum(prof[4 * i] for i in range(3))
+    g_ms = sum(prof[4 * i + 1] for i in range(3))
+    g_n = int(sum(prof[4 * i + 2] for i in range(3)))
+    prefill = {"ms": ms_prefill, "rows": batch * (2 + 250 + (1 + n_enroll if n_enroll else 0)),
+               "roofline": {"bound": "mfma", "achieved": g_flop / (g_ms * 1e-3) / 1e12 if g_ms else None, "peak": MFMA_F32_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": g_flop / (g_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if g_ms else None,
+                            "gemm_launches": g_n, "gemm_ms": g_ms, "gemm_flop": g_flop,
+                            "whole_prefill_tflops": g_flop / (ms_prefill * 1e-3) / 1e12 if ms_prefill > 0 else None,
+                            "note": "all conv_gemm launches of the prefill (HIP events on the launch stream, qa_profile_begin/end); "
+                                    "whole_prefill_tflops divides the same FLOPs by the prefill wall time (attention, norms, RoPE / cache append included)"}}
     # algorithmic HBM bytes of one decode step: 12 layers x (qkv 3 d^2 + o d^2 + gate/up 2 d I + down d I) fp32 weights + the active
     # output_head slice, and K + V of every cached position of every sequence (fp32); averaged over the 283 steps
     d, inter, layers, prompt = 512, 2048, 12, 2 + 250 + (1 + n_enroll if n_enroll else 0)
@@ -260,7 +281,8 @@ def lm_bench(dev, rank, world, dist, batch, reps=2, task="se", n_enroll=0):
     ms_step = 1e3 * best / 283
     return {"metric": "UniSE AR tokens/sec (greedy generate, prefill included)", "value": world * batch * 283 / best,
             "unit": "tokens/sec", "ms_per_generate": 1e3 * best, "ms_per_decode_step_incl_prefill": ms_step,
-            "ms_prefill": ms_prefill, "ms_per_decode_step": ms_decode,
+            "ms_prefill": ms_prefill, "ms_per_decode_step": ms_decode, "prefill": prefill,
+            "chains": max(1, -(-batch // 32)),
             "roofline": {"bound": "hbm", "achieved": step_bytes / (ms_step * 1e-3) / 1e12, "peak": HBM_PEAK_TBS, "unit": "TB/s",
                          "frac": step_bytes / (ms_step * 1e-3) / 1e12 / HBM_PEAK_TBS,
                          "bytes_per_step": {"weights": w_body + w_head, "kv_cache_mean": kv},
@@ -496,6 +518,13 @@ def main():
             extras["unise_lm_tse_b8"] = lm_bench(dev, rank, world, None, 8, reps=1, task="tse", n_enroll=250)
         except Exception as e:  # noqa: BLE001
             extras["unise_lm_tse_b8"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        try:
+            # BASELINE configs[3] on ONE GPU is 64 segments: batches above 32 run as concurrent chains of 32 (csrc/lm.cpp)
+            log("UniSE LM at 64 segments per GPU (2 concurrent chains): SE and TSE ...")
+            extras["unise_lm_b64"] = lm_bench(dev, rank, world, None, 64, reps=1)
+            extras["unise_lm_tse_b64"] = lm_bench(dev, rank, world, None, 64, reps=1, task="tse", n_enroll=250)
+        except Exception as e:  # noqa: BLE001
+            extras["unise_lm_b64"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
 
     if rank == 0 and world == 1 and not args.lean and not args.no_extras and args.model == "1.5":
         try:

@@ -253,3 +253,62 @@ def test_generate_do_sample_default_runs_and_is_seeded(qa_lib, gpu_device):
     gg, sg = lm.generate("se", None, None, mel, mix, global_length=G, do_sample=False)
     gk, sk = lm.generate("se", None, None, mel, mix, global_length=G, top_k=1)
     assert torch.equal(gg, gk) and torch.equal(sg, sk)
+
+
+# ------------------------------------------------------------------------------------------- B > 32: concurrent chains
+
+def test_batches_above_32_run_as_concurrent_chains(qa_lib, gpu_device, knob):
+    """B > 32 (BASELINE configs[3] on ONE GPU is 64 segments): ceil(B / 32) chains on internal streams, each replaying its own
+    captured step.  Every sequence must produce what it produces alone, the whole batch must pass the oracle audit, and forcing
+    another chain count (QA_LM_CHAINS) must not change a token."""
+    spec = SMALL
+    sd, lm = _model(spec, 21, gpu_device)
+    B, Nm, Ne, S, G = 40, 6, 5, 9, 3
+    mix = L.synth_feats(5, B, Nm, spec.feats_dim)
+    enr = L.synth_feats(6, B, Ne, spec.feats_dim)
+    mel = torch.zeros(B, S, 80)
+    g, s = lm.generate("tse", mel, enr.to(gpu_device), mel, mix.to(gpu_device), global_length=G, do_sample=False)
+    torch.cuda.synchronize()
+    assert g.shape == (B, G) and s.shape == (B, S)
+    _audit(sd, spec, "tse", enr, mix, S, G, g.cpu(), s.cpu())
+    for i in (0, 19, 20, 39):
+        g1, s1 = lm.generate("tse", mel[i:i + 1], enr[i:i + 1].to(gpu_device), mel[i:i + 1], mix[i:i + 1].to(gpu_device), global_length=G,
+                             do_sample=False)
+        assert torch.equal(g1[0], g[i]) and torch.equal(s1[0], s[i]), i
+    for chains in (1, 4, 40):  # 1: one chain of 40 does not tile the fused step -> the per-op path; 40: one sequence per chain is capped at 16 chains
+        knob("QA_LM_CHAINS", chains)
+        g2, s2 = lm.generate("tse", mel, enr.to(gpu_device), mel, mix.to(gpu_device), global_length=G, do_sample=False)
+        assert torch.equal(g2, g) and torch.equal(s2, s), chains
+    knob("QA_LM_CHAINS", 0)
+    g3, s3 = lm.generate("tse", mel, enr.to(gpu_device), mel, mix.to(gpu_device), global_length=G, do_sample=False)  # cached graphs re-used
+    assert torch.equal(g3, g) and torch.equal(s3, s)
+
+
+def test_chains_full_width_b64_matches_b16_chunks(qa_lib, gpu_device):
+    """Full UniSE width, 64 segments (2 chains x 32): every 16-sequence chunk of the call equals the same chunk generated alone."""
+    spec = L.SPEC_UNISE
+    _, lm = _model(spec, 33, gpu_device)
+    B, Nm, S = 64, 40, 24
+    mix = L.synth_feats(9, B, Nm).to(gpu_device)
+    mel = torch.zeros(B, S, 80)
+    g, s = lm.generate("se", None, None, mel, mix, do_sample=False)
+    for b0 in (0, 16, 48):
+        g1, s1 = lm.generate("se", None, None, mel[b0:b0 + 16], mix[b0:b0 + 16], do_sample=False)
+        assert torch.equal(g1, g[b0:b0 + 16]) and torch.equal(s1, s[b0:b0 + 16]), b0
+
+
+def test_sampled_chains_key_the_rng_by_the_global_sequence_index(qa_lib, gpu_device, knob):
+    """The device sampler's Philox stream is keyed by (seed, sequence index IN THE CALL, step): splitting a call into chains must not
+    change a draw."""
+    sd, lm = _model(SMALL, 21, gpu_device)
+    B, Nm, S, G = 36, 5, 10, 4
+    mix = L.synth_feats(3, B, Nm, SMALL.feats_dim).to(gpu_device)
+    mel = torch.zeros(B, S, 80)
+    outs = []
+    for chains in (0, 3, 6):
+        knob("QA_LM_CHAINS", chains)
+        torch.manual_seed(11)
+        outs.append(lm.generate("se", None, None, mel, mix, global_length=G))
+    for g, s in outs[1:]:
+        assert torch.equal(g, outs[0][0]) and torch.equal(s, outs[0][1])
+    assert outs[0][1][0].tolist() != outs[0][1][33].tolist() or outs[0][0][0].tolist() != outs[0][0][33].tolist()

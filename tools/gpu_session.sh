@@ -18,7 +18,7 @@ cd $R
 cmd_of() {
   case "$1" in
     lm) echo "python $R/tools/lm_bench.py 16 2" ;;
-    lm-tse) echo "python $R/tools/lm_bench.py 8 2 tse" ;;
+    lm-short) echo "python $R/tools/lm_bench.py 16 1 24" ;;
     bench-lean) echo "python $R/bench.py --steps 3 --warmup 1 --lean" ;;
     bench-serial) echo "env QA_SERIAL=1 python $R/bench.py --steps 3 --warmup 1 --lean" ;;
     hc10) echo "python $R/bench.py --steps 5 --warmup 2 --lean --model 1.0" ;;

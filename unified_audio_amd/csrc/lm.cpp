@@ -47,6 +47,7 @@ struct LMLayer {
     const float* gu_dec = nullptr;
 };
 constexpr int LM_MAX_POS = 4096;  // max_position_embeddings (conf/config.yaml:146)
+constexpr int LM_MAX_CHAINS = 16;
 }  // namespace
 
 struct StepGraph {  // one captured decode step of a phase, replayable because every loop-carried scalar lives in device state
@@ -68,7 +69,10 @@ struct qa_lm {
     bool fused_ok = false;   // the shapes fit the fused decode step (otherwise the per-op decode path runs)
     int nt_qkv = 0, nt_o = 0, nt_gu = 0, nt_down = 0;
     hipStream_t cap_stream = nullptr;
-    StepGraph graphs[2];     // [0] global phase, [1] semantic phase
+    std::vector<StepGraph> graphs;  // [2 * chain + phase]: phase 0 global, 1 semantic
+    std::vector<hipStream_t> chain_streams;  // internal streams of the chains of a B > 32 call
+    std::vector<hipEvent_t> chain_join;
+    hipEvent_t ev_fork = nullptr;
     unsigned long long calls = 0;
     WeightStore store;
     const float *task_emb = nullptr, *enroll_sos = nullptr, *mix_sos = nullptr, *codec_emb = nullptr, *ones = nullptr,
@@ -380,17 +384,19 @@ uint64_t mix_key(uint64_t h, uint64_t v) {
 // device memory - one more dependent load per kernel - and cannot size the attention grid to the current key count: off by default.
 bool use_graphs() { return knob(K_LM_GRAPH) != 0; }
 
-int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, const float* mix, int Nm, int B, int G,
-                   int S, long long* gids, long long* sids, const SampleCfg& sc) {
-    const qa_lm_spec& sp = lm->spec;
-    const int d = sp.hidden, I = sp.intermediate, H = sp.n_heads;
-    const int L = 1 + (enroll ? 1 + Ne : 0) + 1 + Nm;
-    const int max_len = L + G + 1 + S;
-    QA_REQUIRE(max_len <= LM_MAX_POS, "generate: %d positions exceed max_position_embeddings %d", max_len, LM_MAX_POS);
-    const int cap = (int)round_up(max_len, 64);  // cache row stride: shapes that round alike share their captured step graphs
-    const bool fused = lm->fused_ok && B <= 32 && head_nt(sp.global_size) && head_nt(sp.semantic_size);
-    const int64_t prow = (int64_t)B * L;
+// One chain = one batch of <= 32 sequences with its own buffers, KV cache and (for B > 32, or QA_LM_CHAINS) its own internal stream.
+struct Chain {
+    int b0 = 0, B = 0;  // sequences [b0, b0 + B) of the call
     LMBuffers b{};
+    float *emix = nullptr, *eenr = nullptr;
+    hipStream_t s = nullptr;
+};
+
+int chain_alloc(qa_lm* lm, Ctx& c, Chain& ch, int L, int cap, int G, int S, int Nm, int Ne, bool enroll) {
+    const qa_lm_spec& sp = lm->spec;
+    const int d = sp.hidden, I = sp.intermediate, H = sp.n_heads, B = ch.B;
+    const int64_t prow = (int64_t)B * L;
+    LMBuffers& b = ch.b;
     b.cap = cap;
     b.S_att = std::max(1, std::min(4, (int)ceil_div(cap, 256)));  // captured steps: sized for the cache capacity
     b.x = c.arena.alloc<float>(prow * d);
@@ -411,35 +417,97 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
     b.state = c.arena.alloc<int>(ST_WORDS);
     b.ids_g = c.arena.alloc<long long>((size_t)B * std::max(G, 1));
     b.ids_s = c.arena.alloc<long long>((size_t)B * std::max(S, 1));
-    float* emix = c.arena.alloc<float>((size_t)B * Nm * d);
-    float* eenr = enroll ? c.arena.alloc<float>((size_t)B * Ne * d) : nullptr;
-    if (c.dry) return QA_OK;
+    ch.emix = c.arena.alloc<float>((size_t)B * Nm * d);
+    ch.eenr = enroll ? c.arena.alloc<float>((size_t)B * Ne * d) : nullptr;
+    return QA_OK;
+}
 
-    // ---- prompt (llm_sft.py:110-128) and prefill (llm_sft.py:130-135)
-    QA_TRY(lm_linear(c, mix, (int64_t)B * Nm, lm->adapter, emix));
-    if (enroll) QA_TRY(lm_linear(c, enroll, (int64_t)B * Ne, lm->adapter, eenr));
-    QA_TRY(launch_assemble_prompt(b.x, lm->task_emb + (size_t)task * d, enroll ? lm->enroll_sos : nullptr, eenr, lm->mix_sos,
-                                  emix, B, Ne, Nm, d, c.stream));
-    QA_TRY(lm_body(lm, c, b, B, L, 0, cap, true));
+// Batches of more than 32 sequences (the fused step's GEMVs hold at most two 16-row tiles) run as ceil(B / 32) independent CHAINS
+// on internal streams: a decode step is bound by the latency of its ~62 dependent launches and leaves the device almost idle
+// (DESIGN.md section 11), so chains overlap nearly for free - tokens/s scales with the number of chains until the CUs fill.  Every
+// chain replays ONE captured step per token (hipGraph), round-robin over the chains, so the host issues two graph launches per
+// step instead of 124 kernel launches (eager launches go host-bound below ~3 us per kernel).  QA_LM_CHAINS forces a chain count.
+int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, const float* mix, int Nm, int B, int G,
+                   int S, long long* gids, long long* sids, const SampleCfg& sc) {
+    const qa_lm_spec& sp = lm->spec;
+    const int d = sp.hidden;
+    const int L = 1 + (enroll ? 1 + Ne : 0) + 1 + Nm;
+    const int max_len = L + G + 1 + S;
+    QA_REQUIRE(max_len <= LM_MAX_POS, "generate: %d positions exceed max_position_embeddings %d", max_len, LM_MAX_POS);
+    const int cap = (int)round_up(max_len, 64);  // cache row stride: shapes that round alike share their captured step graphs
+    const bool tiles = lm->fused_ok && head_nt(sp.global_size) && head_nt(sp.semantic_size);
+    int nc = (int)knob(K_LM_CHAINS);
+    if (nc <= 0) nc = tiles ? (int)ceil_div(B, 32) : 1;
+    nc = std::max(1, std::min(std::min(nc, B), LM_MAX_CHAINS));
+    const int cb = (int)ceil_div(B, nc);
+    nc = (int)ceil_div(B, cb);
+    const bool fused = tiles && cb <= 32;
+    std::vector<Chain> chains(nc);
+    for (int i = 0; i < nc; ++i) {
+        chains[i].b0 = i * cb;
+        chains[i].B = std::min(cb, B - i * cb);
+        QA_TRY(chain_alloc(lm, c, chains[i], L, cap, G, S, Nm, Ne, enroll != nullptr));
+    }
+    if (c.dry) return QA_OK;
+    const bool multi = nc > 1;
+    if (multi) {  // fork: the chains' streams start behind everything already queued on the caller's stream
+        while ((int)lm->chain_streams.size() < nc) {
+            hipStream_t st = nullptr;
+            hipEvent_t ev = nullptr;
+            QA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            QA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            lm->chain_streams.push_back(st);
+            lm->chain_join.push_back(ev);
+        }
+        if (!lm->ev_fork) QA_HIP(hipEventCreateWithFlags(&lm->ev_fork, hipEventDisableTiming));
+        QA_HIP(hipEventRecord(lm->ev_fork, c.stream));
+        for (int i = 0; i < nc; ++i) {
+            chains[i].s = lm->chain_streams[i];
+            QA_HIP(hipStreamWaitEvent(chains[i].s, lm->ev_fork, 0));
+        }
+    } else {
+        chains[0].s = c.stream;
+    }
+    hipStream_t caller = c.stream;
+
+    // ---- prompt (llm_sft.py:110-128) and prefill (llm_sft.py:130-135), chain by chain (these launches fill the device by themselves)
+    for (Chain& ch : chains) {
+        c.stream = ch.s;
+        const float* mix_c = mix + (size_t)ch.b0 * Nm * sp.feats_dim;
+        const float* enr_c = enroll ? enroll + (size_t)ch.b0 * Ne * sp.feats_dim : nullptr;
+        int st = lm_linear(c, mix_c, (int64_t)ch.B * Nm, lm->adapter, ch.emix);
+        if (st == QA_OK && enroll) st = lm_linear(c, enr_c, (int64_t)ch.B * Ne, lm->adapter, ch.eenr);
+        if (st == QA_OK)
+            st = launch_assemble_prompt(ch.b.x, lm->task_emb + (size_t)task * d, enroll ? lm->enroll_sos : nullptr, ch.eenr, lm->mix_sos,
+                                        ch.emix, ch.B, Ne, Nm, d, ch.s);
+        if (st == QA_OK) st = lm_body(lm, c, ch.b, ch.B, L, 0, cap, true);
+        c.stream = caller;
+        QA_TRY(st);
+    }
 
     // ---- decode: G+1 global tokens (the last is fed to the cache but discarded), then S semantic tokens
     int pos = L;
-    const bool graphs = fused && use_graphs();
-    auto phase = [&](int which, long long first_id, int steps, int lo, int width, long long* ids, int ids_ld, int keep) -> int {
-        QA_TRY(launch_lm_phase_init(b.tok, first_id, B, b.state, pos, which == 0, sc.seed, c.stream));
-        if (fused) {
-            if (graphs && steps > 0) {
-                StepGraph& g = lm->graphs[which];
+    const bool graphs = fused && (multi || use_graphs());
+    auto phase = [&](int which, long long first_id, int steps, int lo, int width, int keep) -> int {
+        const int ids_ld = keep;
+        for (Chain& ch : chains)
+            QA_TRY(launch_lm_phase_init(ch.b.tok, first_id, ch.B, ch.b.state, pos, which == 0, sc.seed, ch.b0, ch.s));
+        if (fused && graphs && steps > 0) {
+            if ((int)lm->graphs.size() < 2 * nc) lm->graphs.resize(2 * nc);
+            for (int i = 0; i < nc; ++i) {
+                Chain& ch = chains[i];
+                long long* ids = which == 0 ? ch.b.ids_g : ch.b.ids_s;
+                StepGraph& g = lm->graphs[2 * i + which];
                 uint64_t key = 0x51ull;
-                for (uint64_t v : {(uint64_t)(uintptr_t)lm->ws, (uint64_t)B, (uint64_t)cap, (uint64_t)L, (uint64_t)G, (uint64_t)S,
-                                   (uint64_t)Ne, (uint64_t)lo, (uint64_t)width, (uint64_t)keep, (uint64_t)sc.do_sample,
+                for (uint64_t v : {(uint64_t)(uintptr_t)lm->ws, (uint64_t)B, (uint64_t)nc, (uint64_t)ch.b0, (uint64_t)ch.B, (uint64_t)cap, (uint64_t)L,
+                                   (uint64_t)G, (uint64_t)S, (uint64_t)Ne, (uint64_t)lo, (uint64_t)width, (uint64_t)keep, (uint64_t)sc.do_sample,
                                    (uint64_t)sc.top_k, (uint64_t)(sc.top_p * 1e6f), (uint64_t)(sc.temperature * 1e6f)})
                     key = mix_key(key, v);
                 if (!g.exec || g.key != key) {
                     g.reset();
                     if (!lm->cap_stream) QA_HIP(hipStreamCreateWithFlags(&lm->cap_stream, hipStreamNonBlocking));
                     QA_HIP(hipStreamBeginCapture(lm->cap_stream, hipStreamCaptureModeThreadLocal));
-                    const int st = fused_step(lm, b, B, lo, width, ids, ids_ld, keep, sc, lm->cap_stream, -1, -1);
+                    const int st = fused_step(lm, ch.b, ch.B, lo, width, ids, ids_ld, keep, sc, lm->cap_stream, -1, -1);
                     hipGraph_t graph = nullptr;
                     const hipError_t e = hipStreamEndCapture(lm->cap_stream, &graph);
                     if (st != QA_OK) {
@@ -451,36 +519,62 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
                     QA_HIP(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
                     g.key = key;
                 }
-                for (int st = 0; st < steps; ++st) QA_HIP(hipGraphLaunch(g.exec, c.stream));
-            } else {
-                for (int st = 0; st < steps; ++st) QA_TRY(fused_step(lm, b, B, lo, width, ids, ids_ld, keep, sc, c.stream, pos + st, st));
             }
+            for (int st = 0; st < steps; ++st)  // round-robin: every chain advances one token per turn
+                for (int i = 0; i < nc; ++i) QA_HIP(hipGraphLaunch(lm->graphs[2 * i + which].exec, chains[i].s));
             pos += steps;
             return QA_OK;
         }
-        for (int st = 0; st < steps; ++st, ++pos) {  // per-op fallback for shapes the fused step does not tile
-            QA_TRY(launch_embed(b.tok, lm->codec_emb, b.x, B, d, c.stream));
-            QA_TRY(lm_body(lm, c, b, B, 1, pos, cap, false));
-            if (skinny_ok(B, lm->head)) {
-                QA_TRY(lm_linear(c, b.x, B, lm->head, b.logits, nullptr, nullptr, width, lm->head.w + (size_t)lo * d, sp.rms_eps));
-            } else {
-                QA_TRY(launch_rmsnorm(b.x, lm->ones, b.hn, B, d, sp.rms_eps, c.stream));
-                QA_TRY(lm_linear(c, b.hn, B, lm->head, b.logits, nullptr, nullptr, width, lm->head.w + (size_t)lo * d));
-            }
-            if (sc.do_sample) {
-                QA_TRY(launch_lm_sample(b.logits, width, width, B, lo, sc.top_k, sc.top_p, sc.temperature, 1, b.tok, ids, ids_ld, keep,
-                                        b.state, c.stream));
-                QA_TRY(launch_lm_advance(b.state, c.stream));
-            } else {
-                QA_TRY(launch_argmax(b.logits, B, width, width, lo, b.tok, st < keep ? ids : nullptr, ids_ld, st, c.stream));
+        if (fused) {
+            for (int st = 0; st < steps; ++st)
+                for (Chain& ch : chains)
+                    QA_TRY(fused_step(lm, ch.b, ch.B, lo, width, which == 0 ? ch.b.ids_g : ch.b.ids_s, ids_ld, keep, sc, ch.s, pos + st, st));
+            pos += steps;
+            return QA_OK;
+        }
+        for (int st = 0; st < steps; ++st, ++pos) {  // per-op decode step (QA_LM_UNFUSED, or a spec the fused step does not tile)
+            for (Chain& ch : chains) {
+                LMBuffers& b = ch.b;
+                long long* ids = which == 0 ? b.ids_g : b.ids_s;
+                c.stream = ch.s;
+                int rc = launch_embed(b.tok, lm->codec_emb, b.x, ch.B, d, ch.s);
+                if (rc == QA_OK) rc = lm_body(lm, c, b, ch.B, 1, pos, cap, false);
+                if (rc == QA_OK) {
+                    if (skinny_ok(ch.B, lm->head)) {
+                        rc = lm_linear(c, b.x, ch.B, lm->head, b.logits, nullptr, nullptr, width, lm->head.w + (size_t)lo * d, sp.rms_eps);
+                    } else {
+                        rc = launch_rmsnorm(b.x, lm->ones, b.hn, ch.B, d, sp.rms_eps, ch.s);
+                        if (rc == QA_OK) rc = lm_linear(c, b.hn, ch.B, lm->head, b.logits, nullptr, nullptr, width, lm->head.w + (size_t)lo * d);
+                    }
+                }
+                if (rc == QA_OK) {
+                    if (sc.do_sample) {
+                        rc = launch_lm_sample(b.logits, width, width, ch.B, lo, sc.top_k, sc.top_p, sc.temperature, 1, b.tok, ids, ids_ld, keep,
+                                              b.state, ch.s);
+                        if (rc == QA_OK) rc = launch_lm_advance(b.state, ch.s);
+                    } else {
+                        rc = launch_argmax(b.logits, ch.B, width, width, lo, b.tok, st < keep ? ids : nullptr, ids_ld, st, ch.s);
+                    }
+                }
+                c.stream = caller;
+                QA_TRY(rc);
             }
         }
         return QA_OK;
     };
-    QA_TRY(phase(0, 0, G + 1, 3, sp.global_size, b.ids_g, G, G));                            // llm_sft.py:137-164
-    QA_TRY(phase(1, 1, S, 3 + sp.global_size, sp.semantic_size, b.ids_s, S, S));            // llm_sft.py:166-193
-    if (G > 0) QA_HIP(hipMemcpyAsync(gids, b.ids_g, sizeof(long long) * (size_t)B * G, hipMemcpyDeviceToDevice, c.stream));
-    if (S > 0) QA_HIP(hipMemcpyAsync(sids, b.ids_s, sizeof(long long) * (size_t)B * S, hipMemcpyDeviceToDevice, c.stream));
+    QA_TRY(phase(0, 0, G + 1, 3, sp.global_size, G));                            // llm_sft.py:137-164
+    QA_TRY(phase(1, 1, S, 3 + sp.global_size, sp.semantic_size, S));            // llm_sft.py:166-193
+    for (int i = 0; i < nc; ++i) {
+        Chain& ch = chains[i];
+        if (G > 0)
+            QA_HIP(hipMemcpyAsync(gids + (size_t)ch.b0 * G, ch.b.ids_g, sizeof(long long) * (size_t)ch.B * G, hipMemcpyDeviceToDevice, ch.s));
+        if (S > 0)
+            QA_HIP(hipMemcpyAsync(sids + (size_t)ch.b0 * S, ch.b.ids_s, sizeof(long long) * (size_t)ch.B * S, hipMemcpyDeviceToDevice, ch.s));
+        if (multi) {  // join: the caller's stream continues behind every chain
+            QA_HIP(hipEventRecord(lm->chain_join[i], ch.s));
+            QA_HIP(hipStreamWaitEvent(caller, lm->chain_join[i], 0));
+        }
+    }
     return QA_OK;
 }
 
@@ -527,6 +621,9 @@ void qa_lm_destroy(qa_lm* lm) {
     (void)hipDeviceSynchronize();
     for (StepGraph& g : lm->graphs) g.reset();
     if (lm->cap_stream) (void)hipStreamDestroy(lm->cap_stream);
+    for (hipStream_t st : lm->chain_streams) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : lm->chain_join) (void)hipEventDestroy(ev);
+    if (lm->ev_fork) (void)hipEventDestroy(lm->ev_fork);
     lm->store.release();
     if (lm->ws) (void)hipFree(lm->ws);
     delete lm;
@@ -590,7 +687,7 @@ int qa_sample_logits(const float* logits, int64_t B, int64_t width, int64_t ld, 
     QA_HIP(hipMalloc(reinterpret_cast<void**>(&scratch), 256 + sizeof(long long) * (size_t)B));
     int* state = reinterpret_cast<int*>(scratch);
     long long* tok = reinterpret_cast<long long*>(scratch + 256);
-    int st = launch_lm_phase_init(tok, 0, (int)B, state, 0, 1, (unsigned long long)seed, s);
+    int st = launch_lm_phase_init(tok, 0, (int)B, state, 0, 1, (unsigned long long)seed, 0, s);
     if (st == QA_OK)
         st = launch_lm_sample(logits, ld, (int)width, (int)B, 0, top_k, top_p, temperature, do_sample, tok, (long long*)out_index, 1, 1,
                               state, s);

@@ -6,7 +6,8 @@ namespace qa {
 
 enum { GM_QKV = 0, GM_GATEUP = 1, GM_RESID = 2, GM_HEAD = 3 };
 // device-side loop state (int words): position of the token being processed (= keys already cached), ids column, RNG step, seed
-enum { ST_POS = 0, ST_COL = 1, ST_STEP = 2, ST_SEED_LO = 4, ST_SEED_HI = 5, ST_WORDS = 8 };
+// ST_SEQ0: index of the chain's first sequence inside the call (the sampler keys its Philox stream by the GLOBAL sequence index)
+enum { ST_POS = 0, ST_COL = 1, ST_STEP = 2, ST_SEQ0 = 3, ST_SEED_LO = 4, ST_SEED_HI = 5, ST_WORDS = 8 };
 
 struct GemvArgs {
     // A operand: rows of x (or, with tok != nullptr, rows table[tok[m]] - the codec_embedding gather of the step's token)
@@ -52,7 +53,7 @@ int launch_lm_attn(const float* q, long long ldq, const float* kc, const float* 
 int launch_lm_pick(const float* pmax, const int* pidx, int n_tiles, int B, int lo, long long* tok, long long* ids, long long ids_ld,
                    int keep, int* state, int col, hipStream_t s);
 int launch_lm_phase_init(long long* tok, long long first_id, int B, int* state, int pos, int reset_step, unsigned long long seed,
-                         hipStream_t s);
+                         int seq0, hipStream_t s);
 int launch_lm_advance(int* state, hipStream_t s);
 int lm_sample_prepare();
 int launch_lm_sample(const float* logits, long long ldl, int width, int B, int lo, int top_k, float top_p, float temperature,

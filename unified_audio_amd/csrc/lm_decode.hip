@@ -699,12 +699,13 @@ int launch_lm_pick(const float* pmax, const int* pidx, int n_tiles, int B, int l
 
 // phase start: tok[:] = first_id, pos, col = 0 (the RNG step counter keeps running across the two phases of a call)
 __global__ void lm_phase_init_kernel(long long* tok, long long first_id, int B, int* state, int pos, int reset_step, unsigned seed_lo,
-                                     unsigned seed_hi) {
+                                     unsigned seed_hi, int seq0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B) tok[i] = first_id;
     if (i == 0) {
         state[ST_POS] = pos;
         state[ST_COL] = 0;
+        state[ST_SEQ0] = seq0;
         if (reset_step) {
             state[ST_STEP] = 0;
             state[ST_SEED_LO] = (int)seed_lo;
@@ -713,9 +714,9 @@ __global__ void lm_phase_init_kernel(long long* tok, long long first_id, int B, 
     }
 }
 int launch_lm_phase_init(long long* tok, long long first_id, int B, int* state, int pos, int reset_step, unsigned long long seed,
-                         hipStream_t s) {
+                         int seq0, hipStream_t s) {
     hipLaunchKernelGGL(lm_phase_init_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, s, tok, first_id, B, state, pos, reset_step,
-                       (unsigned)(seed & 0xffffffffull), (unsigned)(seed >> 32));
+                       (unsigned)(seed & 0xffffffffull), (unsigned)(seed >> 32), seq0);
     QA_LAUNCH_CHECK();
     return QA_OK;
 }
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(1024) void lm_sample_kernel(const float* __restrict
         }
         float Z;
         const float incl = block_scan_1024(loc, s_wave, &Z);
-        const float uu = philox_uniform((unsigned)state[ST_SEED_LO], (unsigned)state[ST_SEED_HI], (unsigned)b, (unsigned)state[ST_STEP]) * Z;
+        const float uu = philox_uniform((unsigned)state[ST_SEED_LO], (unsigned)state[ST_SEED_HI], (unsigned)(b + state[ST_SEQ0]), (unsigned)state[ST_STEP]) * Z;
         if (tid == 0) s_pick = n2 - 1;  // rounding guard: u * Z may land on the total
         __syncthreads();
         float run = incl - loc;
