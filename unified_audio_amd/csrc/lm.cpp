@@ -45,6 +45,7 @@ struct LMLayer {
     // gu_dec holds per tile NT/2 gate rows then NT/2 up rows (both norm-folded)
     const float* qkv_dec = nullptr;
     const float* gu_dec = nullptr;
+    const float* down_dec = nullptr;  // fused MLP: W_down slice-major [I / 16][d][16] (slice j = columns 16 j .. 16 j + 15 of every row)
 };
 constexpr int LM_MAX_POS = 4096;  // max_position_embeddings (conf/config.yaml:146)
 constexpr int LM_MAX_CHAINS = 16;
@@ -67,6 +68,9 @@ struct qa_lm {
     qa_lm_spec spec{};
     int device = 0;
     bool fused_ok = false;   // the shapes fit the fused decode step (otherwise the per-op decode path runs)
+    bool mlp_fused = false;  // QA_LM_MLP_FUSED at create time: gate/up + SwiGLU + down as one launch + a reduce launch
+    int mlp_ac = 16;         // activation columns per workgroup of that launch (QA_LM_MLP_FUSED=2: 8)
+    int att_split = 256;     // keys per workgroup of the decode attention (QA_LM_ATT_SPLIT), at most 4 splits
     int nt_qkv = 0, nt_o = 0, nt_gu = 0, nt_down = 0;
     hipStream_t cap_stream = nullptr;
     std::vector<StepGraph> graphs;  // [2 * chain + phase]: phase 0 global, 1 semantic
@@ -125,6 +129,9 @@ int build_lm(qa_lm* lm, const HostTable& tab) {
     lm->nt_o = tile_width(K_LM_NT_O, d);
     lm->nt_gu = tile_width(K_LM_NT_GU, 2 * I);
     lm->nt_down = tile_width(K_LM_NT_DOWN, d);
+    lm->mlp_fused = knob(K_LM_MLP_FUSED) != 0 && lm_mlp_fused_supported(d, I, lm->nt_gu);
+    lm->mlp_ac = lm_mlp_ac();
+    lm->att_split = knob(K_LM_ATT_SPLIT) >= 32 ? (int)knob(K_LM_ATT_SPLIT) : 256;
     lm->fused_ok = lm_gemv_supported(d, I) && d % lm->nt_qkv == 0 && hd % lm->nt_qkv == 0 && d % lm->nt_o == 0 &&
                    (2 * I) % lm->nt_gu == 0 && hd % 8 == 0 && knob(K_LM_UNFUSED) == 0;
     WeightStore& st = lm->store;
@@ -226,6 +233,18 @@ int build_lm(qa_lm* lm, const HostTable& tab) {
         }
         L.down.N = d; L.down.C_in = I;
         vec(&L.down.w, p + ".mlp.down_proj.weight", (int64_t)I * d);
+        if (lm->fused_ok && lm->mlp_fused) {
+            const float* wdn = tab.get(p + ".mlp.down_proj.weight", (int64_t)I * d);
+            if (wdn) {
+                std::vector<float> ws((size_t)I * d);
+                const int ac = lm->mlp_ac;
+                for (int j = 0; j < I / ac; ++j)
+                    for (int n = 0; n < d; ++n) std::memcpy(&ws[((size_t)j * d + n) * ac], &wdn[(size_t)n * I + (size_t)j * ac], sizeof(float) * ac);
+                pend.push_back({&L.down_dec, st.add(ws)});
+            } else {
+                ok = false;
+            }
+        }
     }
     if (!ok) return QA_ERR_MISSING;
     // LlamaRotaryEmbedding (default rope): inv_freq = theta^(-2i/hd), cos / sin of pos * inv_freq in fp32
@@ -250,7 +269,7 @@ struct LMBuffers {
     float *kc, *vc;
     long long* tok;
     // fused decode step
-    float *q, *att_part, *pmax;
+    float *q, *att_part, *pmax, *mlp_part;
     int *pidx, *state;
     long long *ids_g, *ids_s;
     int cap, S_att;
@@ -324,7 +343,7 @@ int fused_step(qa_lm* lm, const LMBuffers& b, int B, int lo, int width, long lon
     const long long kv_bstride = (long long)b.cap * d;
     const size_t cache_stride = (size_t)B * b.cap * d;
     // key split of the attention launch: a workgroup's 8 waves hold 2 tiles of 16 keys each per round
-    const int S_att = pos >= 0 ? std::max(1, std::min(4, (int)ceil_div(pos + 1, 256))) : b.S_att;
+    const int S_att = pos >= 0 ? std::max(1, std::min(4, (int)ceil_div(pos + 1, lm->att_split))) : b.S_att;
     for (int i = 0; i < sp.n_layers; ++i) {
         const LMLayer& L = lm->layers[i];
         float* kc = b.kc + i * cache_stride;
@@ -350,6 +369,10 @@ int fused_step(qa_lm* lm, const LMBuffers& b, int B, int lo, int width, long lon
         // 4. RMSNorm + gate / up + SwiGLU
         GemvArgs g = a;
         g.x = b.x; g.ldx = d; g.w = L.gu_dec; g.N = 2 * I; g.K = d; g.y = b.u; g.ldy = I;
+        if (lm->mlp_fused && L.down_dec) {  // 4 + 5 as the fused MLP launch + the reduce launch (lm_decode.hip)
+            QA_TRY(launch_lm_mlp(g, I, lm->mlp_ac, L.down_dec, b.mlp_part, b.x, d, b.x, d, s));
+            continue;
+        }
         QA_TRY(launch_lm_gemv(g, GM_GATEUP, lm->nt_gu, s));
         // 5. down_proj + residual
         GemvArgs dn = a;
@@ -398,7 +421,7 @@ int chain_alloc(qa_lm* lm, Ctx& c, Chain& ch, int L, int cap, int G, int S, int 
     const int64_t prow = (int64_t)B * L;
     LMBuffers& b = ch.b;
     b.cap = cap;
-    b.S_att = std::max(1, std::min(4, (int)ceil_div(cap, 256)));  // captured steps: sized for the cache capacity
+    b.S_att = std::max(1, std::min(4, (int)ceil_div(cap, lm->att_split)));  // captured steps: sized for the cache capacity
     b.x = c.arena.alloc<float>(prow * d);
     b.hn = c.arena.alloc<float>(prow * d);
     b.qkv = c.arena.alloc<float>(prow * 3 * d);
@@ -412,6 +435,7 @@ int chain_alloc(qa_lm* lm, Ctx& c, Chain& ch, int L, int cap, int G, int S, int 
     b.tok = c.arena.alloc<long long>(B);
     b.q = c.arena.alloc<float>((size_t)B * d);
     b.att_part = c.arena.alloc<float>((size_t)B * H * b.S_att * (d / H + 4));
+    b.mlp_part = c.arena.alloc<float>(lm->mlp_fused ? (size_t)(I / lm->mlp_ac) * 32 * d : 0);
     b.pmax = c.arena.alloc<float>((size_t)B * (wmax / 4 + 1));
     b.pidx = c.arena.alloc<int>((size_t)B * (wmax / 4 + 1));
     b.state = c.arena.alloc<int>(ST_WORDS);

@@ -48,6 +48,10 @@ struct GemvArgs {
 int lm_pick_nt(int N);
 bool lm_gemv_supported(int hidden, int intermediate);  // kernel instances exist for these K
 int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s);
+bool lm_mlp_fused_supported(int d, int I, int nt_gu);
+int lm_mlp_ac();
+int launch_lm_mlp(const GemvArgs& a, int I, int ac, const float* wd, float* partial, const float* res, long long ldr, float* y, long long ldy,
+                  hipStream_t s);
 int launch_lm_attn(const float* q, long long ldq, const float* kc, const float* vc, long long kv_bstride, long long ldkv,
                    float* part, int B, int H, int hd, int S, const int* state, float scale, int pos, hipStream_t s);
 int launch_lm_pick(const float* pmax, const int* pidx, int n_tiles, int B, int lo, long long* tok, long long* ids, long long ids_ld,

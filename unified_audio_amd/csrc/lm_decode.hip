@@ -515,6 +515,203 @@ int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused MLP of the decode step (QA_LM_MLP_FUSED): gate/up GEMV + SwiGLU + the down projection of the SAME 16 activation columns in
+// one launch, then one small reduce launch - instead of gate/up (256 workgroups) and down (128 workgroups that each pull the whole
+// [M, 4d] activation, 128 KB, through one CU).  Workgroup j owns activation columns [16 j, 16 j + 16): it needs x (32 KB), its 32
+// gate / up rows (64 KB) and the 16-column slice of W_down (32 KB, re-laid out slice-major at load time); `act` never exists in HBM.
+// What the K split of the down projection costs is a cross-workgroup sum: every workgroup writes its [M, d] partial (4 MB in all at
+// M = 16) and lm_mlp_reduce_kernel adds the I / 16 partials and the residual in a fixed order (deterministic, no atomics).
+// Phase 1 is lm_gemv_kernel<MT, 16, GM_GATEUP> on two adjacent column tiles of the gate/up decode layout; phase 2 runs the K = 16
+// product on v_mfma_f32_16x16x4_f32 straight from an LDS copy of the activation tile, W_down slice prefetched at kernel entry.
+// AC = activation columns per workgroup: 16 (two gate/up tiles, I / 16 partials) or 8 (one tile, I / 8 partials, twice the workgroups)
+template <int MT, int NB, int AC>
+__global__ __launch_bounds__(512) void lm_mlp_kernel(const GemvArgs a, const float* __restrict__ wd, float* __restrict__ partial) {
+    constexpr int NTL = AC / 8;  // gate/up decode tiles (8 gate + 8 up rows each) per workgroup
+    __shared__ float part[8][NTL][MT][16][17];
+    __shared__ float s_sq[8][MT * 16];
+    __shared__ __attribute__((aligned(16))) float s_act[MT * 16][20];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int j = blockIdx.x;
+    const int K = a.K, M = a.M, d = a.d;
+    const int kw = K >> 3, k0 = wave * kw;
+    // every load of the workgroup in flight before the first MFMA: gate / up rows, x, and the W_down slice of phase 2
+    const float* wp[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) wp[t] = a.w + ((long long)(NTL * j + t) * 16 + li) * K + k0 + 8 * kq;
+    float4 wr[NTL][NB][2];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            wr[t][c][0] = ldg_nt(wp[t] + c * 32);
+            wr[t][c][1] = ldg_nt(wp[t] + c * 32 + 4);
+        }
+    const int ntw = d >> 7;  // 16-column output tiles per wave in phase 2 (d / 8 columns per wave)
+    constexpr int KL = AC / 4;  // W_down values per lane and output tile: k = KL kq + i
+    float wdr[4][KL];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int n = min(wave * (d >> 3) + t * 16 + li, d - 1);
+        const float* src = wd + ((long long)j * d + n) * AC + KL * kq;
+        if (KL == 4) {
+            const float4 v = ldg_nt(src);
+            wdr[t][0] = v.x; wdr[t][1] = v.y; wdr[t][KL - 2] = v.z; wdr[t][KL - 1] = v.w;
+        } else {
+            const float2 v = *reinterpret_cast<const float2*>(src);
+            wdr[t][0] = v.x; wdr[t][1] = v.y;
+        }
+    }
+    float4 xa[MT][NB][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const float* xrow = a.x + (long long)min(m * 16 + li, M - 1) * a.ldx + k0 + 8 * kq;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            xa[m][c][0] = *reinterpret_cast<const float4*>(xrow + c * 32);
+            xa[m][c][1] = *reinterpret_cast<const float4*>(xrow + c * 32 + 4);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[NTL][MT];
+    float sq[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        sq[m] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float4 a0 = xa[m][c][0], a1 = xa[m][c][1];
+            sq[m] += (a0.x * a0.x + a0.y * a0.y + a0.z * a0.z + a0.w * a0.w) + (a1.x * a1.x + a1.y * a1.y + a1.z * a1.z + a1.w * a1.w);
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+                const float4 w0 = wr[t][c][0], w1 = wr[t][c][1];
+                acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w0.x, acc[t][m], 0, 0, 0);
+                acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w0.y, acc[t][m], 0, 0, 0);
+                acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w0.z, acc[t][m], 0, 0, 0);
+                acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w0.w, acc[t][m], 0, 0, 0);
+                acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, w1.x, acc[t][m], 0, 0, 0);
+                acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, w1.y, acc[t][m], 0, 0, 0);
+                acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, w1.z, acc[t][m], 0, 0, 0);
+                acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, w1.w, acc[t][m], 0, 0, 0);
+            }
+        }
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[wave][t][m][4 * kq + r][li] = acc[t][m][r];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        float v = sq[m];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (kq == 0) s_sq[wave][m * 16 + li] = v;
+    }
+    __syncthreads();
+    // SwiGLU of the 16 x (MT * 16) activation tile: column c of the tile = pair (c & 7, (c & 7) + 8) of weight tile c >> 3, summed over
+    // the 8 K shares in the order lm_gemv_kernel's epilogue uses (bit-identical to the two-launch path's activation)
+    if (tid < MT * 16 * AC) {
+        const int row = tid / AC, c = tid % AC, t = c >> 3, p = c & 7;
+        float sqs = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) {
+            sqs += s_sq[wv][row];
+            v1 += part[wv][t][row >> 4][row & 15][p];
+            v2 += part[wv][t][row >> 4][row & 15][p + 8];
+        }
+        const float rs = rsqrtf(sqs / K + a.rms_eps);
+        s_act[row][c] = silu_f(v1 * rs) * (v2 * rs);
+    }
+    __syncthreads();
+    // phase 2: partial[j][row][n] = sum_{k < 16} act[row][k] * W_down[n][16 j + k].  Operands swapped (W is the MFMA's row operand):
+    // D^T[n][row], so a lane ends up with 4 CONSECUTIVE output columns n = 4 kq .. 4 kq + 3 of batch row li - one 16-byte store per tile
+    float* pj = partial + (long long)j * (MT * 16) * d;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        float av[KL];
+#pragma unroll
+        for (int i = 0; i < KL; ++i) av[i] = s_act[m * 16 + li][KL * kq + i];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t >= ntw) break;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < KL; ++i) o = __builtin_amdgcn_mfma_f32_16x16x4f32(wdr[t][i], av[i], o, 0, 0, 0);
+            const int n = wave * (d >> 3) + t * 16 + 4 * kq;
+            *reinterpret_cast<f32x4*>(pj + (long long)(m * 16 + li) * d + n) = o;
+        }
+    }
+}
+
+// x[row][col] = res[row][col] + sum_j partial[j][row][col]: ONE WAVE per (row, 32-column block), no LDS, no barrier: lane = (group g of 8,
+// 4-column slot l8); a lane adds the partials j = g, g + 8, ... (RJ loads in flight at once), then the 8 groups fold with three xor
+// shuffles - a fixed order: deterministic.
+template <int RJ>
+__global__ __launch_bounds__(64) void lm_mlp_reduce_kernel(const float* __restrict__ partial, int n_part, int m_pad, int d,
+                                                           const float* __restrict__ res, long long ldr, float* __restrict__ y, long long ldy) {
+    const int lane = threadIdx.x, g = lane >> 3, l8 = lane & 7;
+    const int row = blockIdx.y, col = blockIdx.x * 32 + 4 * l8;
+    const float* p0 = partial + (long long)row * d + col;
+    const long long pstride = (long long)m_pad * d;
+    f32x4 res4 = {0.f, 0.f, 0.f, 0.f};
+    if (g == 0) res4 = *reinterpret_cast<const f32x4*>(res + (long long)row * ldr + col);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = g; j0 < n_part; j0 += 8 * RJ) {
+        f32x4 t[RJ];
+#pragma unroll
+        for (int u = 0; u < RJ; ++u) {
+            const int jj = j0 + 8 * u;
+            t[u] = jj < n_part ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p0 + jj * pstride)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < RJ; ++u) v += t[u];
+    }
+#pragma unroll
+    for (int of = 8; of < 64; of <<= 1) {
+        v.x += __shfl_xor(v.x, of, 64);
+        v.y += __shfl_xor(v.y, of, 64);
+        v.z += __shfl_xor(v.z, of, 64);
+        v.w += __shfl_xor(v.w, of, 64);
+    }
+    if (g == 0) *reinterpret_cast<f32x4*>(y + (long long)row * ldy + col) = res4 + v;
+}
+
+bool lm_mlp_fused_supported(int d, int I, int nt_gu) {
+    return nt_gu == 16 && I % 16 == 0 && d % 128 == 0 && d <= 512 && (d == 256 || d == 512);
+}
+int lm_mlp_ac() { return knob(K_LM_MLP_FUSED) == 2 ? 8 : 16; }  // read when the weights are laid out (qa_lm_create) and at launch
+
+// a: x / ldx / w (gate-up decode layout, NT = 16) / M / K = d / d / rms_eps; wd: W_down in slice-major layout [I / 16][d][16];
+// partial: [I / 16][16 * MT][d] scratch; y = res + down(act)
+int launch_lm_mlp(const GemvArgs& a, int I, int ac, const float* wd, float* partial, const float* res, long long ldr, float* y, long long ldy,
+                  hipStream_t s) {
+    QA_REQUIRE(a.M >= 1 && a.M <= 32 && a.K == a.d && lm_mlp_fused_supported(a.d, I, 16), "lm_mlp: unsupported shape M=%d d=%d I=%d", a.M, a.d, I);
+    const int mt = a.M <= 16 ? 1 : 2;
+    const int n_part = I / ac;
+    const dim3 grid((unsigned)n_part);
+#define QA_MLP(MT, NB) \
+    if (ac == 16) hipLaunchKernelGGL((lm_mlp_kernel<MT, NB, 16>), grid, dim3(512), 0, s, a, wd, partial); \
+    else hipLaunchKernelGGL((lm_mlp_kernel<MT, NB, 8>), grid, dim3(512), 0, s, a, wd, partial)
+    if (a.d == 512) {
+        if (mt == 1) { QA_MLP(1, 2); } else { QA_MLP(2, 2); }
+    } else {
+        if (mt == 1) { QA_MLP(1, 1); } else { QA_MLP(2, 1); }
+    }
+#undef QA_MLP
+    QA_LAUNCH_CHECK();
+    hipLaunchKernelGGL((lm_mlp_reduce_kernel<16>), dim3((unsigned)(a.d / 32), (unsigned)a.M), dim3(64), 0, s, partial, n_part, 16 * mt, a.d, res,
+                       ldr, y, ldy);
+    QA_LAUNCH_CHECK();
+    return QA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Single-query attention over the KV cache.  The 16-key tiles of a (sequence, head) are dealt round-robin to the S workgroups of
 // its split and their NW waves; a wave keeps two tiles (its K and V rows) in flight.  Lane map: LPK = HD / 4 lanes cover one key
 // row with one float4 each, so a load instruction reads 64 / LPK whole rows of 4 * HD contiguous bytes (full cache lines; the
