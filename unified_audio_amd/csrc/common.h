@@ -122,6 +122,14 @@ struct ConvParams {
     float* y2;
     const float* alpha2;
     long long ldy2;
+    // Grouped launch (groups == 2, Linear layers only): two problems of IDENTICAL shape in one grid - group 1 reads / writes the same
+    // buffers displaced by g_x / g_y / g_res / g_gate floats and uses its own w2 / bias2 / gamma2 (H-Codec 1.5: the two aggregator
+    // stacks, layer by layer).  M, T_in, T_out describe ONE group; the grid holds groups x tiles.
+    int groups;
+    long long g_x, g_y, g_res, g_gate;
+    const float* w2;
+    const float* bias2;
+    const float* gamma2;
 };
 
 // Live measurement hook (bench.py): when enabled every conv_gemm launch is bracketed by HIP events on its own stream.

@@ -93,7 +93,8 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const ConvParams& p, long lo
 // disappear from the main loop - about 20 of its ~50 non-MFMA instructions, each of which costs ~30 cycles beside the co-resident
 // workgroup's MFMAs.
 template <int BM, int BN, int WM, int WN, bool PRO_ELU, int BK = 32, bool LINEAR = false>
-__global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(const ConvParams p_in) {
+    ConvParams p = p_in;
     constexpr int LDS = BK + 4;
     constexpr int RPP = 256 / (BK / 4);  // rows staged per pass: 8 (BK=32) or 4 (BK=16) threads cover one row chunk
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -118,6 +119,19 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(cons
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
         const int xcd = tile & 7, local = tile >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    if (LINEAR && p.groups > 1) {  // grouped launch: the second half of the (swizzled) tile ids is group 1 - workgroup-uniform
+        const int tpg = ((p.M + BM - 1) / BM) * tiles_n;
+        if (tile >= tpg) {
+            tile -= tpg;
+            p.x += p.g_x;
+            p.y += p.g_y;
+            if (p.res) p.res += p.g_res;
+            if (p.gate) p.gate += p.g_gate;
+            p.w = p.w2;
+            p.bias = p.bias2;
+            p.gamma = p.gamma2;
+        }
     }
     const int m0 = (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * BN;
@@ -350,14 +364,15 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(cons
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const ConvParams& p, hipStream_t stream) {
     QA_REQUIRE(p.prologue == ACT_NONE || p.prologue == ACT_ELU, "conv_gemm: prologue %d unsupported", p.prologue);
-    const long long tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+    const int ng = p.groups > 1 ? p.groups : 1;
+    const long long tiles = ng * ceil_div(p.M, BM) * ceil_div(p.N, BN);
     const bool prof = profile_enabled();
     if (prof) {
         const int cfg = BN == 32 ? PROF_CFG_128x32 : (BN == 64 ? PROF_CFG_128x64 : PROF_CFG_128x128);
         const double n = p.algo_n ? p.algo_n : p.N, k = p.algo_k ? p.algo_k : p.K;
         // algorithmic bytes: every input frame, weight and output element once (+ fused residual / gate reads)
         const double elems = (double)p.B * p.T_in * p.C_in + n * k + (double)p.M * n * (1.0 + (p.res ? 1.0 : 0.0) + (p.gate ? 1.0 : 0.0));
-        profile_record_begin(cfg, 2.0 * (double)p.M * n * k, 4.0 * elems, stream, &p);
+        profile_record_begin(cfg, ng * 2.0 * (double)p.M * n * k, ng * 4.0 * elems, stream, &p);
     }
     // BK = 16 chunks need 45 KB / 35 KB of LDS, so 3-4 workgroups are co-resident per CU (BK = 32: 2) and cover each
     // other's barriers, prologues and epilogues: +10..25 % on the K = 512 layers of the aggregator stacks, +3..5 % on
@@ -371,6 +386,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
     const bool linear_on = knob(K_GEMM_LINEAR) != 0;
     const bool linear = linear_on && p.ksize == 1 && p.stride == 1 && p.pad_left == 0 && p.in_rep <= 1 && p.T_in == p.T_out &&
                         (p.dilation <= 1);
+    QA_REQUIRE(ng == 1 || (linear && ng == 2 && p.w2 && !p.y2), "conv_gemm: a grouped launch needs a Linear layer (ksize 1, QA_GEMM_LINEAR) and w2");
     const bool bk16 = BN >= 64 && p.prologue != ACT_ELU && ((p.K <= bk16_max_k && tiles >= bk16_min_tiles) || p.C_in % 32 != 0);
     if (bk16 && linear)
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, (BN >= 64 ? 16 : 32), true>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
@@ -425,7 +441,8 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
         // Tiles of one launch are dealt round-robin over 256 CUs (two co-resident workgroups share a CU's matrix pipes), so
         // the makespan is (tiles on the busiest CU) x (work per tile) / (sustained efficiency of the configuration:
         // measured ~92 TFLOP/s for 128x128 vs ~75 for 128x64 on long-K shapes).
-        const long long t128 = ceil_div(p.M, 128) * ceil_div(p.N, 128), t64 = ceil_div(p.M, 128) * ceil_div(p.N, 64);
+        const long long ngc = p.groups > 1 ? p.groups : 1;
+        const long long t128 = ngc * ceil_div(p.M, 128) * ceil_div(p.N, 128), t64 = ngc * ceil_div(p.M, 128) * ceil_div(p.N, 64);
         const double c128 = (double)ceil_div(t128, 256) * 128 * 128 / 1.0;
         const double c64 = (double)ceil_div(t64, 256) * 128 * 64 / 0.82;
         cfg = c64 < c128 ? PROF_CFG_128x64 : PROF_CFG_128x128;

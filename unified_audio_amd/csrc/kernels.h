@@ -66,8 +66,10 @@ int launch_ring_append(const float* k, const float* v, long long ld, float* kc, 
 // lstm.hip : one nn.LSTM layer (batch_first, zero initial state) given the precomputed input projection
 //   xw [B, T, 4d] = x W_ih^T + b_ih + b_hh with the 4d axis permuted to (unit, gate) order,
 //   w_hh [4d, d] rows permuted the same way.  h_out [B, T, d].  c_state [B, d] scratch.
+// eager = true: the T step kernels are launched one by one on `s` (no hipGraph replay, no persistent kernel) - for CU-masked streams,
+// whose mask a replayed graph is not known to inherit
 int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d,
-                hipStream_t s);
+                hipStream_t s, bool eager = false);
 // persistent-recurrence bookkeeping for the model graphs: launches so far on `dev`; wait for `s` and report (and clear) a barrier
 // time-out; make this thread's next launch_lstm calls take the per-step kernels
 unsigned long long lstm_persistent_count(int dev);

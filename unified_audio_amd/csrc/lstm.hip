@@ -451,13 +451,14 @@ constexpr size_t LSTM_GRAPH_CACHE = 24;
 }  // namespace
 
 int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d,
-                hipStream_t s) {
+                hipStream_t s, bool eager) {
     QA_REQUIRE(d % 128 == 0, "lstm: hidden size %d must be a multiple of 128", d);
     const bool use_graph = knob(K_LSTM_GRAPH) != 0;
     int dev = 0;
     QA_HIP(hipGetDevice(&dev));
     QA_REQUIRE(dev >= 0 && dev < 16, "lstm: device index %d out of range", dev);
     std::lock_guard<std::mutex> lock(g_lstm_mu);
+    if (eager) return lstm_launch_steps(xw, w_hh_ug, h_out, c_state, B, T, d, s, nullptr, nullptr, nullptr);
     {
         bool done = false;
         QA_TRY(launch_lstm_persistent(xw, w_hh_ug, h_out, c_state, B, T, d, s, dev, &done));
