@@ -330,6 +330,43 @@ def bicodec_bench(dev, batch, reps=3):
                                    f"250 semantic + 32 global tokens -> {batch} x 80 000 samples @16 kHz", "dtype": "f32"}}
 
 
+def unise_pipeline_bench(dev, batches=6, seg_per_batch=16, lm_graph=True):
+    """BASELINE configs[2] END TO END over consecutive batches: Model.test_step 'se' (WavLM -> LLM_SFT.generate -> BiCodec.detokenize) on
+    `batches` x `seg_per_batch` independent 5 s segments through UniSE.enhance (one stage after the other, one micro-batch at a
+    time) and through UniSE.enhance_pipelined (the three stages of consecutive micro-batches on three streams).  Published shapes of
+    all three models, seeded weights, waveforms resident in HBM; the two drivers' outputs are compared bit for bit."""
+    import unified_audio_amd as qa
+    from unified_audio_amd import synth
+    from unified_audio_amd import unise as U
+
+    fx = qa.SSLFeatureExtractor(qa.SPEC_WAVLM_BASE_PLUS, device=dev).load_state_dict(_ssl_state_dict(qa.SPEC_WAVLM_BASE_PLUS))
+    lm = qa.LLM_SFT(device=dev).load_state_dict(synth.lm_state_dict(4321))
+    bic = qa.BiCodec(device=dev).load_state_dict(synth.bicodec_state_dict(77, synth.BiCodecShapes()))
+    drv = U.UniSE(lm, fx, tokenizer=qa.BiCodecTokenizer(model=bic))
+    n = batches * seg_per_batch
+    srcs = [synth.synth_wav(300 + i, 1, U.SEG_LEN).to(dev) for i in range(n)]  # n one-segment utterances
+    seq_t = pipe_t = float("inf")
+    for it in range(3):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        want = []
+        for b in range(batches):  # the sequential driver, one micro-batch per call (what end_to_end_b16 sums, measured in one piece)
+            want += drv.enhance("se", srcs[b * seg_per_batch:(b + 1) * seg_per_batch])
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        got = drv.enhance_pipelined("se", srcs, segments_per_batch=seg_per_batch, lm_graph=lm_graph)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        if it:
+            seq_t, pipe_t = min(seq_t, t1 - t0), min(pipe_t, t2 - t1)
+    same = all(torch.equal(a, b) for a, b in zip(got, want))
+    return {"value": n * 5.0 / pipe_t, "unit": "audio-seconds/sec", "ms_per_batch": 1e3 * pipe_t / batches,
+            "sequential": {"value": n * 5.0 / seq_t, "ms_per_batch": 1e3 * seq_t / batches}, "batches": batches, "segments_per_batch": seg_per_batch,
+            "bit_identical_to_sequential": bool(same),
+            "config": {"workload": f"UniSE 'se' end to end, {batches} consecutive batches of {seg_per_batch} x 5 s segments, WavLM | AR-LM | BiCodec of "
+                                   "consecutive batches on three streams (UniSE.enhance_pipelined), LM on replayed step graphs", "dtype": "f32"}}
+
+
 def rvq_bench(dev, lib, n_vec, Q, K=1024, D=512, reps=5):
     """The RVQ search by itself (qa_rvq_search = ResidualVQ.forward) at the shape of one stream of BASELINE configs[4]:
     n_vec residual vectors x Q stages against K x D codebooks (codebooks scaled 0.5^q per stage like the synthetic checkpoints).
@@ -679,6 +716,12 @@ def main():
                                              "tokens_per_sec": args.lm_batch * 283 / tot,
                                              "note": "Model.test_step 'se' on 16 x 5 s segments: WavLM front-end + LLM_SFT.generate + BiCodec.detokenize "
                                                      "(the codec decode the reference's test.py uses, model.py:193), stages timed back to back"}
+            if world == 1 and not args.no_extras and not args.lean:
+                try:
+                    log("UniSE end to end, pipelined over 6 batches of 16 segments ...")
+                    lm_line["end_to_end_pipelined_b16"] = unise_pipeline_bench(dev, 6, args.lm_batch)
+                except Exception as e:  # noqa: BLE001
+                    lm_line["end_to_end_pipelined_b16"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
             line["unise_lm"] = lm_line
         if extras:
             line["extras"] = extras

@@ -240,3 +240,9 @@ def test_bicodec_published_16x5s_matches_oracle(qa_lib, gpu_device):
     assert err < 2e-4 and rms < 1e-3, (err, rms)
     one = bc.detokenize(sem[9:10].to(gpu_device), glob[9:10].to(gpu_device))
     assert torch.equal(one[0], got[9])
+    # more than 32 segments per call (the pipelined UniSE driver at 64): the per-item linears (d-vector, AdaLN conditions) used to
+    # switch kernels at 33 rows, which made a segment's samples depend on the batch it travelled in
+    sem64, glob64 = psynth.bicodec_tokens(13, 40, 100, ospec)
+    big = bc.detokenize(sem64.to(gpu_device), glob64.to(gpu_device))
+    for i in (0, 33, 39):
+        assert torch.equal(bc.detokenize(sem64[i:i + 1].to(gpu_device), glob64[i:i + 1].to(gpu_device))[0], big[i]), i

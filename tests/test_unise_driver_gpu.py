@@ -96,3 +96,38 @@ def test_enhance_end_to_end_against_the_oracle_chain(qa_lib, gpu_device):
     (t1, t2), = drv.enhance("ss", [src.to(gpu_device)])
     assert s1.shape == s2.shape == (90000,) and torch.equal(s1, t1) and torch.equal(s2, t2) and not torch.equal(s1, s2)
     assert torch.isfinite(s1).all() and torch.isfinite(s2).all()
+
+
+def test_pipelined_driver_is_bit_identical_to_the_sequential_one(qa_lib, gpu_device):
+    """UniSE.enhance_pipelined (three streams: WavLM of batch k + 1 | LM of batch k | BiCodec of batch k - 1, micro-batches of a few
+    segments, LM on replayed step graphs) against UniSE.enhance on the same utterances: identical samples, 'se' and 'tse', incl. a
+    ragged last micro-batch and micro-batches that mix utterances."""
+    import unified_audio_amd as qa
+    from oracle import bicodec_ref as BR
+    from unified_audio_amd import synth
+    from unified_audio_amd import unise as U
+
+    sspec = S.SSLSpec(conv_dim=(64,) * 7, hidden_size=96, num_hidden_layers=2, num_attention_heads=3, intermediate_size=192,
+                      num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=2, num_buckets=32, max_bucket_distance=100,
+                      compress_exponent=0.0)
+    fx = qa.SSLFeatureExtractor(qa.SSLSpec(**{f: getattr(sspec, f) for f in sspec.__dataclass_fields__}), device=gpu_device)
+    fx.load_state_dict(S.synth_state_dict(4, sspec, "wavlm"))
+    bspec = BR.BiCodecSpec(latent_dim=64, codebook_size=128, codebook_dim=8, spk_latent_dim=32, token_num=32, vocos_dim=32, vocos_inter=64,
+                           vocos_layers=2, gen_channels=512, rates=(8, 5, 4, 2), kernel_sizes=(16, 11, 8, 4))
+    lspec = L.LMSpec(hidden=256, n_layers=2, n_heads=4, global_size=4096, semantic_size=128, feats_dim=96)
+    lm = qa.LLM_SFT(feats_dim=96, llm_base_config=dict(global_size=4096, semantic_size=128, hidden_size=256, num_layers=2,
+                                                       num_attention_heads=4), device=gpu_device).load_state_dict(L.lm_state_dict(8, lspec))
+    bic = qa.BiCodec(qa.BiCodecSpec(**{f: getattr(bspec, f) for f in bspec.__dataclass_fields__}), device=gpu_device)
+    bic.load_state_dict(synth.bicodec_state_dict(5, bspec))
+    drv = U.UniSE(lm, fx, tokenizer=qa.BiCodecTokenizer(model=bic))
+    g = torch.Generator().manual_seed(3)
+    srcs = [(torch.randn(1, n, generator=g) * 0.1).to(gpu_device) for n in (90000, 250001, 80000, 161000)]  # 2 + 4 + 1 + 3 segments
+    enrs = [(torch.randn(1, 32000, generator=g) * 0.1).to(gpu_device) for _ in srcs]
+    for mode, e in (("se", None), ("tse", enrs)):
+        want = drv.enhance(mode, srcs, e)
+        for m in (3, 4, 16):
+            got = drv.enhance_pipelined(mode, srcs, e, segments_per_batch=m)
+            torch.cuda.synchronize()
+            assert len(got) == len(want)
+            for a, b, src in zip(got, want, srcs):
+                assert a.shape == b.shape == (src.size(-1),) and torch.equal(a, b), (mode, m)

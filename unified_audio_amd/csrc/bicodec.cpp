@@ -319,11 +319,20 @@ int conv(Ctx& c, const float* x, int64_t ldx, int B, int T_in, const ConvW& w, f
     return launch_conv_gemm(p, c.stream);
 }
 
+// per_item: one row per batch item (d-vector, AdaLN conditions) - always the weight-streaming skinny GEMM, 32 rows per launch, so that an
+// item's arithmetic does not depend on how many items share the call (a row-count rule - skinny up to 32 rows, implicit GEMM above -
+// made batches of more than 32 segments differ from smaller ones by 1e-5: found by the pipelined UniSE driver at 64 segments per batch)
 int linear(Ctx& c, const float* x, int64_t rows, const ConvW& w, float* y, int act = ACT_NONE, const float* res = nullptr,
-           const float* gamma = nullptr) {
+           const float* gamma = nullptr, bool per_item = false) {
     if (c.dry) return QA_OK;
-    if (rows <= 32 && w.C_in % 256 == 0 && !gamma)  // a handful of rows (d-vector, AdaLN conditions): the weight-streaming skinny GEMM
-        return launch_skinny_gemm(x, w.C_in, w.w, w.b, nullptr, 0, res, w.N, y, w.N, (int)rows, w.N, w.C_in, act, c.stream, 0.f, 0);
+    if (per_item && w.C_in % 256 == 0 && !gamma) {
+        for (int64_t r0 = 0; r0 < rows; r0 += 32) {
+            const int n = (int)std::min<int64_t>(32, rows - r0);
+            QA_TRY(launch_skinny_gemm(x + r0 * w.C_in, w.C_in, w.w, w.b, nullptr, 0, res ? res + r0 * w.N : nullptr, w.N, y + r0 * w.N, w.N, n, w.N,
+                                      w.C_in, act, c.stream, 0.f, 0));
+        }
+        return QA_OK;
+    }
     ConvOpt o;
     o.act = act; o.res = res; o.gamma = gamma;
     return conv(c, x, w.C_in, 1, (int)rows, w, y, w.N, (int)rows, o);
@@ -374,8 +383,8 @@ int detokenize_graph(qa_bicodec* h, Ctx& c, const long long* sem, const long lon
         QA_TRY(launch_gather_rows(sem, h->sem_table, zq, rows, sp.codebook_size, Ld, c.stream));
         QA_TRY(launch_gather_global(glob, h->glob_table, gflat, B, sp.token_num, h->n_glob, sp.spk_latent_dim, c.stream));
     }
-    QA_TRY(linear(c, gflat, B, h->project, dvec));
-    QA_TRY(linear(c, dvec, B, h->ada, cond));
+    QA_TRY(linear(c, gflat, B, h->project, dvec, ACT_NONE, nullptr, nullptr, true));
+    QA_TRY(linear(c, dvec, B, h->ada, cond, ACT_NONE, nullptr, nullptr, true));
     c.tap("z_q", zq, rows * Ld);
     c.tap("d_vector", dvec, (int64_t)B * Ld);
     // ---- prenet

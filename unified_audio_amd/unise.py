@@ -146,7 +146,115 @@ class UniSE:
                                "enhance_tokens returns the tokens")
         if mode == "ss":
             return self._separate(srcs)
-        return [self._wave(src, g, s) for src, (g, s) in zip(srcs, self.enhance_tokens(mode, srcs, enrolls))]
+        toks = self.enhance_tokens(mode, srcs, enrolls)
+        return self._waves(srcs, toks)
+
+    def _waves(self, srcs, toks):
+        """model.py:192 for every utterance, with ONE detokenize call over all segments (segments are independent and the detokenizer
+        is batch-invariant, so this equals the reference's per-utterance calls bit for bit)."""
+        g = torch.cat([t[0] for t in toks], dim=0)
+        s = torch.cat([t[1] for t in toks], dim=0)
+        est = self.detokenize(g.unsqueeze(1), s).squeeze(1)
+        out, at = [], 0
+        for src, (gi, _) in zip(srcs, toks):
+            out.append(est[at:at + gi.size(0)].reshape(-1)[: src.size(-1)])
+            at += gi.size(0)
+        return out
+
+    @torch.no_grad()
+    def enhance_pipelined(self, mode: str, srcs: Sequence[torch.Tensor], enrolls: Optional[Sequence[torch.Tensor]] = None,
+                          segments_per_batch: int = 16, lm_graph: bool = True):
+        """The same results as `enhance` ('se' / 'tse' / 'rtse'), produced by a THREE-STAGE PIPELINE over micro-batches of
+        `segments_per_batch` 5 s segments on three streams: WavLM features of batch k + 1, LLM_SFT.generate of batch k and
+        BiCodec.detokenize of batch k - 1 run concurrently.  The decode loop of the LM is bound by the latency of its dependent
+        launches and leaves the matrix cores idle; the two GEMM-bound stages fill them.  Every stage owns its
+        handle (workspace), so the three streams never share library state; tensors that cross streams are recorded on the consuming
+        stream.  `lm_graph`: the LM replays one captured hipGraph per token (QA_LM_GRAPH) so that the host - which would otherwise
+        spend the whole generate issuing its ~17 000 launches - is free to enqueue the other two stages.  Segments are independent
+        and every stage is batch-invariant, so the output is bit-identical to `enhance` (tests/test_unise_driver_gpu.py)."""
+        from . import _lib
+
+        if self.detokenize is None:
+            raise RuntimeError("UniSE.enhance_pipelined needs a tokenizer (unified_audio_amd.BiCodecTokenizer) or a detokenize callable")
+        if mode not in ("se", "tse", "rtse"):
+            raise KeyError(mode)
+        segs = [segment(s, normalise=(mode == "se")) for s in srcs]
+        counts = [s.size(0) for s in segs]
+        seg_src = torch.cat(segs, dim=0)
+        dev = seg_src.device
+        n_seg, m = seg_src.size(0), max(1, int(segments_per_batch))
+        owner = torch.repeat_interleave(torch.arange(len(srcs)), torch.tensor(counts)).tolist()  # utterance of every segment
+        cur = torch.cuda.current_stream(dev)
+        s_feat, s_lm, s_dec = (torch.cuda.Stream(dev) for _ in range(3))
+        for st in (s_feat, s_lm, s_dec):
+            st.wait_stream(cur)
+        ef, n_enr = None, 0
+        if mode != "se":
+            if enrolls is None or len(enrolls) != len(srcs):
+                raise ValueError(f"{mode} needs one enrollment per utterance")
+            if len({e.size(-1) for e in enrolls}) != 1:
+                raise ValueError("enrollments of one call must have the same length")
+            with torch.cuda.stream(s_feat):
+                ef = self.semantic_model(torch.cat(list(enrolls), dim=0))
+            n_enr = enrolls[0].size(-1)
+        nb = (n_seg + m - 1) // m
+        feats, toks, wavs, keep = [None] * nb, [None] * nb, [None] * nb, []
+        ev_f = [torch.cuda.Event() for _ in range(nb)]
+        ev_l = [torch.cuda.Event() for _ in range(nb)]
+        old_graph = _lib.set_knob("QA_LM_GRAPH", 1) if lm_graph else None
+        # the detokenizer's range check of its inputs is a host synchronisation per call: the tokens here are the LM's own (offsets
+        # subtracted inside the active vocabulary slices, in range by construction), so the check is switched off inside the pipeline
+        bic = getattr(getattr(self.detokenize, "__self__", None), "model", None)
+        old_check = getattr(bic, "check_tokens", None)
+        if old_check:
+            bic.check_tokens = False
+        try:
+            for k in range(nb + 2):
+                if k < nb:  # stage 1: features of micro-batch k
+                    with torch.cuda.stream(s_feat):
+                        x = seg_src[k * m:(k + 1) * m]
+                        f = self.semantic_model(x)
+                        e = None
+                        if ef is not None:
+                            e = ef[torch.tensor(owner[k * m:(k + 1) * m], device=dev)].contiguous()
+                            e.record_stream(s_lm)
+                        f.record_stream(s_lm)
+                        feats[k] = (f, e, x.size(0))
+                        ev_f[k].record(s_feat)
+                j = k - 2
+                if 0 <= j < nb:  # stage 3: waveform of micro-batch k - 2 (enqueued BEFORE the long LM enqueue of this turn)
+                    with torch.cuda.stream(s_dec):
+                        s_dec.wait_event(ev_l[j])
+                        g, s = toks[j]
+                        w = self.detokenize(g.unsqueeze(1), s).squeeze(1)
+                        w.record_stream(cur)
+                        wavs[j] = w
+                j = k - 1
+                if 0 <= j < nb:  # stage 2: tokens of micro-batch k - 1
+                    with torch.cuda.stream(s_lm):
+                        s_lm.wait_event(ev_f[j])
+                        f, e, b = feats[j]
+                        g, s = self.dnn.generate(task_name=mode, enroll_mel=None if e is None else _Frames(b, mel_frames(n_enr)), enroll_feats=e,
+                                                 mix_mel=_Frames(b, mel_frames(SEG_LEN)), mix_feats=f, do_sample=False)
+                        g.record_stream(s_dec)
+                        s.record_stream(s_dec)
+                        toks[j] = (g, s)
+                        ev_l[j].record(s_lm)
+                keep.append((feats, toks))
+        finally:
+            if old_graph is not None:
+                _lib.set_knob("QA_LM_GRAPH", old_graph)
+            if old_check:
+                bic.check_tokens = old_check
+        cur.wait_stream(s_dec)
+        cur.wait_stream(s_lm)
+        cur.wait_stream(s_feat)
+        est = torch.cat(wavs, dim=0)
+        out, at = [], 0
+        for src, c in zip(srcs, counts):
+            out.append(est[at:at + c].reshape(-1)[: src.size(-1)])
+            at += c
+        return out
 
     def _separate(self, srcs: Sequence[torch.Tensor]):
         # pass 1 (model.py:224-242): SE on the first 5 s of every mixture (wrap-padded if shorter; no peak normalisation in this mode)
@@ -167,6 +275,5 @@ class UniSE:
         out = []
         tse = self._split(counts, *self._generate("tse", seg_src, counts, ef, SEG_LEN))
         rtse = self._split(counts, *self._generate("rtse", seg_src, counts, ef, SEG_LEN))
-        for src, (g1, s1), (g2, s2) in zip(srcs, tse, rtse):
-            out.append((self._wave(src, g1, s1), self._wave(src, g2, s2)))
-        return out
+        w1, w2 = self._waves(srcs, tse), self._waves(srcs, rtse)
+        return list(zip(w1, w2))
