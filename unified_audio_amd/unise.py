@@ -163,15 +163,20 @@ class UniSE:
 
     @torch.no_grad()
     def enhance_pipelined(self, mode: str, srcs: Sequence[torch.Tensor], enrolls: Optional[Sequence[torch.Tensor]] = None,
-                          segments_per_batch: int = 16, lm_graph: bool = True):
+                          segments_per_batch: int = 16, lm_graph: bool = False):
         """The same results as `enhance` ('se' / 'tse' / 'rtse'), produced by a THREE-STAGE PIPELINE over micro-batches of
         `segments_per_batch` 5 s segments on three streams: WavLM features of batch k + 1, LLM_SFT.generate of batch k and
         BiCodec.detokenize of batch k - 1 run concurrently.  The decode loop of the LM is bound by the latency of its dependent
         launches and leaves the matrix cores idle; the two GEMM-bound stages fill them.  Every stage owns its
         handle (workspace), so the three streams never share library state; tensors that cross streams are recorded on the consuming
-        stream.  `lm_graph`: the LM replays one captured hipGraph per token (QA_LM_GRAPH) so that the host - which would otherwise
-        spend the whole generate issuing its ~17 000 launches - is free to enqueue the other two stages.  Segments are independent
-        and every stage is batch-invariant, so the output is bit-identical to `enhance` (tests/test_unise_driver_gpu.py)."""
+        stream.  `lm_graph`: the LM replays one captured hipGraph per token (QA_LM_GRAPH) instead of issuing its ~17 000 launches.
+        Segments are independent and every stage is batch-invariant, so the output is bit-identical to `enhance`
+        (tests/test_unise_driver_gpu.py).
+        MEASURED (profiles/r03_unise_pipeline_ab.txt, 6 x 16 segments): 176.8 ms per batch against 181.2 ms for `enhance` batch by
+        batch - the overlap is almost nil: the workgroups of the GEMM stages (30 - 300 us each) hold the wave slots of every CU, so
+        the 5 us launches of the LM queue behind them exactly as the LSTM step launches do, and the work adds
+        up instead of overlapping; with replayed LM graphs 194.8 ms.  Throughput comes from the batch size instead: 64 segments per
+        call (two LM chains) run at 692 audio-s/s end to end against 442 at 16."""
         from . import _lib
 
         if self.detokenize is None:
