@@ -490,6 +490,51 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(out).all()
 
+    # N > 1: (a) which devices the ranks really sit on (all-gather of their UUIDs: "did RCCL see N distinct GPUs" is answerable from
+    # the line), (b) the exchange step north_star names - scatter of the clips from rank 0, gather of codes + waveforms back over
+    # RCCL (unified_audio_amd.dist.run_sharded, the code path the gloo tests exercise) - timed NEXT TO the hot path, never inside
+    # `value`: in the timed region above every rank draws its own shard, like the reference's rank-strided file lists
+    ranks_seen, exchange = None, None
+    if dist is not None:
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "host": os.uname().nodename}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        ranks_seen = {"ranks": seen, "distinct_devices": len({(s["host"], s["uuid"], s["pci_bus_id"]) for s in seen})}
+        try:
+            from unified_audio_amd import dist as qd
+
+            K = spec.codebook_size
+            all_wav = torch.cat([(synth.synth_wav_fullband(7 + r, B, T) if args.model == "2.0" else synth.synth_wav(7 + r, B, T)) for r in range(world)]).to(dev) if rank == 0 else None
+            all_feats = torch.cat([synth.synth_feat(9 + r, B, T // hop_in, spec.sem_in).transpose(1, 2).contiguous() for r in range(world)]).to(dev) if rank == 0 else None
+
+            def hot_path(w, f):
+                if adaptive:
+                    codes = codec.encode(w.unsqueeze(1), f.transpose(1, 2))
+                    return codes["acoustic_codes"], codes["semantic_codes"], codec.decode(**codes)
+                a_, s_ = codec.encode(w.unsqueeze(1), f.transpose(1, 2))
+                return a_, s_, codec.decode(a_, s_)
+
+            tm = {}
+            fence()
+            res = qd.run_sharded(hot_path, [all_wav, all_feats], dev, pad_values=[-K, -K, 0.0] if adaptive else None, timings=tm)
+            tt = torch.tensor([tm["scatter_s"], tm["compute_s"], tm["gather_s"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            exchange = {"scatter_ms": 1e3 * float(tt[0]), "compute_ms": 1e3 * float(tt[1]), "gather_ms": 1e3 * float(tt[2]),
+                        "exchange_ms": 1e3 * float(tt[0] + tt[2]),
+                        "scatter_bytes": world * B * (T + (T // hop_in) * spec.sem_in) * 4,
+                        "note": "max over ranks; rank 0 scatters every rank's clips + SSL features and gathers codes + waveforms "
+                                "(torch.distributed scatter / gather over RCCL); reported beside the hot path, never inside `value`"}
+            if rank == 0:
+                own = hot_path(wav, feats)  # rank 0's block of the gathered result must be what rank 0 computes from its own shard
+                g0 = res[2][:B]
+                exchange["gathered_shapes"] = [list(r_.shape) for r_ in res]
+                exchange["rank0_block_matches_local_run"] = bool(torch.equal(g0[..., : own[2].shape[-1]], own[2]))
+            del all_wav, all_feats, res
+        except Exception as e:  # noqa: BLE001
+            exchange = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+
     # the same kernels with the library's internal stream concurrency switched off (every launch alone on the device):
     # what a kernel achieves by itself, as opposed to while it shares the CUs with the other stream's kernels
     iso = (C.c_double * 12)()
@@ -723,6 +768,10 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     lm_line["end_to_end_pipelined_b16"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
             line["unise_lm"] = lm_line
+        if ranks_seen is not None:
+            line["ranks_seen"] = ranks_seen
+        if exchange is not None:
+            line["exchange"] = exchange
         if extras:
             line["extras"] = extras
         if ssl_line is not None:

@@ -106,3 +106,115 @@ def test_gather_pads_data_dependent_trailing_dims_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert q.get() == "ok"
+
+
+# --------------------------------------------------------------------------------------- ragged lists, failure propagation
+
+def test_balanced_partition_properties():
+    import random
+
+    rnd = random.Random(3)
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 7, 64):
+            lengths = [rnd.randint(16000, 16000 * 60) for _ in range(n)]
+            parts = qd.balanced_partition(lengths, world)
+            assert sorted(i for p in parts for i in p) == list(range(n))            # every utterance exactly once
+            loads = [sum(lengths[i] for i in p) for p in parts]
+            if n >= world:
+                # LPT (Graham): makespan <= 4/3 OPT, and OPT >= max(mean load, longest utterance)
+                assert max(loads) <= (4 / 3) * max(sum(lengths) / world, max(lengths)) + 1
+            assert parts == qd.balanced_partition(lengths, world)                   # deterministic
+            for p in parts:
+                assert [lengths[i] for i in p] == sorted((lengths[i] for i in p), reverse=True)  # longest first inside a rank
+    # the block split of the same list is far less even: 2 long + 6 short utterances over 2 ranks
+    lengths = [60, 60, 1, 1, 1, 1, 1, 1]
+    lpt = [sum(lengths[i] for i in p) for p in qd.balanced_partition(lengths, 2)]
+    assert max(lpt) == 63 and sum(lengths[:4]) == 122
+
+
+def _ragged_worker(rank, world, port, lengths, fail_rank, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        utts = [torch.arange(n, dtype=torch.float32) + 1000 * i for i, n in enumerate(lengths)] if rank == 0 else None
+
+        def hot_path(local):  # per-utterance, output length differs from the input's (like codes / padded waveforms)
+            if rank == fail_rank:
+                raise ValueError("device fault on this rank")
+            return [torch.cat([u * 2, u[:1]]) for u in local]
+
+        try:
+            out = qd.run_sharded_ragged(hot_path, utts, dev)
+        except qd.ShardError as e:
+            q.put(("error", rank, str(e)))
+            return
+        if rank == 0:
+            ok = len(out) == len(lengths) and all(torch.equal(o, torch.cat([u * 2, u[:1]])) for o, u in zip(out, utts))
+            q.put(("ok" if ok else "mismatch", rank, ""))
+        else:
+            assert out is None
+            q.put(("none", rank, ""))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_ragged(world, lengths, fail_rank=-1):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, lengths, fail_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, "a rank hung or crashed"
+    return sorted(q.get() for _ in range(world))
+
+
+@pytest.mark.parametrize("world,lengths", [(2, [50, 7, 33, 12, 90]), (3, [5, 400, 17, 17, 230, 1, 64]), (3, [9, 4])])
+def test_run_sharded_ragged_gloo(world, lengths):
+    """Utterances of different lengths, partitioned by length, one packed transfer per rank each way, results back in the original
+    order (incl. a rank with nothing to do)."""
+    res = _run_ragged(world, lengths)
+    assert [r[0] for r in res] == ["none"] * (world - 1) + ["ok"], res
+
+
+def test_a_failing_rank_raises_everywhere_instead_of_hanging_gloo():
+    """The hot path throws on rank 1 of 3: every rank must raise ShardError (naming the rank) rather than wait in the gather."""
+    res = _run_ragged(3, [10, 20, 30, 40, 50, 60], fail_rank=1)
+    assert [r[0] for r in res] == ["error"] * 3, res
+    assert all("rank 1: ValueError: device fault" in r[2] for r in res)
+
+
+def _fail_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        clips = torch.ones(4, 6) if rank == 0 else None
+
+        def hot_path(w):
+            if rank == 1:
+                raise RuntimeError("out of memory")
+            return (w * 2,)
+
+        try:
+            qd.run_sharded(hot_path, [clips], torch.device("cpu"))
+            q.put("no error")
+        except qd.ShardError as e:
+            q.put("ShardError" if "rank 1: RuntimeError: out of memory" in str(e) else str(e))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_run_sharded_propagates_a_rank_failure_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fail_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get() for _ in range(2)) == ["ShardError", "ShardError"]

@@ -74,17 +74,31 @@ def gather_ragged(local: torch.Tensor, dst: int = 0, group=None, pad_value=0) ->
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
 
 
+def _tick(device: torch.device) -> float:
+    import time
+
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    return time.perf_counter()
+
+
 def run_sharded(fn: Callable[..., Sequence[torch.Tensor]], inputs: Sequence[Optional[torch.Tensor]], device: torch.device,
-                src: int = 0, group=None, pad_values: Optional[Sequence] = None) -> Optional[List[torch.Tensor]]:
+                src: int = 0, group=None, pad_values: Optional[Sequence] = None, timings: Optional[dict] = None) -> Optional[List[torch.Tensor]]:
     """scatter every input from rank `src`, run `fn(*local_inputs)` (the per-GPU hot path, e.g. tokenize+detokenize),
-    gather every output back to `src`.  Ranks whose shard is empty skip `fn`.  `pad_values[i]` fills output i where a rank's
-    trailing dimensions are shorter than another's (gather_ragged)."""
+    gather every output back to `src` (`timings`: a dict that receives this rank's scatter_s / compute_s / gather_s).  Ranks whose shard is empty skip `fn`.  `pad_values[i]` fills output i where a rank's
+    trailing dimensions are shorter than another's (gather_ragged).  If `fn` raises on any rank, EVERY rank raises ShardError."""
+    t0 = _tick(device) if timings is not None else 0.0
     local = [scatter_clips(t, device, src, group) for t in inputs]
-    if local[0].shape[0] > 0:
-        outs = list(fn(*local))
-        template = [(tuple(o.shape[1:]), o.dtype) for o in outs]
-    else:
-        outs, template = None, None
+    t1 = _tick(device) if timings is not None else 0.0
+    outs, template, err = None, None, None
+    try:
+        if local[0].shape[0] > 0:
+            outs = list(fn(*local))
+            template = [(tuple(o.shape[1:]), o.dtype) for o in outs]
+    except Exception as e:  # noqa: BLE001  (reported to every rank below: nobody may be left waiting in the gather)
+        err = f"{type(e).__name__}: {e}"
+    t2 = _tick(device) if timings is not None else 0.0
+    _raise_if_any_failed(err, group)
     # ranks with an empty shard need the output signature to build their (empty) contribution
     sigs = [None] * dist.get_world_size(group)
     dist.all_gather_object(sigs, template, group=group)
@@ -93,4 +107,108 @@ def run_sharded(fn: Callable[..., Sequence[torch.Tensor]], inputs: Sequence[Opti
         outs = [torch.empty((0,) + shp, dtype=dt, device=device) for shp, dt in sig]
     pads = list(pad_values) if pad_values is not None else [0] * len(outs)
     gathered = [gather_ragged(o, src, group, pv) for o, pv in zip(outs, pads)]
+    if timings is not None:  # this rank's wall time of the three phases: the exchange steps next to - never inside - the compute
+        t3 = _tick(device)
+        timings.update(scatter_s=t1 - t0, compute_s=t2 - t1, gather_s=t3 - t2)
     return gathered if dist.get_rank(group) == src else None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Ragged utterance lists ("sorted by length to balance").  The reference feeds one utterance per step and shards the
+# file list rank-strided (QuarkAudio-UniSE/dataloader/data_module.py:340,364), which leaves the ranks with whatever total length
+# the stride happens to give them; here the list is partitioned by LENGTH so that every rank gets about the same number of samples.
+
+class ShardError(RuntimeError):
+    """Raised on EVERY rank when the hot path failed on some rank (so that no rank is left waiting in a collective)."""
+
+
+def balanced_partition(lengths: Sequence[int], world: int) -> List[List[int]]:
+    """Longest-processing-time partition: utterances sorted by length (longest first, ties by index) are dealt one by one to the
+    rank with the smallest total so far (ties: lowest rank).  Returns the utterance indices of every rank, longest first -
+    deterministic, every index exactly once, max load <= (4/3 - 1/(3 world)) x optimal (Graham's bound)."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    loads, parts = [0] * world, [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        parts[r].append(i)
+        loads[r] += int(lengths[i])
+    return parts
+
+
+def _raise_if_any_failed(err: Optional[str], group=None) -> None:
+    errs = [None] * dist.get_world_size(group)
+    dist.all_gather_object(errs, err, group=group)
+    bad = [(r, e) for r, e in enumerate(errs) if e is not None]
+    if bad:
+        raise ShardError("; ".join(f"rank {r}: {e}" for r, e in bad))
+
+
+def _pack(tensors: Sequence[torch.Tensor], device: torch.device, dtype: torch.dtype) -> torch.Tensor:
+    if not tensors:
+        return torch.empty(0, dtype=dtype, device=device)
+    return torch.cat([t.reshape(-1).to(device=device, dtype=dtype) for t in tensors])
+
+
+def run_sharded_ragged(fn: Callable[[List[torch.Tensor]], Sequence[torch.Tensor]], utterances: Optional[Sequence[torch.Tensor]],
+                       device: torch.device, src: int = 0, group=None) -> Optional[List[torch.Tensor]]:
+    """rank `src` holds `utterances` (1-D tensors of different lengths, one dtype); they are partitioned by length
+    (balanced_partition), every rank receives its share as ONE packed point-to-point transfer, runs
+    `fn(list of its utterances) -> one 1-D tensor per utterance` (the per-GPU hot path; results may be of any length), and the results
+    travel back the same way.  Returns, on `src`, the results in the ORIGINAL order (None elsewhere).  A rank with no utterance
+    skips `fn`.  If `fn` raises anywhere, every rank raises ShardError instead of blocking in the gather."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    plan = [None]
+    if rank == src:
+        lengths = [int(u.numel()) for u in utterances]
+        plan = [(balanced_partition(lengths, world), lengths, utterances[0].dtype if utterances else torch.float32)]
+    dist.broadcast_object_list(plan, src=src, group=group)
+    parts, lengths, dtype = plan[0]
+    mine = parts[rank]
+    # ---- scatter: one packed tensor per destination rank
+    if rank == src:
+        for r in range(world):
+            if r != src and parts[r]:
+                dist.send(_pack([utterances[i] for i in parts[r]], device, dtype), dst=r, group=group)
+        local = [utterances[i].reshape(-1).to(device) for i in mine]
+    else:
+        packed = torch.empty(sum(lengths[i] for i in mine), dtype=dtype, device=device)
+        if mine:
+            dist.recv(packed, src=src, group=group)
+        local, at = [], 0
+        for i in mine:
+            local.append(packed[at:at + lengths[i]])
+            at += lengths[i]
+    # ---- the hot path; a failure is reported to everybody before anyone enters the gather
+    outs, err = [], None
+    try:
+        if local:
+            outs = [o.reshape(-1) for o in fn(local)]
+            if len(outs) != len(local):
+                raise ValueError(f"fn returned {len(outs)} results for {len(local)} utterances")
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    _raise_if_any_failed(err, group)
+    # ---- gather: lengths first (objects), then one packed transfer per rank
+    meta = [None] * world
+    dist.all_gather_object(meta, ([int(o.numel()) for o in outs], outs[0].dtype if outs else None), group=group)
+    if rank != src:
+        if outs:
+            dist.send(_pack(outs, device, outs[0].dtype), dst=src, group=group)
+        return None
+    result: List[Optional[torch.Tensor]] = [None] * len(lengths)
+    for r in range(world):
+        lens, odt = meta[r]
+        if not lens:
+            continue
+        if r == src:
+            pieces = outs
+        else:
+            buf = torch.empty(sum(lens), dtype=odt, device=device)
+            dist.recv(buf, src=r, group=group)
+            pieces, at = [], 0
+            for n in lens:
+                pieces.append(buf[at:at + n])
+                at += n
+        for i, p in zip(parts[r], pieces):
+            result[i] = p
+    return result
