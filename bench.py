@@ -251,13 +251,12 @@ def lm_bench(dev, rank, world, dist, batch, reps=2, task="se", n_enroll=0):
     ms_decode = 1e3 * (best - short) / (283 - 2)
     ms_prefill = 1e3 * short - 2 * ms_decode
     # the prefill's dense GEMMs (adapter + 12 layers of QKV / O / SwiGLU over B x prompt rows) against the fp32 matrix peak - north_star's
-    # "MFMA utilisation for the LM GEMMs": per-launch HIP events inside the library around a generate of 1 + 0 tokens
+    # "MFMA utilisation for the LM GEMMs": per-launch HIP events inside the library around a generate of 1 + 1 tokens
     import ctypes as C
 
     lib = qa.load_library()
-    mel0 = torch.zeros(batch, 0, 80)
-    lib.qa_profile_begin()
-    lm.generate(task, mel0 if enr is not None else None, enr, mel0, mix, global_length=0, do_sample=False)
+    lib.qa_profile_begin()  # only the prefill runs on conv_gemm (the decode steps are GEMV launches): 1 + 1 tokens keep every output non-empty
+    lm.generate(task, mel1 if enr is not None else None, enr, mel1, mix, global_length=1, do_sample=False)
     torch.cuda.synchronize(dev)
     prof = (C.c_double * 12)()
     lib.qa_profile_end(prof, 12)

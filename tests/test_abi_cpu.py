@@ -25,6 +25,28 @@ def test_header_symbols_are_exported_and_bound(qa_lib):
     assert qa_lib.qa_version() == 102
 
 
+def test_knob_table_is_enumerable_settable_and_documented(qa_lib):
+    """csrc/knobs.h: every tuning switch is a row of one table - enumerable through the C-ABI, settable at run time, initialised from
+    the environment variable of its name, and listed in INTEGRATION.md."""
+    from unified_audio_amd import _lib
+
+    rows = _lib.knobs()
+    assert {"QA_SERIAL", "QA_LSTM_PERSISTENT", "QA_LM_UNFUSED", "QA_GEMM_CFG", "QA_LM_CHAINS"} <= set(rows)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name, (value, default, text) in rows.items():
+        assert name.startswith("QA_") and text and f"`{name}`" in doc, f"{name} is not documented in INTEGRATION.md"
+        if name not in os.environ:
+            assert value == default, name
+    old = _lib.set_knob("QA_GEMM_CFG", 2)
+    assert _lib.get_knob("QA_GEMM_CFG") == 2 and _lib.set_knob("QA_GEMM_CFG", old) == 2
+    with pytest.raises(_lib.QuarkAudioError):
+        _lib.set_knob("QA_NO_SUCH_KNOB", 1)
+    csrc = os.path.join(ROOT, "unified_audio_amd", "csrc")
+    for f in os.listdir(csrc):  # the library reads the environment in ONE place (api.cpp: the knob table and QA_GEMM_SHAPES)
+        if f != "api.cpp":
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+
+
 def test_struct_layouts_match_header(qa_lib):
     from unified_audio_amd import _lib
 

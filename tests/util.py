@@ -58,12 +58,12 @@ def act_ref(v, code):
 # graphs): the codes of another implementation must EQUAL the oracle's except where the oracle's own decision is a
 # near-tie.  `emb` is the ORACLE's RVQ input (so both are judged on identical context); the HIP path's embedding differs
 # from it by < STAGE_TOL relative RMS, which moves a squared distance difference by at most ~ 2 |delta| |e1 - e2|, hence
-# the tolerance below (8 x the per-stage bar, relative to the mean squared norm of the inputs).
-CODE_TIE_TOL = 4e-4
+# a tolerance relative to the mean squared norm of the inputs; r02's 4e-4 / 2 % were population bounds far above anything observed.
+CODE_TIE_TOL = 5e-5  # 10 x the largest excess the round-3 GPU suite observed (5.1e-6 over 56 audits / 5 004 vectors, no accepted flip)
 AUDIT_LOG = []  # (n_vectors, flip fraction, largest accepted relative gap, largest relative excess) per audit: printed by conftest's summary
 
 
-def audit_codes(emb, cb, got, want, rel_tol=CODE_TIE_TOL, max_flip_frac=0.02):
+def audit_codes(emb, cb, got, want, rel_tol=CODE_TIE_TOL, max_flip_frac=0.002):
     """emb [n, D] float32 (oracle RVQ input), cb [Q, K, D], got / want [n, Q] int64.  Returns the fraction of vectors
     whose stream left the oracle's at an (accepted) near-tie.  Raises on any decisive mismatch."""
     import numpy as np

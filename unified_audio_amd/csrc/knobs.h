@@ -34,10 +34,9 @@ namespace qa {
     X(LM_NT_O, "QA_LM_NT_O", 0, "column-tile width of the o_proj GEMV")                                                          \
     X(LM_NT_GU, "QA_LM_NT_GU", 0, "column-tile width of the gate/up GEMV")                                                       \
     X(LM_NT_DOWN, "QA_LM_NT_DOWN", 0, "column-tile width of the down GEMV")                                                      \
-    X(LM_MLP_FUSED, "QA_LM_MLP_FUSED", 1, "decode step: gate/up + SwiGLU + down in one launch emitting K-slice partials, summed by a reduce launch (0: gate/up and down launches)") \
-    X(LM_PICK_FOLD, "QA_LM_PICK_FOLD", 1, "decode step: greedy pick folded into the next step's first launch")                   \
-    X(LM_ATT_SPLIT, "QA_LM_ATT_SPLIT", 0, "decode step: keys per attention split (0: 256)")                                      \
-    X(LM_CHAINS, "QA_LM_CHAINS", 0, "generate: number of concurrent sub-batch chains for B > 32 (0: auto)")
+    X(LM_MLP_FUSED, "QA_LM_MLP_FUSED", 1, "decode step: gate/up + SwiGLU + down of 16 activation columns per workgroup in one launch emitting K-slice partials, summed by a reduce launch (0: separate gate/up and down launches; 2: 8 columns per workgroup)") \
+    X(LM_ATT_SPLIT, "QA_LM_ATT_SPLIT", 0, "decode step: keys per workgroup of the single-query attention, at most 4 splits (0: 256)")  \
+    X(LM_CHAINS, "QA_LM_CHAINS", 0, "generate: number of concurrent chains of <= 32 sequences on internal streams (0: ceil(B / 32))")
 
 enum Knob {
 #define QA_KNOB_ENUM(id, name, def, doc) K_##id,
