@@ -31,9 +31,11 @@ for step in "$@"; do
   echo "=== $step" | tee -a $O/session.log
   case "$kind" in
     tests)
-      sel=""; [ -n "$rest" ] && { case "$rest" in *.py*) sel="$rest" ;; *) sel="-k $rest" ;; esac; }
-      case "$sel" in *.py*) tgt="$sel" ;; *) tgt="tests $sel" ;; esac
-      ( time timeout 1500 python -m pytest $tgt -q -m gpu 2>&1 | tail -25 ) 2>&1 | tee -a $O/tests.log ;;
+      case "$rest" in
+        "") ( time timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -25 ) 2>&1 | tee -a $O/tests.log ;;
+        *.py*) ( time timeout 1500 python -m pytest $rest -q -m gpu 2>&1 | tail -25 ) 2>&1 | tee -a $O/tests.log ;;
+        *) ( time timeout 1500 python -m pytest tests -q -m gpu -k "$rest" 2>&1 | tail -25 ) 2>&1 | tee -a $O/tests.log ;;
+      esac ;;
     bench)
       ( time timeout 900 python bench.py $rest > $O/bench.json 2> $O/bench.err ) 2>&1 | tail -3 | tee -a $O/session.log
       python - <<PY 2>&1 | tee -a $O/session.log

@@ -24,6 +24,7 @@
 namespace qa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // BIAS: WavLM's gated relative position bias (transformers WavLMAttention.forward): score(i, j) += gate[b, head, i] *
 // relbias[head][clamp(j - i, -R, R) + R]; the bucket function saturates below R, so the clamp is exact.
@@ -109,7 +110,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     // HD = 64 at n_keys = 1500: half of all outputs differed from run to run (tools/diag_attention.py on the -DQA_ATT_OLD build,
     // profiles/r03_attention_determinism.txt).  Caught by the at-size parity test of H-Codec 2.0 (tests/test_at_size_gpu.py).
     constexpr int NLD = HD / 32;  // float4 per thread per operand: 32 keys x HD floats over 256 threads
-    float4 kreg[NLD], vreg[NLD];
+    // native vector type, NOT float4: with float4 staging arrays hipcc funnels the unconditional loads through ONE temporary register
+    // quad into AGPRs for HD >= 96 (global_load; s_waitcnt vmcnt(0); v_accvgpr_write - eight serialized round trips per tile: 110 -> 177 us
+    // per launch at HD = 128); ext_vector_type values stay in VGPRs and the loads stay in flight
+    f32x4 kreg[NLD], vreg[NLD];
     auto fetch = [&](int kt) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
@@ -117,16 +121,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
             const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
 #ifdef QA_ATT_OLD  // diagnostic build only (tools/variants.py): the round-2 predicated prefetch
             const int key = kt * 32 + row;
-            kreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            kreg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             vreg[j] = kreg[j];
             if (key < n_keys) {
-                kreg[j] = *reinterpret_cast<const float4*>(kb + (long long)key * ldkv + c4);
-                vreg[j] = *reinterpret_cast<const float4*>(vb + (long long)key * ldkv + c4);
+                kreg[j] = *reinterpret_cast<const f32x4*>(kb + (long long)key * ldkv + c4);
+                vreg[j] = *reinterpret_cast<const f32x4*>(vb + (long long)key * ldkv + c4);
             }
 #else
             const int key = min(kt * 32 + row, n_keys - 1);
-            kreg[j] = *reinterpret_cast<const float4*>(kb + (long long)key * ldkv + c4);
-            vreg[j] = *reinterpret_cast<const float4*>(vb + (long long)key * ldkv + c4);
+            kreg[j] = *reinterpret_cast<const f32x4*>(kb + (long long)key * ldkv + c4);
+            vreg[j] = *reinterpret_cast<const f32x4*>(vb + (long long)key * ldkv + c4);
 #endif
         }
     };
@@ -137,8 +141,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         for (int j = 0; j < NLD; ++j) {
             const int i = tid + 256 * j;
             const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
-            *reinterpret_cast<float4*>(sK + row * LD + c4) = kreg[j];
-            *reinterpret_cast<float4*>(sV + row * LD + c4) = vreg[j];
+            *reinterpret_cast<f32x4*>(sK + row * LD + c4) = kreg[j];
+            *reinterpret_cast<f32x4*>(sV + row * LD + c4) = vreg[j];
         }
         __syncthreads();
         if (kt + 1 < n_tiles) fetch(kt + 1);
