@@ -107,6 +107,7 @@ struct ConvParams {
     int prologue, act, post_act;
     int algo_n, algo_k;  // un-padded N / K for the algorithmic FLOP count (0 = use N / K)
     int xcd_swizzle;
+    int panel;  // > 0: column panels of this many tiles, row tiles fastest inside a panel (QA_GEMM_PANEL)
     int in_rep;  // >1: the input is read as if every frame were repeated in_rep times (x.repeat_interleave, H-Codec 2.0 decoder)
     int vec_epi;  // epilogue may move float4 (set by launch_conv_gemm from N, leading dimensions and pointer alignment)
     unsigned rep_magic, rep_one;  // r / in_rep == __umulhi(r, rep_magic) + r * rep_one  (branch-free; set by launch_conv_gemm)

@@ -133,8 +133,20 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(cons
             p.gamma = p.gamma2;
         }
     }
-    const int m0 = (tile / tiles_n) * BM;
-    const int n0 = (tile % tiles_n) * BN;
+    int tm_i = tile / tiles_n, tn_i = tile % tiles_n;
+    if (p.panel > 0 && tiles_n > p.panel) {
+        // 2-D blocking of the tile order (QA_GEMM_PANEL = PW): column panels of PW tiles, row tiles fastest inside a panel, so that the
+        // ~96 tiles an XCD has in flight form a ~(96 / PW) x PW block - the bytes they pull through the XCD's L2 scale with
+        // rows + columns of the block instead of with one of them
+        const int tiles_m = (p.M + BM - 1) / BM;
+        const int per_panel = tiles_m * p.panel;
+        const int panel = tile / per_panel, r = tile - panel * per_panel;
+        const int pw = min(p.panel, tiles_n - panel * p.panel);
+        tm_i = r / pw;
+        tn_i = panel * p.panel + (r - tm_i * pw);
+    }
+    const int m0 = tm_i * BM;
+    const int n0 = tn_i * BN;
 
     const int ld_row = tid / (BK / 4);          // 0..RPP-1
     const int ld_c4 = (tid % (BK / 4)) * 4;     // float offset inside the BK-wide K chunk
@@ -419,6 +431,7 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
     const int swz = (int)knob(K_GEMM_XCD);
     ConvParams q = p;
     q.xcd_swizzle = swz;
+    q.panel = (int)knob(K_GEMM_PANEL);
     // frame / in_rep by multiply-high: exact for frame * in_rep < 2^32 (frames of one clip are < 2^31 / ldx)
     auto al16 = [](const void* ptr) { return ((uintptr_t)ptr % 16) == 0; };
     q.vec_epi = p.N % 4 == 0 && p.ldy % 4 == 0 && al16(p.y) && (!p.bias || al16(p.bias)) && (!p.gamma || al16(p.gamma)) &&

@@ -16,6 +16,7 @@ namespace qa {
     X(GEMM_BK16_MIN_TILES, "QA_GEMM_BK16_MIN_TILES", 384, "fewest tiles of a launch that take BK = 16")                          \
     X(GEMM_LINEAR, "QA_GEMM_LINEAR", 1, "table-free K loop for ksize-1 layers")                                                  \
     X(GEMM_XCD, "QA_GEMM_XCD", 1, "XCD-aware tile order")                                                                        \
+    X(GEMM_PANEL, "QA_GEMM_PANEL", 8, "conv_gemm tile order: column panels of this many tiles, row tiles fastest inside a panel (0: column tiles fastest over the whole row; 8: +4 % on N >= 4096 shapes, +1.2 % on H-Codec 2.0)") \
     X(GEMM_GROUPED, "QA_GEMM_GROUPED", 0, "H-Codec 1.5: 1 = the two aggregator stacks as ONE grouped launch per layer op on one stream (measured: 147.1 ms against 143.5 for the default, the two stacks on two streams)") \
     X(ATT_DEBUG, "QA_ATT_DEBUG", 0, "attention_kernel debug bits: 1 always rescale, 2 extra barrier per tile, 4 wait for the prefetch at once") \
     X(SEANET_FUSED, "QA_SEANET_FUSED", 1, "fused conv0 + first SEANet residual block")                                           \
