@@ -329,7 +329,7 @@ def bicodec_bench(dev, batch, reps=3):
                                    f"250 semantic + 32 global tokens -> {batch} x 80 000 samples @16 kHz", "dtype": "f32"}}
 
 
-def unise_pipeline_bench(dev, batches=6, seg_per_batch=16, lm_graph=True):
+def unise_pipeline_bench(dev, batches=6, seg_per_batch=16, lm_graph=False):
     """BASELINE configs[2] END TO END over consecutive batches: Model.test_step 'se' (WavLM -> LLM_SFT.generate -> BiCodec.detokenize) on
     `batches` x `seg_per_batch` independent 5 s segments through UniSE.enhance (one stage after the other, one micro-batch at a
     time) and through UniSE.enhance_pipelined (the three stages of consecutive micro-batches on three streams).  Published shapes of
@@ -363,7 +363,7 @@ def unise_pipeline_bench(dev, batches=6, seg_per_batch=16, lm_graph=True):
             "sequential": {"value": n * 5.0 / seq_t, "ms_per_batch": 1e3 * seq_t / batches}, "batches": batches, "segments_per_batch": seg_per_batch,
             "bit_identical_to_sequential": bool(same),
             "config": {"workload": f"UniSE 'se' end to end, {batches} consecutive batches of {seg_per_batch} x 5 s segments, WavLM | AR-LM | BiCodec of "
-                                   "consecutive batches on three streams (UniSE.enhance_pipelined), LM on replayed step graphs", "dtype": "f32"}}
+                                   "consecutive batches on three streams (UniSE.enhance_pipelined)", "dtype": "f32"}}
 
 
 def rvq_bench(dev, lib, n_vec, Q, K=1024, D=512, reps=5):

@@ -25,6 +25,7 @@ namespace qa {
     X(LSTM_GRAPH, "QA_LSTM_GRAPH", 1, "replay the T step launches of an LSTM call from a cached hipGraph")                       \
     X(LSTM_SPLIT, "QA_LSTM_SPLIT", 0, "1: two concurrent half-batch step chains (measured slower)")                              \
     X(LSTM_PERSISTENT, "QA_LSTM_PERSISTENT", -1, "persistent recurrence kernel: -1 auto (d >= 1536), 0 off, 1 on for every supported width") \
+    X(LSTM_PERSISTENT_U, "QA_LSTM_PERSISTENT_U", 0, "persistent recurrence: hidden units per workgroup (0: the fewest that fit the CU count; 8 halves the workgroups at d = 1024)") \
     X(LSTM_CUS, "QA_LSTM_CUS", 0, "H-Codec 1.0 / 1.5 encode: CUs reserved (hipExtStreamCreateWithCUMask) for the encoder's LSTM step launches while the semantic encoder runs on the other CUs (0: off, everything on one stream)") \
     X(LSTM_SPIN_LIMIT, "QA_LSTM_SPIN_LIMIT", 1 << 21, "persistent recurrence: polls of a barrier word before the barrier is declared broken") \
     X(LSTM_FAULT, "QA_LSTM_FAULT", 0, "1 (tests): the persistent kernel's barrier waits for a workgroup that does not exist, like a starved launch") \

@@ -380,8 +380,11 @@ static int launch_lstm_persistent(const float* xw, const float* w_hh_ug, float* 
     // U hidden units per workgroup: the fewest that keep d / U workgroups (a multiple of the 8 barrier groups) <= CU count
     int U = 1;
     while (U <= 8 && (d % U || d / U > P.cus || (d / U) % 8)) ++U;
+    // QA_LSTM_PERSISTENT_U: more units per workgroup than necessary (fewer workgroups: a cheaper barrier, more MFMA work each)
+    const int u_force = (int)knob(K_LSTM_PERSISTENT_U);
+    if (u_force > U && u_force <= 8 && d % u_force == 0 && (d / u_force) % 8 == 0) U = u_force;
     const int NT = (4 * U + 15) / 16;
-    if (U > 8 || NT > 2 || (NT == 2 && d != 1536) || (NT == 1 && d == 1536)) return QA_OK;
+    if (U > 8 || NT > 2 || (NT == 1 && d == 1536)) return QA_OK;
     // QA_LSTM_FAULT (tests): the barrier waits for one workgroup more than exists, i.e. what a starved launch looks like
     const int nwg = d / U, ngrp = 8, per_grp = nwg / ngrp + (knob(K_LSTM_FAULT) ? 1 : 0);
     const unsigned spin_limit = (unsigned)std::max<long long>(64, std::min<long long>(knob(K_LSTM_SPIN_LIMIT), 1LL << 30));
@@ -397,8 +400,11 @@ static int launch_lstm_persistent(const float* xw, const float* w_hh_ug, float* 
     hipLaunchKernelGGL((lstm_persistent_kernel<MT, NT_, NI>), dim3(nwg), dim3(512), 0, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, U, sy, ngrp, per_grp, P.err_dev, spin_limit)
         const bool two = bn > 16;
         if (d == 1536) { if (two) QA_LP(2, 2, 12); else QA_LP(1, 2, 12); }
+        else if (d == 1024 && NT == 2) { if (two) QA_LP(2, 2, 8); else QA_LP(1, 2, 8); }
         else if (d == 1024) { if (two) QA_LP(2, 1, 8); else QA_LP(1, 1, 8); }
+        else if (d == 768 && NT == 2) { if (two) QA_LP(2, 2, 6); else QA_LP(1, 2, 6); }
         else if (d == 768) { if (two) QA_LP(2, 1, 6); else QA_LP(1, 1, 6); }
+        else if (NT == 2) { if (two) QA_LP(2, 2, 4); else QA_LP(1, 2, 4); }
         else { if (two) QA_LP(2, 1, 4); else QA_LP(1, 1, 4); }
 #undef QA_LP
         QA_LAUNCH_CHECK();
