@@ -34,7 +34,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
                                                         long long ldkv, long long kv_bstride, float* __restrict__ out,
                                                         long long ldo, int n_q, int n_keys, float scale, int causal,
                                                         const float* __restrict__ gate, const float* __restrict__ relbias, int R,
-                                                        int context, int q_pos0, int ring_end, int dbg) {
+                                                        int context, int q_pos0, int ring_end, int dbg_arg) {
+#if defined(QA_ATT_DBG) && QA_ATT_DBG == 0
+    constexpr int dbg = 0;
+    (void)dbg_arg;
+#else
+    const int dbg = dbg_arg;
+#endif
     constexpr int LD = HD + 4;
     constexpr int DT = HD / 32;
     constexpr int NG = HD / 8;
@@ -44,7 +50,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     // `wave` through readfirstlane: every wave-level test below (tile skips, mask tests) is then a SCALAR branch.  As a VGPR value
     // hipcc lowers them to exec-masked regions, and exec-masked VMEM next to register-staged prefetches is where ROCm 7.2 mis-tracks
     // outstanding loads (see fetch()).
-#ifdef QA_ATT_OLD
+#if defined(QA_ATT_OLD) || (defined(QA_ATT_SWAVE) && QA_ATT_SWAVE == 0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #else
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);

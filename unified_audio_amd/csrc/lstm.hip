@@ -21,7 +21,9 @@
 // barrier (~4 us) - so it is the default only where the stream dominates (d >= 1536: H-Codec 2.0); QA_LSTM_PERSISTENT=0 / 1 forces
 // it off / on for every supported width.  It needs every workgroup resident at once: two such kernels sharing the device (two
 // handles driven concurrently on two streams) starve each other until the spin bound trips; that sets an error word in pinned host
-// memory which the next launch_lstm call on the device reports (QA_ERR_HIP) - run concurrent handles with QA_LSTM_PERSISTENT=0.
+// memory.  The model graph that launched the kernel waits for its stream before returning, reads the word (lstm_persistent_collect) and
+// re-runs the call on the per-step kernels (hcodec.cpp run_graph_checked), so the failing call itself returns valid results; the device
+// then stops choosing the persistent kernel by itself.  Run concurrent handles with QA_LSTM_PERSISTENT=0 to avoid the time-out altogether.
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
