@@ -1217,7 +1217,14 @@ static int ensure_masked_streams(qa_hcodec* h) {
 template <typename F>
 static int run_graph_checked(qa_hcodec* h, Ctx& c, F&& graph) {
     const unsigned long long before = lstm_persistent_count(h->device);
-    QA_TRY(graph());
+    {
+        const int st = graph();
+        if (st != QA_OK) {  // error path only: internal streams (aggregator side stream, CU-masked streams) may still run out of the workspace
+            c.lstm_stream = nullptr;
+            (void)hipDeviceSynchronize();
+            return st;
+        }
+    }
     if (lstm_persistent_count(h->device) == before) return QA_OK;
     bool failed = false;
     QA_TRY(lstm_persistent_collect(h->device, c.stream, &failed));

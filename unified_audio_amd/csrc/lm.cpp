@@ -676,8 +676,13 @@ static int lm_generate_impl(qa_lm* lm, int32_t task, const float* enroll_feats, 
     QA_TRY(ensure_ws(lm, c.arena.peak()));
     c.dry = false;
     c.arena.begin(lm->ws, lm->ws_cap);
-    return generate_graph(lm, c, task, enroll_feats, (int)n_enroll, mix_feats, (int)n_mix, (int)B, global_length, semantic_length,
-                          (long long*)global_ids, (long long*)semantic_ids, sc);
+    const int st = generate_graph(lm, c, task, enroll_feats, (int)n_enroll, mix_feats, (int)n_mix, (int)B, global_length, semantic_length,
+                                  (long long*)global_ids, (long long*)semantic_ids, sc);
+    if (st != QA_OK) {  // an error between the fork and the join of a multi-chain call: the chains' streams may still be running out of the
+        c.stream = static_cast<hipStream_t>(stream);  // workspace the next call re-uses - quiesce them (error path only)
+        for (hipStream_t cs : lm->chain_streams) (void)hipStreamSynchronize(cs);
+    }
+    return st;
 }
 
 int qa_lm_generate(qa_lm* lm, int32_t task, const float* enroll_feats, int64_t n_enroll, const float* mix_feats,
