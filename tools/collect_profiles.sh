@@ -2,7 +2,7 @@
 # Round evidence on the GPU box: rocprofv3 kernel trace of the bench command (product mode and QA_SERIAL=1), three PMC passes
 # (FETCH_SIZE | WRITE_SIZE | MFMA busy), the LM generate trace; summaries into gpurun_out/$1/ (raw traces stay in /tmp).
 # The PMC summary json is stamped with the hash of conv_gemm.hip so that bench.py refuses to quote it for another build.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 3 --warmup 1 --lean"
