@@ -29,7 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // BIAS: WavLM's gated relative position bias (transformers WavLMAttention.forward): score(i, j) += gate[b, head, i] *
 // relbias[head][clamp(j - i, -R, R) + R]; the bucket function saturates below R, so the clamp is exact.
 template <int HD, bool BIAS>
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, long long ldq,
+__global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ q, long long ldq,
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         long long ldkv, long long kv_bstride, float* __restrict__ out,
                                                         long long ldo, int n_q, int n_keys, float scale, int causal,
