@@ -312,3 +312,26 @@ def test_sampled_chains_key_the_rng_by_the_global_sequence_index(qa_lib, gpu_dev
     for g, s in outs[1:]:
         assert torch.equal(g, outs[0][0]) and torch.equal(s, outs[0][1])
     assert outs[0][1][0].tolist() != outs[0][1][33].tolist() or outs[0][0][0].tolist() != outs[0][0][33].tolist()
+
+
+def test_config4_on_one_gpu_64_tse_segments_match_the_reference_golden(qa_lib, gpu_device):
+    """BASELINE configs[3] placed on ONE GPU: 64 TSE segments (prompt 503, KV 786) = two concurrent chains of 32.  The batch is the
+    reference-golden case `lm_config4_tse_b8` eight times over, so every block of 8 sequences must reproduce the token stream the
+    reference's own LLM_SFT.generate produced (smallest top-2 gap of the golden 3.2e-4: no near-tie, the streams must be identical)."""
+    import os
+
+    import numpy as np
+
+    from oracle import gen_golden_lm as GG
+
+    name = "lm_config4_tse_b8"
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    spec, sd, task, mix, enr, S, G = GG.case_tensors(name)
+    _, lm = _model(spec, GG.CASES[name][1], gpu_device)
+    rep = 8
+    mix64, enr64 = mix.repeat(rep, 1, 1).to(gpu_device), enr.repeat(rep, 1, 1).to(gpu_device)
+    mel = torch.zeros(mix64.shape[0], S, 80)
+    gids, sids = lm.generate(task, mel, enr64, mel, mix64, global_length=G, do_sample=False)
+    want_g, want_s = torch.from_numpy(g["global_ids"].astype(np.int64)), torch.from_numpy(g["semantic_ids"].astype(np.int64))
+    for r in range(rep):
+        assert torch.equal(gids[8 * r:8 * r + 8].cpu(), want_g) and torch.equal(sids[8 * r:8 * r + 8].cpu(), want_s), r
