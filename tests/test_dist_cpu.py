@@ -26,6 +26,39 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _run_ranks(target, world, args_of_rank, timeout=180):
+    """Start one process per rank, wait, and NEVER leave a child behind: a rank that hangs (rendezvous, a collective nobody else
+    entered) is killed by PID and the test fails, instead of pytest blocking at exit on a non-daemon child."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args_of_rank) + (q,), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    import time
+
+    deadline = time.monotonic() + timeout
+    for p in procs:
+        p.join(max(0.0, deadline - time.monotonic()))
+    hung = [i for i, p in enumerate(procs) if p.exitcode is None]
+    for p in procs:
+        if p.exitcode is None:
+            p.kill()
+            p.join(10)
+    assert not hung, f"ranks {hung} did not finish within {timeout} s"
+    codes = [p.exitcode for p in procs]
+    assert codes == [0] * world, f"rank exit codes {codes}"
+    return q
+
+
+def _drain(q, n):
+    out = []
+    for _ in range(n):
+        assert not q.empty(), f"only {len(out)} of {n} ranks reported"
+        out.append(q.get())
+    return out
+
+
 def _worker(rank, world, port, n_clips, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -55,16 +88,8 @@ def _worker(rank, world, port, n_clips, q):
 
 @pytest.mark.parametrize("world,n_clips", [(2, 5), (2, 4), (3, 2)])
 def test_scatter_run_gather_gloo(world, n_clips):
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_clips, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    assert q.get() == "ok"
+    q = _run_ranks(_worker, world, (n_clips,))
+    assert not q.empty() and q.get() == "ok"
 
 
 def _worker_ragged_tail(rank, world, port, q):
@@ -96,16 +121,8 @@ def _worker_ragged_tail(rank, world, port, q):
 
 
 def test_gather_pads_data_dependent_trailing_dims_gloo():
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker_ragged_tail, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    assert q.get() == "ok"
+    q = _run_ranks(_worker_ragged_tail, 2, ())
+    assert not q.empty() and q.get() == "ok"
 
 
 # --------------------------------------------------------------------------------------- ragged lists, failure propagation
@@ -160,16 +177,8 @@ def _ragged_worker(rank, world, port, lengths, fail_rank, q):
 
 
 def _run_ragged(world, lengths, fail_rank=-1):
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = _free_port()
-    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, lengths, fail_rank, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0, "a rank hung or crashed"
-    return sorted(q.get() for _ in range(world))
+    q = _run_ranks(_ragged_worker, world, (lengths, fail_rank))
+    return sorted(_drain(q, world))
 
 
 @pytest.mark.parametrize("world,lengths", [(2, [50, 7, 33, 12, 90]), (3, [5, 400, 17, 17, 230, 1, 64]), (3, [9, 4])])
@@ -208,13 +217,5 @@ def _fail_worker(rank, world, port, q):
 
 
 def test_run_sharded_propagates_a_rank_failure_gloo():
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = _free_port()
-    procs = [ctx.Process(target=_fail_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    assert sorted(q.get() for _ in range(2)) == ["ShardError", "ShardError"]
+    q = _run_ranks(_fail_worker, 2, ())
+    assert sorted(_drain(q, 2)) == ["ShardError", "ShardError"]

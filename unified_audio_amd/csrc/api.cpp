@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include <atomic>
 #include <cstring>
 #include <mutex>
 
@@ -25,22 +26,22 @@ const KnobRow g_knob_rows[K_COUNT] = {
     QA_KNOB_TABLE(QA_KNOB_ROW)
 #undef QA_KNOB_ROW
 };
-long long g_knob_val[K_COUNT];
+std::atomic<long long> g_knob_val[K_COUNT];  // relaxed: a knob is an independent integer, read at launch time by any host thread
 std::once_flag g_knob_once;
 void knob_init() {
     for (int i = 0; i < K_COUNT; ++i) {
         const char* e = getenv(g_knob_rows[i].name);
-        g_knob_val[i] = (e && *e) ? atoll(e) : g_knob_rows[i].def;
+        g_knob_val[i].store((e && *e) ? atoll(e) : g_knob_rows[i].def, std::memory_order_relaxed);
     }
 }
 }  // namespace
 long long knob(Knob k) {
     std::call_once(g_knob_once, knob_init);
-    return g_knob_val[k];
+    return g_knob_val[k].load(std::memory_order_relaxed);
 }
 void knob_set(Knob k, long long v) {
     std::call_once(g_knob_once, knob_init);
-    g_knob_val[k] = v;
+    g_knob_val[k].store(v, std::memory_order_relaxed);
 }
 int raise_dynamic_lds(const void* kernel, int bytes) {
     static std::mutex mu;

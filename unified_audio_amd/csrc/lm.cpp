@@ -524,7 +524,7 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
                 StepGraph& g = lm->graphs[2 * i + which];
                 uint64_t key = 0x51ull;
                 for (uint64_t v : {(uint64_t)(uintptr_t)lm->ws, (uint64_t)B, (uint64_t)nc, (uint64_t)ch.b0, (uint64_t)ch.B, (uint64_t)cap, (uint64_t)L,
-                                   (uint64_t)G, (uint64_t)S, (uint64_t)Ne, (uint64_t)lo, (uint64_t)width, (uint64_t)keep, (uint64_t)sc.do_sample,
+                                   (uint64_t)G, (uint64_t)S, (uint64_t)Ne, (uint64_t)Nm, (uint64_t)(enroll != nullptr), (uint64_t)lo, (uint64_t)width, (uint64_t)keep, (uint64_t)sc.do_sample,
                                    (uint64_t)sc.top_k, (uint64_t)(sc.top_p * 1e6f), (uint64_t)(sc.temperature * 1e6f)})
                     key = mix_key(key, v);
                 if (!g.exec || g.key != key) {

@@ -102,7 +102,9 @@ def run_sharded(fn: Callable[..., Sequence[torch.Tensor]], inputs: Sequence[Opti
     # ranks with an empty shard need the output signature to build their (empty) contribution
     sigs = [None] * dist.get_world_size(group)
     dist.all_gather_object(sigs, template, group=group)
-    sig = next(s for s in sigs if s is not None)
+    sig = next((s for s in sigs if s is not None), None)
+    if sig is None:  # no rank had an item: there is no output signature to build the (empty) results from
+        raise ValueError("run_sharded: the inputs hold no items")
     if outs is None:
         outs = [torch.empty((0,) + shp, dtype=dt, device=device) for shp, dt in sig]
     pads = list(pad_values) if pad_values is not None else [0] * len(outs)
