@@ -142,6 +142,7 @@ def test_persistent_lstm_forced_on_matches_per_step_and_torch(qa_lib, gpu_device
     sc = torch.randint(0, ospec.codebook_size, (B, ospec.num_quantizers, T // 2), generator=gen)
     name = "decoder.prior_net.3.layers.0.self_attn.rnn"
     outs = {}
+    knob("QA_LSTM_XCD", 0)  # d = 512 / 768 would take the XCD-local kernel first
     for mode in (1, 0):
         knob("QA_LSTM_PERSISTENT", mode)
         wav = codec.decode(ac.to(gpu_device), sc.to(gpu_device))
@@ -156,6 +157,50 @@ def test_persistent_lstm_forced_on_matches_per_step_and_torch(qa_lib, gpu_device
     errs = (rel_err(outs[1][0].view(B, T, d)[:2], dtaps[name]), rel_err(outs[0][0].view(B, T, d)[:2], dtaps[name]),
             rel_err(codec.tap("dec.prior_res1").view(B, T, d)[:2], dtaps["dec.prior_res1"].transpose(1, 2)))
     assert errs[0] < STAGE_TOL, errs
+
+
+@pytest.mark.parametrize("d,B,T,mode", [(512, 32, 500, 1), (512, 32, 500, 2), (768, 20, 250, 2), (512, 5, 64, 2), (768, 33, 96, 1)])
+def test_xcd_local_lstm_matches_per_step_and_torch(qa_lib, gpu_device, knob, capfd, d, B, T, mode):
+    """QA_LSTM_XCD (lstm.hip lstm_xcd_kernel): W_hh resident in the registers of every XCD's 32 CUs, the sequences dealt to the XCDs,
+    the step barrier inside one XCD.  Inside a real transformer layer of the codec: rnn tap and waveform against the per-step
+    kernels (another K-split order: close, not bit-identical) and against torch.nn.LSTM through the oracle's transformer; B = 33 takes
+    two launches, B = 5 leaves three XCD teams without a sequence."""
+    import dataclasses
+
+    import unified_audio_amd as qa
+
+    heads = d // 64
+    ospec = dataclasses.replace(R.SPEC_10, dec_dim=d, dec_heads=heads, dec_layers=1, convnext_layers=1, dec_inter=2 * d)
+    sd = synth.hcodec10_state_dict(90 + d // 256, ospec)
+    kw = {f: getattr(ospec, f) for f in ospec.__dataclass_fields__}
+    codec = qa.Codec(None, None, None, spec=qa.HCodecSpec(**kw), device=gpu_device).load_state_dict(sd)
+    codec.enable_taps(True)
+    gen = torch.Generator().manual_seed(d + B)
+    ac = torch.randint(0, ospec.codebook_size, (B, ospec.num_quantizers, T // 2), generator=gen)
+    sc = torch.randint(0, ospec.codebook_size, (B, ospec.num_quantizers, T // 2), generator=gen)
+    name = "decoder.prior_net.3.layers.0.self_attn.rnn"
+    outs = {}
+    capfd.readouterr()
+    for m in (mode, 0):
+        knob("QA_LSTM_XCD", m)
+        wav = codec.decode(ac.to(gpu_device), sc.to(gpu_device))
+        torch.cuda.synchronize()
+        outs[m] = (codec.tap(name).clone(), wav.clone())
+    assert "re-running the call on the per-step kernels" not in capfd.readouterr().err, "the XCD-local kernel timed out and fell back"
+    assert torch.isfinite(outs[mode][0]).all()
+    ab = (rel_err(outs[mode][0], outs[0][0]), rel_err(outs[mode][1], outs[0][1]))
+    assert max(ab) < 1e-5, ab
+    assert ab[0] > 0.0, "bit-identical taps: the XCD-local kernel did not run (it reduces K in another order)"
+    dtaps = {}
+    with torch.no_grad():
+        R.decode(sd, ac[:2], sc[:2], ospec, dtaps)
+    err = rel_err(outs[mode][0].view(B, T, d)[:2], dtaps[name])
+    assert err < STAGE_TOL, err
+    # a sequence's recurrence does not depend on the batch it rides in: rows 0 .. 2 alone == the same rows of the batch
+    knob("QA_LSTM_XCD", mode)
+    codec.decode(ac[:3].to(gpu_device), sc[:3].to(gpu_device))
+    torch.cuda.synchronize()
+    assert torch.equal(codec.tap(name).view(3, T, d), outs[mode][0].view(B, T, d)[:3])
 
 
 def test_persistent_lstm_barrier_timeout_is_recovered_in_the_same_call(qa_lib, gpu_device, knob, capfd):
@@ -175,20 +220,27 @@ def test_persistent_lstm_barrier_timeout_is_recovered_in_the_same_call(qa_lib, g
     gen = torch.Generator().manual_seed(3)
     ac = torch.randint(0, 1024, (4, 4, 20), generator=gen).to(gpu_device)
     sc = torch.randint(0, 1024, (4, 4, 20), generator=gen).to(gpu_device)
+    knob("QA_LSTM_XCD", 0)
     knob("QA_LSTM_PERSISTENT", 0)
     want = codec.decode(ac, sc).clone()
-    knob("QA_LSTM_PERSISTENT", 1)
-    ok = codec.decode(ac, sc).clone()
-    assert rel_err(ok, want) < 1e-5
-    capfd.readouterr()
-    knob("QA_LSTM_FAULT", 1)
-    knob("QA_LSTM_SPIN_LIMIT", 4096)
-    got = codec.decode(ac, sc).clone()
-    torch.cuda.synchronize()
-    assert "re-running the call on the per-step kernels" in capfd.readouterr().err
-    assert torch.equal(got, want)  # the re-run IS the per-step path
+    for which in ("QA_LSTM_PERSISTENT", "QA_LSTM_XCD"):  # both in-launch recurrences share the error word and the re-run
+        knob("QA_LSTM_FAULT", 0)
+        knob("QA_LSTM_SPIN_LIMIT", 1 << 21)
+        knob(which, 1)
+        ok = codec.decode(ac, sc).clone()
+        assert rel_err(ok, want) < 1e-5 and not torch.equal(ok, want), which
+        capfd.readouterr()
+        knob("QA_LSTM_FAULT", 1)
+        knob("QA_LSTM_SPIN_LIMIT", 4096)
+        got = codec.decode(ac, sc).clone()
+        torch.cuda.synchronize()
+        assert "re-running the call on the per-step kernels" in capfd.readouterr().err, which
+        assert torch.equal(got, want), which  # the re-run IS the per-step path
+        knob(which, 0)
     knob("QA_LSTM_FAULT", 0)
-    assert torch.equal(codec.decode(ac, sc), ok)  # and the device is usable afterwards
+    knob("QA_LSTM_SPIN_LIMIT", 1 << 21)
+    knob("QA_LSTM_XCD", 1)
+    assert torch.equal(codec.decode(ac, sc), ok)  # and the device is usable afterwards (an injected fault does not degrade it)
 
 
 def test_wavlm_base_plus_16x5s_matches_oracle(qa_lib, gpu_device):

@@ -24,8 +24,10 @@ namespace qa {
     X(RVQ_LEGACY, "QA_RVQ_LEGACY", 0, "1: the single-launch RVQ search kernel instead of distance GEMM + pick")                   \
     X(LSTM_GRAPH, "QA_LSTM_GRAPH", 1, "replay the T step launches of an LSTM call from a cached hipGraph")                       \
     X(LSTM_SPLIT, "QA_LSTM_SPLIT", 0, "1: two concurrent half-batch step chains (measured slower)")                              \
+    X(LSTM_GROUP_ROWS, "QA_LSTM_GROUP_ROWS", 0, "per-step LSTM kernel: batch rows per workgroup group (blockIdx.y); 0 = every workgroup serves all rows of the call. 16 halves the h_{t-1} slice a workgroup pulls at B = 32; results are bit-identical for every value") \
     X(LSTM_PERSISTENT, "QA_LSTM_PERSISTENT", -1, "persistent recurrence kernel: -1 auto (d >= 1536), 0 off, 1 on for every supported width") \
     X(LSTM_PERSISTENT_U, "QA_LSTM_PERSISTENT_U", 0, "persistent recurrence: hidden units per workgroup (0: the fewest that fit the CU count; 8 halves the workgroups at d = 1024)") \
+    X(LSTM_XCD, "QA_LSTM_XCD", 1, "XCD-local LSTM recurrence for d = 512 / 768 (one launch, W_hh in the registers of every XCD's 32 CUs, sequences dealt to the XCDs, 32-member step barrier per XCD): 0 off (the per-step kernels; use it when several handles drive one device concurrently), 1 agent-scope hand-off forms, 2 XCD-local forms (h stores that stay in the XCD's L2; H-Codec 1.0: 42.7 against 43.3 ms)") \
     X(LSTM_CUS, "QA_LSTM_CUS", 0, "H-Codec 1.0 / 1.5 encode: CUs reserved (hipExtStreamCreateWithCUMask) for the encoder's LSTM step launches while the semantic encoder runs on the other CUs (0: off, everything on one stream)") \
     X(LSTM_SPIN_LIMIT, "QA_LSTM_SPIN_LIMIT", 1 << 21, "persistent recurrence: polls of a barrier word before the barrier is declared broken") \
     X(LSTM_FAULT, "QA_LSTM_FAULT", 0, "1 (tests): the persistent kernel's barrier waits for a workgroup that does not exist, like a starved launch") \

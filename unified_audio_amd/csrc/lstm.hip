@@ -39,11 +39,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int MT, int NI>
 __global__ __launch_bounds__(512) void lstm_step_kernel(const float* __restrict__ xw, const float* __restrict__ w_hh,
                                                         float* __restrict__ h_out, float* __restrict__ c_state, int B,
-                                                        int T, int d, int t) {
+                                                        int T, int d, int t, int rows) {
     __shared__ float part[8][MT][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16;  // first permuted gate row of this workgroup
     const int li = lane & 15, kq = lane >> 4;
+    // QA_LSTM_GROUP_ROWS: gridDim.y groups of `rows` batch rows each - a workgroup then pulls only its group's slice of h_{t-1}
+    // (rows x d x 4 bytes instead of B x d x 4); a row's arithmetic does not depend on the grouping (bit-identical)
+    if (rows > 0) {
+        const int b0 = blockIdx.y * rows;
+        xw += (long long)b0 * T * 4 * d;
+        h_out += (long long)b0 * T * d;
+        c_state += (long long)b0 * d;
+        B = min(rows, B - b0);
+    }
 
     f32x4 acc[MT];
 #pragma unroll
@@ -129,8 +138,9 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const float* __restrict_
 }
 
 template <int MT>
-static void launch_step(int ni, dim3 grid, hipStream_t s, const float* xw, const float* w, float* h, float* c, int bn, int T, int d, int t) {
-#define QA_LS(NI) hipLaunchKernelGGL((lstm_step_kernel<MT, NI>), grid, dim3(512), 0, s, xw, w, h, c, bn, T, d, t)
+static void launch_step(int ni, dim3 grid, hipStream_t s, const float* xw, const float* w, float* h, float* c, int bn, int T, int d, int t,
+                        int rows) {
+#define QA_LS(NI) hipLaunchKernelGGL((lstm_step_kernel<MT, NI>), grid, dim3(512), 0, s, xw, w, h, c, bn, T, d, t, rows)
     switch (ni) {
         case 1: QA_LS(1); break;
         case 2: QA_LS(2); break;
@@ -143,16 +153,23 @@ static void launch_step(int ni, dim3 grid, hipStream_t s, const float* xw, const
 #undef QA_LS
 }
 
+// QA_LSTM_GROUP_ROWS = r > 0: the batch rows of a step launch are dealt to ceil(bn / r) workgroup groups (blockIdx.y)
+static int lstm_group_rows(int bn) {
+    const int r = (int)knob(K_LSTM_GROUP_ROWS);
+    return (r > 0 && r < bn) ? std::min(r, 64) : 0;
+}
+
 // One chain of T dependent step launches for batch rows [0, bn) of the given buffers.
 static void lstm_chain(const float* xw_b, const float* w_hh_ug, float* h_b, float* c_b, int bn, int T, int d, int t, hipStream_t s) {
     const int ni = (d % 128 == 0) ? d / 128 : 0;
-    const int mt = (int)ceil_div(bn, 16);
-    const dim3 grid(d / 4);
+    const int rows = lstm_group_rows(bn);  // 0: one group of all bn rows
+    const int mt = (int)ceil_div(rows ? rows : bn, 16);
+    const dim3 grid(d / 4, rows ? (unsigned)ceil_div(bn, rows) : 1u);
     switch (mt) {
-        case 1: launch_step<1>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
-        case 2: launch_step<2>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
-        case 3: launch_step<3>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
-        default: launch_step<4>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
+        case 1: launch_step<1>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t, rows); break;
+        case 2: launch_step<2>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t, rows); break;
+        case 3: launch_step<3>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t, rows); break;
+        default: launch_step<4>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t, rows); break;
     }
 }
 
@@ -340,6 +357,130 @@ __global__ __launch_bounds__(512) void lstm_persistent_kernel(const float* __res
     if (epi) c_state[(long long)eb * d + unit] = c_reg;
 }
 
+// ------------------------------------------------------------------------------------------------ XCD-local recurrence (QA_LSTM_XCD)
+// The batch rows of an LSTM are independent recurrences and a d <= 768 W_hh (4.2 / 9.4 MB) fits the REGISTERS of the 32 CUs of ONE
+// XCD.  So: one launch for all T steps, one workgroup per CU, and the workgroups that land on XCD x (s_getreg HW_REG_XCC_ID - read
+// from the hardware, never assumed from blockIdx) form TEAM x.  Every team keeps its own copy of the whole W_hh in registers (a
+// workgroup: U = d / 32 hidden units = 4 U gate rows) and runs the sequences b = x, x + 8, x + 16, ... of the call all by itself: no
+// exchange between XCDs at all, a step's h_t travels through the team's own L2, and the per-step barrier has 32 participants on one
+// counter in that L2 (~1 us) instead of 256 over the fabric (~4 us).  Matrix work on v_mfma_f32_4x4x1_16b_f32: block = hidden unit
+// (A: lane & 3 = gate row of the unit, resident weights), B: lane & 3 = sequence of the team (h_{t-1} from LDS); lane (unit, q) ends
+// with the unit's 4 gate pre-activations of sequence q.  K is split over the waves; partials meet in LDS in a fixed order
+// (deterministic; a row's arithmetic does not depend on the batch).
+//   QA_LSTM_XCD = 1: agent-scope forms (sc1 write-through h stores, agent atomics) - valid wherever the workgroups sit;
+//   QA_LSTM_XCD = 2: XCD-local forms (plain h stores that stay in the team's L2, workgroup-scope atomic executed in that L2) -
+//                    relies on what defines a team: its members share one L2.  Loads of h / the counter bypass L1 (sc1) in both.
+// Needs 32 resident workgroups per XCD: a surplus or missing member trips the bounded spins -> error word -> the calling model
+// graph re-runs the call on the per-step kernels (run_graph_checked), exactly like lstm_persistent_kernel.
+enum { SX_SLOT = 0, SX_CNT = 8 };  // sync lines: team slot counters [8], team arrive counters [8], SY_ERR
+
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 15u;
+}
+
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void lstm_xcd_kernel(const float* __restrict__ xw, const float* __restrict__ w_hh, float* h_out,
+                                                               float* __restrict__ c_state, int B, int T, unsigned* sy, int per_team,
+                                                               int n_teams, unsigned* err_host, unsigned spin_limit, int fast) {
+    constexpr int U = D / 32, R = 4 * U, RG = (R + 63) / 64, KS = NW / RG, KW = D / KS, NQ = 4, LDH = D + 4;
+    static_assert(NW % RG == 0 && D % KS == 0 && KW % 4 == 0 && NQ * D / 4 == NW * 64, "lstm_xcd: shape does not tile");
+    __shared__ __attribute__((aligned(16))) float s_h[NQ][LDH];           // h_{t-1} of the team's sequences (rows 16 B apart in bank phase)
+    __shared__ __attribute__((aligned(16))) float s_part[KS][RG * 64][4];  // [K slice][unit * 4 + q][gate]
+    __shared__ int s_ctl[3];
+    extern __shared__ float s_pad[];  // unused: sized by the host so that ONE workgroup fits a CU
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rg = wave % RG, ks = wave / RG;
+    if (tid == 0) {
+        const unsigned x = xcc_id();
+        s_ctl[0] = (int)x;
+        s_ctl[1] = x < 8u ? (int)__hip_atomic_fetch_add(sy + (SX_SLOT + x) * SY_STRIDE, 1u, QA_RLX) : per_team;
+    }
+    __syncthreads();
+    const int team = s_ctl[0], slot = s_ctl[1];
+    unsigned* err = sy + SY_ERR * SY_STRIDE;
+    if (slot >= per_team || team >= n_teams) {  // a 33rd workgroup on this XCD (so another team is short of one): nobody can finish
+        if (tid == 0) {
+            __hip_atomic_store(err, 1u, QA_RLX);
+            __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    const int nq = min(NQ, (B - team + n_teams - 1) / n_teams);  // this team's sequences: b = team + n_teams * q
+    if (nq <= 0) return;
+    unsigned* cnt = sy + (SX_CNT + team) * SY_STRIDE;
+
+    // resident weights: lane = gate row (unit-major, gate-minor: the load-time permutation) of row group rg, K slice ks
+    const int lrow = rg * 64 + lane;
+    float wreg[KW];
+    {
+        const float* wrow = w_hh + ((long long)slot * R + min(lrow, R - 1)) * D + ks * KW;
+#pragma unroll
+        for (int j = 0; j < KW / 4; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(wrow + 4 * j);
+            wreg[4 * j] = v.x; wreg[4 * j + 1] = v.y; wreg[4 * j + 2] = v.z; wreg[4 * j + 3] = v.w;
+        }
+    }
+    // epilogue lane (waves of K slice 0): hidden unit of the team slot, sequence q
+    const int q = lane & 3, ul = rg * 16 + (lane >> 2);
+    const bool epi = ks == 0 && ul < U && q < nq;
+    const int unit = slot * U + min(ul, U - 1);
+    const int eb = team + n_teams * min(q, nq - 1);
+    // staging share of this thread: one float4 of h_{t-1}
+    const int sq = tid / (D / 4), sc4 = tid % (D / 4);
+    const int sb = team + n_teams * min(sq, nq - 1);
+    float c_reg = 0.f;
+    for (int t = 0; t < T; ++t) {
+        float4 xg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (epi) xg = *reinterpret_cast<const float4*>(xw + ((long long)eb * T + t) * 4 * D + (long long)unit * 4);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {
+            if (tid == 0) s_ctl[2] = lstm_spin_until(cnt, (unsigned)(per_team * t), err, err_host, spin_limit) ? 1 : 0;
+            __syncthreads();
+            if (!s_ctl[2]) break;  // uniform: a broken barrier ends the call for the whole workgroup (the error words are set)
+            asm volatile("" ::: "memory");
+            f32x4 hv = lstm_load_sc1_b128(h_out + ((long long)sb * T + (t - 1)) * D + 4 * sc4);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv)::"memory");
+            *reinterpret_cast<f32x4*>(&s_h[sq][4 * sc4]) = hv;
+            __syncthreads();
+            const float* hq = &s_h[q][ks * KW];
+#pragma unroll
+            for (int j = 0; j < KW / 4; ++j) {
+                const float4 hb = *reinterpret_cast<const float4*>(hq + 4 * j);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * j], hb.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * j + 1], hb.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * j + 2], hb.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * j + 3], hb.w, acc, 0, 0, 0);
+            }
+            *reinterpret_cast<f32x4*>(&s_part[ks][rg * 64 + lane][0]) = acc;
+            __syncthreads();
+        }
+        if (epi) {
+            f32x4 g = {xg.x, xg.y, xg.z, xg.w};
+            if (t > 0) {
+#pragma unroll
+                for (int k = 0; k < KS; ++k) g += *reinterpret_cast<const f32x4*>(&s_part[k][rg * 64 + lane][0]);
+            }
+            const float ig = sigmoid_f(g[0]), fg = sigmoid_f(g[1]), gg = tanhf(g[2]), og = sigmoid_f(g[3]);
+            c_reg = fg * c_reg + ig * gg;
+            unsigned* dst = reinterpret_cast<unsigned*>(h_out + ((long long)eb * T + t) * D + unit);
+            const unsigned hbits = __float_as_uint(og * tanhf(c_reg));
+            if (fast) __hip_atomic_store(dst, hbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // plain store: stays in this XCD's L2
+            else __hip_atomic_store(dst, hbits, QA_RLX);                                               // sc1: write-through
+        }
+        if (t + 1 < T) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing waves drain before the workgroup reports the step done
+            __syncthreads();
+            if (tid == 0) {
+                if (fast) (void)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else (void)__hip_atomic_fetch_add(cnt, 1u, QA_RLX);
+            }
+        }
+    }
+    if (epi) c_state[(long long)eb * D + unit] = c_reg;
+}
+
 namespace {
 struct LstmPersistentDev {
     unsigned* sync = nullptr;      // LSTM_SYNC_RING blocks of SY_WORDS * SY_STRIDE words (device)
@@ -357,14 +498,8 @@ thread_local bool t_lstm_per_step = false;  // lstm_force_per_step(): the re-run
 int lstm_persistent_mode() { return (int)knob(K_LSTM_PERSISTENT); }
 }  // namespace
 
-// returns QA_OK and sets *done = true when the persistent kernel took the call; *done = false: shape / device not eligible
-static int launch_lstm_persistent(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d, hipStream_t s,
-                                  int dev, bool* done) {
-    *done = false;
-    const int mode = lstm_persistent_mode();
-    LstmPersistentDev& P = g_lstm_p[dev];
-    if (t_lstm_per_step || mode == 0 || (mode < 0 && (d < 1536 || P.degraded))) return QA_OK;
-    if (!(d == 1536 || d == 1024 || d == 768 || d == 512) || T < 2) return QA_OK;
+// sync ring + error word of a device (first use), and the backstop for a caller that did not collect an earlier failure
+static int lstm_persistent_prepare(LstmPersistentDev& P, int dev) {
     if (!P.sync) {
         QA_HIP(hipDeviceGetAttribute(&P.cus, hipDeviceAttributeMultiprocessorCount, dev));
         QA_HIP(hipMalloc(reinterpret_cast<void**>(&P.sync), sizeof(unsigned) * LSTM_SYNC_RING * SY_WORDS * SY_STRIDE));
@@ -379,6 +514,18 @@ static int launch_lstm_persistent(const float* xw, const float* w_hh_ug, float* 
                   "needs every workgroup resident at once - another persistent kernel was sharing the device; set QA_LSTM_PERSISTENT=0", dev);
         return QA_ERR_HIP;
     }
+    return QA_OK;
+}
+
+// returns QA_OK and sets *done = true when the persistent kernel took the call; *done = false: shape / device not eligible
+static int launch_lstm_persistent(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d, hipStream_t s,
+                                  int dev, bool* done) {
+    *done = false;
+    const int mode = lstm_persistent_mode();
+    LstmPersistentDev& P = g_lstm_p[dev];
+    if (t_lstm_per_step || mode == 0 || (mode < 0 && (d < 1536 || P.degraded))) return QA_OK;
+    if (!(d == 1536 || d == 1024 || d == 768 || d == 512) || T < 2) return QA_OK;
+    QA_TRY(lstm_persistent_prepare(P, dev));
     // U hidden units per workgroup: the fewest that keep d / U workgroups (a multiple of the 8 barrier groups) <= CU count
     int U = 1;
     while (U <= 8 && (d % U || d / U > P.cus || (d / U) % 8)) ++U;
@@ -409,6 +556,43 @@ static int launch_lstm_persistent(const float* xw, const float* w_hh_ug, float* 
         else if (NT == 2) { if (two) QA_LP(2, 2, 4); else QA_LP(1, 2, 4); }
         else { if (two) QA_LP(2, 1, 4); else QA_LP(1, 1, 4); }
 #undef QA_LP
+        QA_LAUNCH_CHECK();
+        ++P.launches;
+    }
+    *done = true;
+    return QA_OK;
+}
+
+// QA_LSTM_XCD: the XCD-local recurrence for the widths whose W_hh fits one XCD's registers (d = 512 / 768); *done as above
+static int launch_lstm_xcd(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d, hipStream_t s, int dev,
+                           bool* done) {
+    *done = false;
+    const int mode = (int)knob(K_LSTM_XCD);
+    LstmPersistentDev& P = g_lstm_p[dev];
+    if (t_lstm_per_step || mode <= 0 || P.degraded || !(d == 512 || d == 768) || T < 2) return QA_OK;
+    QA_TRY(lstm_persistent_prepare(P, dev));
+    const int per_team = 32, n_teams = P.cus / per_team;
+    if (n_teams < 1 || n_teams > 8 || P.cus % per_team) return QA_OK;
+    const unsigned spin_limit = (unsigned)std::max<long long>(64, std::min<long long>(knob(K_LSTM_SPIN_LIMIT), 1LL << 30));
+    const int pad = 96 * 1024;  // dynamic LDS nobody touches: ONE workgroup per CU, so the grid spreads 32 per XCD
+    const int fault = knob(K_LSTM_FAULT) ? 1 : 0;
+    if (d == 512) QA_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(lstm_xcd_kernel<512, 8>), pad));
+    else QA_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(lstm_xcd_kernel<768, 12>), pad));
+    for (int b0 = 0; b0 < B; b0 += 4 * n_teams) {
+        const int bn = std::min(4 * n_teams, B - b0);
+        const float* xw_b = xw + (long long)b0 * T * 4 * d;
+        float* h_b = h_out + (long long)b0 * T * d;
+        float* c_b = c_state + (long long)b0 * d;
+        unsigned* sy = P.sync + (size_t)P.next * SY_WORDS * SY_STRIDE;
+        P.next = (P.next + 1) % LSTM_SYNC_RING;
+        QA_HIP(hipMemsetAsync(sy, 0, sizeof(unsigned) * SY_WORDS * SY_STRIDE, s));
+        const dim3 grid((unsigned)(n_teams * per_team));
+        if (d == 512)
+            hipLaunchKernelGGL((lstm_xcd_kernel<512, 8>), grid, dim3(512), pad, s, xw_b, w_hh_ug, h_b, c_b, bn, T, sy, per_team + fault, n_teams,
+                               P.err_dev, spin_limit, mode >= 2 ? 1 : 0);
+        else
+            hipLaunchKernelGGL((lstm_xcd_kernel<768, 12>), grid, dim3(768), pad, s, xw_b, w_hh_ug, h_b, c_b, bn, T, sy, per_team + fault, n_teams,
+                               P.err_dev, spin_limit, mode >= 2 ? 1 : 0);
         QA_LAUNCH_CHECK();
         ++P.launches;
     }
@@ -469,6 +653,8 @@ int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_st
     if (eager) return lstm_launch_steps(xw, w_hh_ug, h_out, c_state, B, T, d, s, nullptr, nullptr, nullptr);
     {
         bool done = false;
+        QA_TRY(launch_lstm_xcd(xw, w_hh_ug, h_out, c_state, B, T, d, s, dev, &done));
+        if (done) return QA_OK;
         QA_TRY(launch_lstm_persistent(xw, w_hh_ug, h_out, c_state, B, T, d, s, dev, &done));
         if (done) return QA_OK;
     }
@@ -481,7 +667,7 @@ int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_st
     hipStream_t side = serial_mode() ? nullptr : g_lstm_side[dev];  // qa_set_serial(1): every kernel alone on the device
     if (!use_graph || T < 8) return lstm_launch_steps(xw, w_hh_ug, h_out, c_state, B, T, d, s, side, g_lstm_ev[dev][0], g_lstm_ev[dev][1]);
     LstmGraph* hit = nullptr;
-    const int split_tag = side ? 1 : 0;
+    const int split_tag = (side ? 1 : 0) | ((int)std::max<long long>(0, std::min<long long>(knob(K_LSTM_GROUP_ROWS), 64)) << 1);
     for (LstmGraph& g : g_lstm_graphs)
         if (g.xw == xw && g.w == w_hh_ug && g.h == h_out && g.c == c_state && g.B == B && g.T == T && g.d == d && g.device == dev &&
             g.split == split_tag)
