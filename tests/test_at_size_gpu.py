@@ -7,6 +7,7 @@ path against its oracle.  configs[1] (H-Codec 1.5, 32 x 10 s) lives in tests/tes
   * the persistent recurrence forced on for d = 512 / 768 / 1024 with B > 16 (ADVICE r02);
   * configs[2]'s other two stages at size: wavlm-base-plus and the published BiCodec on 16 x 5 s segments.
 """
+import os
 import time
 
 import pytest
@@ -201,6 +202,45 @@ def test_xcd_local_lstm_matches_per_step_and_torch(qa_lib, gpu_device, knob, cap
     codec.decode(ac[:3].to(gpu_device), sc[:3].to(gpu_device))
     torch.cuda.synchronize()
     assert torch.equal(codec.tap(name).view(3, T, d), outs[mode][0].view(B, T, d)[:3])
+
+
+@pytest.mark.skipif(not os.environ.get("QA_TEST_EXPERIMENTAL"), reason="QA_LSTM_TEAM was written without GPU time left (round 3): run with QA_TEST_EXPERIMENTAL=1, then A/B it")
+@pytest.mark.parametrize("B,T", [(32, 500), (17, 64), (40, 32)])
+def test_team_lstm_d1024_matches_per_step_and_torch(qa_lib, gpu_device, knob, capfd, B, T):
+    """QA_LSTM_TEAM (lstm.hip lstm_team_kernel): the d = 1024 recurrence (H-Codec 1.5 decoder) on 4 teams of 64 workgroups with W_hh in
+    registers - same checks as the XCD-local kernel's test."""
+    import dataclasses
+
+    import unified_audio_amd as qa
+
+    d = 1024
+    ospec = dataclasses.replace(R.SPEC_10, dec_dim=d, dec_heads=d // 64, dec_layers=1, convnext_layers=1, dec_inter=2 * d)
+    sd = synth.hcodec10_state_dict(94, ospec)
+    kw = {f: getattr(ospec, f) for f in ospec.__dataclass_fields__}
+    codec = qa.Codec(None, None, None, spec=qa.HCodecSpec(**kw), device=gpu_device).load_state_dict(sd)
+    codec.enable_taps(True)
+    gen = torch.Generator().manual_seed(d + B)
+    ac = torch.randint(0, ospec.codebook_size, (B, ospec.num_quantizers, T // 2), generator=gen)
+    sc = torch.randint(0, ospec.codebook_size, (B, ospec.num_quantizers, T // 2), generator=gen)
+    name = "decoder.prior_net.3.layers.0.self_attn.rnn"
+    outs = {}
+    capfd.readouterr()
+    for m in (1, 0):
+        knob("QA_LSTM_TEAM", m)
+        wav = codec.decode(ac.to(gpu_device), sc.to(gpu_device))
+        torch.cuda.synchronize()
+        outs[m] = (codec.tap(name).clone(), wav.clone())
+    assert "re-running the call on the per-step kernels" not in capfd.readouterr().err, "the team kernel timed out and fell back"
+    ab = (rel_err(outs[1][0], outs[0][0]), rel_err(outs[1][1], outs[0][1]))
+    assert max(ab) < 1e-5 and ab[0] > 0.0, ab
+    dtaps = {}
+    with torch.no_grad():
+        R.decode(sd, ac[:2], sc[:2], ospec, dtaps)
+    assert rel_err(outs[1][0].view(B, T, d)[:2], dtaps[name]) < STAGE_TOL
+    knob("QA_LSTM_TEAM", 1)
+    codec.decode(ac[:3].to(gpu_device), sc[:3].to(gpu_device))
+    torch.cuda.synchronize()
+    assert torch.equal(codec.tap(name).view(3, T, d), outs[1][0].view(B, T, d)[:3])
 
 
 def test_persistent_lstm_barrier_timeout_is_recovered_in_the_same_call(qa_lib, gpu_device, knob, capfd):

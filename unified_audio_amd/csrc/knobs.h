@@ -28,6 +28,7 @@ namespace qa {
     X(LSTM_PERSISTENT, "QA_LSTM_PERSISTENT", -1, "persistent recurrence kernel: -1 auto (d >= 1536), 0 off, 1 on for every supported width") \
     X(LSTM_PERSISTENT_U, "QA_LSTM_PERSISTENT_U", 0, "persistent recurrence: hidden units per workgroup (0: the fewest that fit the CU count; 8 halves the workgroups at d = 1024)") \
     X(LSTM_XCD, "QA_LSTM_XCD", 1, "XCD-local LSTM recurrence for d = 512 / 768 (one launch, W_hh in the registers of every XCD's 32 CUs, sequences dealt to the XCDs, 32-member step barrier per XCD): 0 off (the per-step kernels; use it when several handles drive one device concurrently), 1 agent-scope hand-off forms, 2 XCD-local forms (h stores that stay in the XCD's L2; H-Codec 1.0: 42.7 against 43.3 ms)") \
+    X(LSTM_TEAM, "QA_LSTM_TEAM", 0, "1: the team recurrence for d = 1024 (4 teams of 64 workgroups, W_hh resident in registers, 8 sequences per team, agent-scope hand-offs): written at the end of round 3, NOT YET MEASURED - off until its parity test (QA_TEST_EXPERIMENTAL) and an A/B have run") \
     X(LSTM_CUS, "QA_LSTM_CUS", 0, "H-Codec 1.0 / 1.5 encode: CUs reserved (hipExtStreamCreateWithCUMask) for the encoder's LSTM step launches while the semantic encoder runs on the other CUs (0: off, everything on one stream)") \
     X(LSTM_SPIN_LIMIT, "QA_LSTM_SPIN_LIMIT", 1 << 21, "persistent recurrence: polls of a barrier word before the barrier is declared broken") \
     X(LSTM_FAULT, "QA_LSTM_FAULT", 0, "1 (tests): the persistent kernel's barrier waits for a workgroup that does not exist, like a starved launch") \

@@ -484,6 +484,121 @@ __global__ __launch_bounds__(NW * 64, 1) void lstm_xcd_kernel(const float* __res
     if (epi) c_state[(long long)eb * D + unit] = c_reg;
 }
 
+// ------------------------------------------------------------------------------------------------ team recurrence for wider layers
+// QA_LSTM_TEAM (default 0: NOT YET MEASURED - written at the end of round 3 without GPU time left; tests/test_at_size_gpu.py holds its
+// parity test behind QA_TEST_EXPERIMENTAL).  The XCD-local idea for widths whose W_hh does not fit ONE XCD's registers: a team is PT
+// workgroups (64 at d = 1024: two XCDs' worth of register files per copy of W_hh, four teams; 128 at d = 1536, two teams), team =
+// blockIdx % n_teams, slot = blockIdx / n_teams - nothing depends on where a workgroup lands, because every hand-off uses the
+// agent-scope forms (sc1 write-through stores, drained vmcnt, agent atomic on the team's counter, sc1 loads).  A team runs
+// 4 SG sequences (two MFMA chains per wave at SG = 2: the resident A operand is used twice), so B = 32 at d = 1024 is ONE launch.
+// Per step: one PT-member counter + 4 SG x d x 4 bytes of h per workgroup + KW x SG 4x4x1 MFMAs per wave (MFMA floor at
+// d = 1024 / B = 32: 2 us per step; the per-step kernel takes 9.7 us).
+template <int D, int NW, int PT, int SG>
+__global__ __launch_bounds__(NW * 64, 1) void lstm_team_kernel(const float* __restrict__ xw, const float* __restrict__ w_hh, float* h_out,
+                                                                float* __restrict__ c_state, int B, int T, unsigned* sy, int n_teams, int fault,
+                                                                unsigned* err_host, unsigned spin_limit) {
+    constexpr int U = D / PT, R = 4 * U, KS = NW, KW = D / KS, NQ = 4 * SG, LDH = D + 4, F4 = NQ * D / 4 / (NW * 64);
+    static_assert(R <= 64 && D % PT == 0 && D % KS == 0 && KW % 4 == 0 && (NQ * D / 4) % (NW * 64) == 0, "lstm_team: shape does not tile");
+    __shared__ __attribute__((aligned(16))) float s_h[NQ][LDH];
+    __shared__ __attribute__((aligned(16))) float s_part[KS][64][SG][4];  // [K slice][unit * 4 + q][sequence group][gate]
+    __shared__ int s_ok;
+    extern __shared__ float s_pad[];  // unused: sized by the host so that ONE workgroup fits a CU
+    const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+    const int team = blockIdx.x % n_teams, slot = blockIdx.x / n_teams;
+    unsigned* err = sy + SY_ERR * SY_STRIDE;
+    const int nq = min(NQ, (B - team + n_teams - 1) / n_teams);  // this team's sequences: b = team + n_teams * q
+    if (nq <= 0) return;
+    unsigned* cnt = sy + (SX_CNT + team) * SY_STRIDE;
+    const unsigned members = (unsigned)(PT + fault);  // QA_LSTM_FAULT: wait for a member that does not exist
+
+    float wreg[KW];
+    {
+        const float* wrow = w_hh + ((long long)slot * R + min(lane, R - 1)) * D + ks * KW;
+#pragma unroll
+        for (int j = 0; j < KW / 4; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(wrow + 4 * j);
+            wreg[4 * j] = v.x; wreg[4 * j + 1] = v.y; wreg[4 * j + 2] = v.z; wreg[4 * j + 3] = v.w;
+        }
+    }
+    const int q = lane & 3, ul = lane >> 2;
+    const bool epi_wave = ks == 0 && ul < U;
+    const int unit = slot * U + min(ul, U - 1);
+    float c_reg[SG];
+#pragma unroll
+    for (int g = 0; g < SG; ++g) c_reg[g] = 0.f;
+    for (int t = 0; t < T; ++t) {
+        float4 xg[SG];
+#pragma unroll
+        for (int g = 0; g < SG; ++g) {
+            xg[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (epi_wave && q + 4 * g < nq)
+                xg[g] = *reinterpret_cast<const float4*>(xw + ((long long)(team + n_teams * (q + 4 * g)) * T + t) * 4 * D + (long long)unit * 4);
+        }
+        f32x4 acc[SG];
+#pragma unroll
+        for (int g = 0; g < SG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {
+            if (tid == 0) s_ok = lstm_spin_until(cnt, members * (unsigned)t, err, err_host, spin_limit) ? 1 : 0;
+            __syncthreads();
+            if (!s_ok) break;
+            asm volatile("" ::: "memory");
+            f32x4 hv[F4];
+#pragma unroll
+            for (int i = 0; i < F4; ++i) {
+                const int f = tid + i * NW * 64, sq = f / (D / 4), sc4 = f % (D / 4);
+                hv[i] = lstm_load_sc1_b128(h_out + ((long long)(team + n_teams * min(sq, nq - 1)) * T + (t - 1)) * D + 4 * sc4);
+            }
+#pragma unroll
+            for (int i = 0; i < F4; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[i])::"memory");
+#pragma unroll
+            for (int i = 0; i < F4; ++i) {
+                const int f = tid + i * NW * 64;
+                *reinterpret_cast<f32x4*>(&s_h[f / (D / 4)][4 * (f % (D / 4))]) = hv[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < KW / 4; ++j) {
+#pragma unroll
+                for (int g = 0; g < SG; ++g) {
+                    const float4 hb = *reinterpret_cast<const float4*>(&s_h[q + 4 * g][ks * KW + 4 * j]);
+                    acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * j], hb.x, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * j + 1], hb.y, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * j + 2], hb.z, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * j + 3], hb.w, acc[g], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < SG; ++g) *reinterpret_cast<f32x4*>(&s_part[ks][lane][g][0]) = acc[g];
+            __syncthreads();
+        }
+        if (epi_wave) {
+#pragma unroll
+            for (int g = 0; g < SG; ++g) {
+                if (q + 4 * g >= nq) continue;
+                f32x4 gt = {xg[g].x, xg[g].y, xg[g].z, xg[g].w};
+                if (t > 0) {
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) gt += *reinterpret_cast<const f32x4*>(&s_part[k][lane][g][0]);
+                }
+                const float ig = sigmoid_f(gt[0]), fg = sigmoid_f(gt[1]), gg = tanhf(gt[2]), og = sigmoid_f(gt[3]);
+                c_reg[g] = fg * c_reg[g] + ig * gg;
+                const int b = team + n_teams * (q + 4 * g);
+                __hip_atomic_store(reinterpret_cast<unsigned*>(h_out + ((long long)b * T + t) * D + unit), __float_as_uint(og * tanhf(c_reg[g])), QA_RLX);
+            }
+        }
+        if (t + 1 < T) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) (void)__hip_atomic_fetch_add(cnt, 1u, QA_RLX);
+        }
+    }
+    if (epi_wave) {
+#pragma unroll
+        for (int g = 0; g < SG; ++g)
+            if (q + 4 * g < nq) c_state[(long long)(team + n_teams * (q + 4 * g)) * D + unit] = c_reg[g];
+    }
+}
+
 namespace {
 struct LstmPersistentDev {
     unsigned* sync = nullptr;      // LSTM_SYNC_RING blocks of SY_WORDS * SY_STRIDE words (device)
@@ -603,6 +718,35 @@ static int launch_lstm_xcd(const float* xw, const float* w_hh_ug, float* h_out, 
     return QA_OK;
 }
 
+// QA_LSTM_TEAM: the team recurrence for d = 1024 (4 teams of 64 workgroups) - see lstm_team_kernel; *done as above
+static int launch_lstm_team(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d, hipStream_t s, int dev,
+                            bool* done) {
+    *done = false;
+    LstmPersistentDev& P = g_lstm_p[dev];
+    if (t_lstm_per_step || knob(K_LSTM_TEAM) <= 0 || P.degraded || d != 1024 || T < 2) return QA_OK;
+    QA_TRY(lstm_persistent_prepare(P, dev));
+    constexpr int PT = 64, SG = 2;
+    const int n_teams = P.cus / PT;
+    if (n_teams < 1 || n_teams > 8 || P.cus % PT) return QA_OK;
+    const unsigned spin_limit = (unsigned)std::max<long long>(64, std::min<long long>(knob(K_LSTM_SPIN_LIMIT), 1LL << 30));
+    const int pad = 64 * 1024;  // with 49 KB of static LDS: one workgroup per CU
+    const int fault = knob(K_LSTM_FAULT) ? 1 : 0;
+    QA_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(lstm_team_kernel<1024, 8, PT, SG>), pad));
+    const int per_launch = 4 * SG * n_teams;
+    for (int b0 = 0; b0 < B; b0 += per_launch) {
+        const int bn = std::min(per_launch, B - b0);
+        unsigned* sy = P.sync + (size_t)P.next * SY_WORDS * SY_STRIDE;
+        P.next = (P.next + 1) % LSTM_SYNC_RING;
+        QA_HIP(hipMemsetAsync(sy, 0, sizeof(unsigned) * SY_WORDS * SY_STRIDE, s));
+        hipLaunchKernelGGL((lstm_team_kernel<1024, 8, PT, SG>), dim3((unsigned)(n_teams * PT)), dim3(512), pad, s, xw + (long long)b0 * T * 4 * d,
+                           w_hh_ug, h_out + (long long)b0 * T * d, c_state + (long long)b0 * d, bn, T, sy, n_teams, fault, P.err_dev, spin_limit);
+        QA_LAUNCH_CHECK();
+        ++P.launches;
+    }
+    *done = true;
+    return QA_OK;
+}
+
 // ---- what the model graphs (hcodec.cpp) do about a timed-out barrier: a call that launched the persistent kernel waits for its
 // stream before returning, reads the error word, and - if a barrier broke - runs itself again on the per-step kernels, so the
 // call that HIT the failure still returns valid results (the error used to surface one call late, or never).
@@ -657,6 +801,8 @@ int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_st
     {
         bool done = false;
         QA_TRY(launch_lstm_xcd(xw, w_hh_ug, h_out, c_state, B, T, d, s, dev, &done));
+        if (done) return QA_OK;
+        QA_TRY(launch_lstm_team(xw, w_hh_ug, h_out, c_state, B, T, d, s, dev, &done));
         if (done) return QA_OK;
         QA_TRY(launch_lstm_persistent(xw, w_hh_ug, h_out, c_state, B, T, d, s, dev, &done));
         if (done) return QA_OK;
