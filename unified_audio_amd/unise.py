@@ -203,7 +203,7 @@ class UniSE:
                 ef = self.semantic_model(torch.cat(list(enrolls), dim=0))
             n_enr = enrolls[0].size(-1)
         nb = (n_seg + m - 1) // m
-        feats, toks, wavs, keep = [None] * nb, [None] * nb, [None] * nb, []
+        feats, toks, wavs = [None] * nb, [None] * nb, [None] * nb  # alive until the final join: nothing is freed under a stream
         ev_f = [torch.cuda.Event() for _ in range(nb)]
         ev_l = [torch.cuda.Event() for _ in range(nb)]
         old_graph = _lib.set_knob("QA_LM_GRAPH", 1) if lm_graph else None
@@ -245,7 +245,6 @@ class UniSE:
                         s.record_stream(s_dec)
                         toks[j] = (g, s)
                         ev_l[j].record(s_lm)
-                keep.append((feats, toks))
         finally:
             if old_graph is not None:
                 _lib.set_knob("QA_LM_GRAPH", old_graph)
