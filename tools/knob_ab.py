@@ -3,8 +3,10 @@ with qa_set_knob between timed blocks, and every output of every setting compare
 
     python tools/knob_ab.py --models 1.0,1.5 --knob QA_LSTM_GROUP_ROWS=0,16,8 [--steps 4] [--batch 32] [--seconds 10]
 
-Prints one line per (model, value): ms per encode+decode step (best and mean of --repeats blocks), and `identical` = codes and
-waveform equal to the first value's.  Several --knob arguments are swept one after the other (not as a product).
+Prints one line per (model, value): ms per encode+decode step (best and mean of --repeats blocks), `identical` = codes and
+waveform equal to the first value's, and a digest of the outputs.  Several --knob arguments are swept one after the other (not as a
+product).  --libs default,tools/_variants/X/libquarkaudio_hip.so repeats the sweep per library BUILD (tools/variants.py) and compares the
+digests across builds.
 """
 from __future__ import annotations
 
@@ -27,7 +29,29 @@ def main():
     ap.add_argument("--repeats", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--libs", default="", help="comma-separated library builds (tools/variants.py; 'default' = the product library): the whole "
+                    "sweep is repeated in one child process per build (QA_LIBRARY) and the digests of the outputs are compared")
     args = ap.parse_args()
+    if args.libs:
+        import subprocess
+
+        digests = {}
+        for lib in args.libs.split(","):
+            env = dict(os.environ)
+            if lib != "default":
+                env["QA_LIBRARY"] = os.path.abspath(lib)
+            else:
+                env.pop("QA_LIBRARY", None)
+            argv = [a for i, a in enumerate(sys.argv) if a != "--libs" and (i == 0 or sys.argv[i - 1] != "--libs") and not a.startswith("--libs=")]
+            out = subprocess.run([sys.executable] + argv, env=env, capture_output=True, text=True).stdout
+            for line in out.splitlines():
+                if line.startswith("H-Codec"):
+                    print(f"[{lib}] {line}", flush=True)
+                    key = line.split(": best")[0]
+                    digests.setdefault(key, []).append((lib, line.rsplit("digest=", 1)[-1]))
+        for key, lst in digests.items():
+            print(f"{key}: outputs of all builds identical = {len({d for _, d in lst}) == 1}")
+        return
 
     import unified_audio_amd as qa
     from unified_audio_amd import _lib, synth
@@ -80,6 +104,10 @@ def main():
                     codes = sum(int((a != b).sum()) for a, b in zip(out[:2], ref[:2])) / sum(a.numel() for a in out[:2])
                     wrel = float((out[2] - ref[2]).pow(2).mean().sqrt() / ref[2].pow(2).mean().sqrt())
                     note = f"  codes differing {codes:.5f}, waveform rel-RMS diff {wrel:.2e}, finite={bool(torch.isfinite(out[2]).all())}"
+                import hashlib
+
+                dig = hashlib.sha256(b"".join(o.cpu().numpy().tobytes() for o in out)).hexdigest()[:16]
+                note += f"  digest={dig}"
                 print(f"H-Codec {model} {B} x {args.seconds:g} s  {name}={v}: best {min(times):.2f} ms, mean {sum(times) / len(times):.2f} ms per step"
                       f"  ({B * T / sr / (min(times) * 1e-3):.0f} audio-s/s)  identical={same}{note}", flush=True)
             _lib.set_knob(name, default)
