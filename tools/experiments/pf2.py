@@ -15,13 +15,16 @@ bit-identical results.  Cost: the 4 staging float4 are live across the whole ite
 
 
 def transform(src: str) -> str:
+    # only the BK = 16 instances (4 workgroups per CU at <= 128 VGPRs: 124 -> 128); at BK = 32 the longer live range would cost
+    # the third wave per SIMD (166 -> 171 / 174 VGPRs), so those keep today's loop
     old = """    QA_LOAD_GLOBAL(0)
     QA_STORE_LDS(0)
     __syncthreads();
 """
-    new = """    QA_LOAD_GLOBAL(0)
+    new = """    constexpr bool PF2 = BK == 16;
+    QA_LOAD_GLOBAL(0)
     QA_STORE_LDS(0)
-    {
+    if (PF2) {
         const int k1_ = min(1, nk - 1);
         QA_LOAD_GLOBAL(k1_)  // the staging registers now hold chunk 1
     }
@@ -32,17 +35,19 @@ def transform(src: str) -> str:
     old = """            if (kk == QA_LOAD_AT) QA_LOAD_GLOBAL(nxt)
             if (kk == NKK - 1) QA_STORE_LDS(cur ^ 1)
 """
-    new = """            if (kk == 0) {  // registers = chunk kc + 1 (loaded one iteration ago) -> the free buffer; then chunk kc + 2 -> registers
-                QA_STORE_LDS(cur ^ 1)
-                const int nx2_ = min(kc + 2, nk - 1);
-                QA_LOAD_GLOBAL(nx2_)
+    new = """            if (PF2) {
+                if (kk == 0) {  // registers = chunk kc + 1 (loaded one iteration ago) -> the free buffer; then chunk kc + 2 -> registers
+                    QA_STORE_LDS(cur ^ 1)
+                    const int nx2_ = min(kc + 2, nk - 1);
+                    QA_LOAD_GLOBAL(nx2_)
+                }
+            } else {
+                if (kk == QA_LOAD_AT) QA_LOAD_GLOBAL(nxt)
+                if (kk == NKK - 1) QA_STORE_LDS(cur ^ 1)
             }
 """
     assert src.count(old) == 1
-    src = src.replace(old, new)
-    old = "        const int nxt = min(kc + 1, nk - 1);\n"
-    assert src.count(old) == 1
-    return src.replace(old, "")
+    return src.replace(old, new)
 
 
 def transform_interleaved(src: str) -> str:
@@ -54,7 +59,7 @@ def transform_interleaved(src: str) -> str:
         __syncthreads();
     }
 """
-    new = """            if (kk == 0) {
+    new = """            if (PF2 && kk == 0) {
 #pragma unroll
                 for (int s_ = 0; s_ < A_IT + B_IT; ++s_) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
