@@ -10,6 +10,7 @@
 #   trace:NAME:CMD    rocprofv3 --kernel-trace --stats of CMD (lm | bench-lean | bench-serial | hc10 | hc20) -> NAME_kernel_stats.md
 #   pmc:NAME:CMD      three separate --pmc passes (FETCH_SIZE | WRITE_SIZE | MFMA busy) of CMD -> NAME_pmc_summary.{md,json}
 #   profiles          the round's standard evidence set (tools/collect_profiles.sh TAG)
+#   kab:ARGS          tools/knob_ab.py ARGS - in-process knob A/B (and --libs per-build A/B) of the codec hot path -> knob_ab.txt
 #   run:CMD           any shell command (log tail kept in run.log)
 #   smoke             __graft_entry__.smoke()
 TAG=${1:?tag}; shift
@@ -64,6 +65,7 @@ PY
         ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_${name}_$i -o b -- $(cmd_of $what) > $O/${name}_pmc$i.log 2>&1 )
       done
       python tools/pmc_summary.py $O/${name}_pmc_summary /tmp/pmc_${name}_1 /tmp/pmc_${name}_2 /tmp/pmc_${name}_3 2>&1 | tail -3 ;;
+    kab) timeout 600 python tools/knob_ab.py $rest 2>&1 | grep -v amdgpu.ids | tee -a $O/knob_ab.txt ;;
     run) echo "$rest" >> $O/run.log; ( timeout 900 bash -c "$rest" 2>&1 | tail -${TAIL:-60} ) | tee -a $O/run.log ;;
     profiles) bash tools/collect_profiles.sh $TAG ;;
     smoke) ( time timeout 900 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -8 ) 2>&1 | tee -a $O/smoke.log ;;
