@@ -499,10 +499,12 @@ __global__ __launch_bounds__(NW * 64, 1) void lstm_team_kernel(const float* __re
                                                                 unsigned* err_host, unsigned spin_limit) {
     constexpr int U = D / PT, R = 4 * U, KS = NW, KW = D / KS, NQ = 4 * SG, LDH = D + 4, F4 = NQ * D / 4 / (NW * 64);
     static_assert(R <= 64 && D % PT == 0 && D % KS == 0 && KW % 4 == 0 && (NQ * D / 4) % (NW * 64) == 0, "lstm_team: shape does not tile");
-    __shared__ __attribute__((aligned(16))) float s_h[NQ][LDH];
     __shared__ __attribute__((aligned(16))) float s_part[KS][64][SG][4];  // [K slice][unit * 4 + q][sequence group][gate]
     __shared__ int s_ok;
-    extern __shared__ float s_pad[];  // unused: sized by the host so that ONE workgroup fits a CU
+    // h_{t-1} of the team's sequences lives in the DYNAMIC segment (49 KB at d = 1536: static LDS stops at 64 KB); the host sizes that
+    // segment beyond it so that ONE workgroup fits a CU
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    float (*s_h)[LDH] = reinterpret_cast<float (*)[LDH]>(s_dyn);
     const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
     const int team = blockIdx.x % n_teams, slot = blockIdx.x / n_teams;
     unsigned* err = sy + SY_ERR * SY_STRIDE;
@@ -718,31 +720,41 @@ static int launch_lstm_xcd(const float* xw, const float* w_hh_ug, float* h_out, 
     return QA_OK;
 }
 
-// QA_LSTM_TEAM: the team recurrence for d = 1024 (4 teams of 64 workgroups) - see lstm_team_kernel; *done as above
-static int launch_lstm_team(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d, hipStream_t s, int dev,
-                            bool* done) {
-    *done = false;
-    LstmPersistentDev& P = g_lstm_p[dev];
-    if (t_lstm_per_step || knob(K_LSTM_TEAM) <= 0 || P.degraded || d != 1024 || T < 2) return QA_OK;
-    QA_TRY(lstm_persistent_prepare(P, dev));
-    constexpr int PT = 64, SG = 2;
+// QA_LSTM_TEAM: d = 1024 on 4 teams of 64 workgroups - see lstm_team_kernel; *done as above
+template <int D, int PT>
+static int launch_lstm_team_t(LstmPersistentDev& P, const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T,
+                              hipStream_t s) {
+    constexpr int SG = 2;
     const int n_teams = P.cus / PT;
-    if (n_teams < 1 || n_teams > 8 || P.cus % PT) return QA_OK;
     const unsigned spin_limit = (unsigned)std::max<long long>(64, std::min<long long>(knob(K_LSTM_SPIN_LIMIT), 1LL << 30));
-    const int pad = 64 * 1024;  // with 49 KB of static LDS: one workgroup per CU
+    const int dyn = 96 * 1024;  // s_h (4 SG sequences x (D + 4) floats: 33 / 49 KB) + padding: with the static 16 KB one workgroup per CU
+    static_assert(4 * SG * (D + 4) * 4 <= 96 * 1024, "lstm_team: h staging does not fit the dynamic segment");
     const int fault = knob(K_LSTM_FAULT) ? 1 : 0;
-    QA_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(lstm_team_kernel<1024, 8, PT, SG>), pad));
+    QA_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(lstm_team_kernel<D, 8, PT, SG>), dyn));
     const int per_launch = 4 * SG * n_teams;
     for (int b0 = 0; b0 < B; b0 += per_launch) {
         const int bn = std::min(per_launch, B - b0);
         unsigned* sy = P.sync + (size_t)P.next * SY_WORDS * SY_STRIDE;
         P.next = (P.next + 1) % LSTM_SYNC_RING;
         QA_HIP(hipMemsetAsync(sy, 0, sizeof(unsigned) * SY_WORDS * SY_STRIDE, s));
-        hipLaunchKernelGGL((lstm_team_kernel<1024, 8, PT, SG>), dim3((unsigned)(n_teams * PT)), dim3(512), pad, s, xw + (long long)b0 * T * 4 * d,
-                           w_hh_ug, h_out + (long long)b0 * T * d, c_state + (long long)b0 * d, bn, T, sy, n_teams, fault, P.err_dev, spin_limit);
+        hipLaunchKernelGGL((lstm_team_kernel<D, 8, PT, SG>), dim3((unsigned)(n_teams * PT)), dim3(512), dyn, s, xw + (long long)b0 * T * 4 * D, w_hh_ug,
+                           h_out + (long long)b0 * T * D, c_state + (long long)b0 * D, bn, T, sy, n_teams, fault, P.err_dev, spin_limit);
         QA_LAUNCH_CHECK();
         ++P.launches;
     }
+    return QA_OK;
+}
+
+static int launch_lstm_team(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d, hipStream_t s, int dev,
+                            bool* done) {
+    *done = false;
+    LstmPersistentDev& P = g_lstm_p[dev];
+    // d = 1536 (H-Codec 2.0) on 2 teams of 128 was tried at compile time only: 192 resident weights + the h staging registers of a
+    // 512-thread workgroup spill (256 VGPRs + 72 bytes of scratch) - it stays on lstm_persistent_kernel
+    if (t_lstm_per_step || knob(K_LSTM_TEAM) <= 0 || d != 1024 || P.degraded || T < 2) return QA_OK;
+    QA_TRY(lstm_persistent_prepare(P, dev));
+    if (P.cus != 256) return QA_OK;  // the team size is laid out for 256 CUs
+    QA_TRY((launch_lstm_team_t<1024, 64>(P, xw, w_hh_ug, h_out, c_state, B, T, s)));
     *done = true;
     return QA_OK;
 }
