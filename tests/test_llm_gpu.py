@@ -1,4 +1,6 @@
 """UniSE AR-LM generate through the C-ABI against the CPU oracle (greedy token streams, integer output)."""
+import os
+
 import pytest
 import torch
 
@@ -117,6 +119,15 @@ def test_unfused_decode_step_matches_reference_goldens(qa_lib, gpu_device, knob,
     """QA_LM_UNFUSED=1: the per-op decode step (skinny GEMM + attention_decode kernels of csrc/lm_kernels.hip), the path a
     spec takes when the fused step does not tile it - through the same reference goldens, incl. the KV-786 case."""
     knob("QA_LM_UNFUSED", 1)  # read at qa_lm_create
+    golden_stream_parity(name, gpu_device, audit=False)
+
+
+@pytest.mark.skipif(not os.environ.get("QA_TEST_EXPERIMENTAL"), reason="QA_LM_XCD was written without GPU time left (round 3): run with QA_TEST_EXPERIMENTAL=1, then tools/lm_bench.py under QA_LM_XCD=1")
+@pytest.mark.parametrize("name", ["lm_unise_se", "lm_unise_tse", "lm_config3_se_b16", "lm_config4_tse_b8"])
+def test_xcd_decode_kernel_matches_reference_goldens(qa_lib, gpu_device, knob, name):
+    """QA_LM_XCD=1 (csrc/lm_xcd.hip): the greedy decode loop as one persistent launch per phase, a decode chain per XCD - through the
+    reference's own token streams, incl. the BASELINE configs[2] / configs[3] shapes."""
+    knob("QA_LM_XCD", 1)  # read at qa_lm_create (extra weight layouts) and at the call
     golden_stream_parity(name, gpu_device, audit=False)
 
 
