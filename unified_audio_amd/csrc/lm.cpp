@@ -145,6 +145,14 @@ void xcd_pack128(const float* W0, const float* W1, int K, RowOf row_of, float* o
                 }
 }
 
+// source row of local row lr (0..15) of slot's QKV block: part 0 / 1 = q / k (8 rotary pairs: rows 2 p, 2 p + 1 = dims jj, jj + hd / 2 of
+// head h, pair P = 8 slot + p = 32 h + jj), part 2 = v (rows 16 slot + lr)
+int xcd_row_qkv(int slot, int part, int lr, int hd) {
+    if (part == 2) return slot * 16 + lr;
+    const int P = slot * 8 + (lr >> 1), h = P / (hd / 2), jj = P % (hd / 2);
+    return h * hd + jj + (lr & 1) * (hd / 2);
+}
+
 int build_lm(qa_lm* lm, const HostTable& tab) {
     const qa_lm_spec& sp = lm->spec;
     const int d = sp.hidden, V = vocab_of(sp), I = sp.intermediate;
@@ -256,12 +264,7 @@ int build_lm(qa_lm* lm, const HostTable& tab) {
             std::vector<float> wx((size_t)3 * d * d);
             for (int slot = 0; slot < 32; ++slot)
                 for (int part = 0; part < 3; ++part)
-                    xcd_pack16(&wq[(size_t)part * d * d], d,
-                               [&](int lr) {
-                                   if (part == 2) return slot * 16 + lr;
-                                   const int P = slot * 8 + (lr >> 1), h = P >> 5, jj = P & 31;
-                                   return h * hd + jj + (lr & 1) * (hd / 2);
-                               },
+                    xcd_pack16(&wq[(size_t)part * d * d], d, [&](int lr) { return xcd_row_qkv(slot, part, lr, hd); },
                                &wx[((size_t)slot * 3 + part) * 16 * d]);
             pend.push_back({&L.xcd.qkv, st.add(wx)});
             const float* wo = tab.get(p + ".self_attn.o_proj.weight", (int64_t)d * d);
@@ -852,6 +855,37 @@ int qa_lm_generate_sampled(qa_lm* lm, int32_t task, const float* enroll_feats, i
     const SampleCfg sc{1, top_k, top_p, temperature, (unsigned long long)seed};
     return lm_generate_impl(lm, task, enroll_feats, n_enroll, mix_feats, n_mix, B, global_length, semantic_length, sc, global_ids,
                             semantic_ids, stream);
+}
+
+// Test hook (host memory only, no device needed): the weight layouts of lm_xcd.hip exactly as build_lm lays them out, one workgroup
+// block at a time, so that a CPU emulation of the kernel's lane arithmetic can be checked against a plain Llama step
+// (tests/test_llm_xcd_layout_cpu.py).  kind 0: QKV part `aux` of `slot` (src0 = that section's [512][K] matrix); 1: plain 16-row block
+// (o_proj / down_proj); 2: gate (src0) / up (src1) 128-row block; 3: head block whose first row is `aux` (src0 = output_head).
+int qa_debug_lm_xcd_pack(int32_t kind, const float* src0, const float* src1, int32_t K, int32_t slot, int32_t aux, float* out) {
+    if (!src0 || !out || K <= 0 || K % 128 || slot < 0 || slot >= 32) {
+        set_error("qa_debug_lm_xcd_pack: bad argument");
+        return QA_ERR_INVALID;
+    }
+    switch (kind) {
+        case 0: xcd_pack16(src0, K, [&](int lr) { return xcd_row_qkv(slot, aux, lr, 64); }, out); break;
+        case 1: xcd_pack16(src0, K, [&](int lr) { return slot * 16 + lr; }, out); break;
+        case 2:
+            if (!src1 || K != 512) {
+                set_error("qa_debug_lm_xcd_pack: gate / up need two matrices with K = 512");
+                return QA_ERR_INVALID;
+            }
+            xcd_pack128(src0, src1, K, [&](int, int lane) { return slot * 64 + lane; }, out);
+            break;
+        case 3:
+            if (K != 512) {
+                set_error("qa_debug_lm_xcd_pack: the head block has K = 512");
+                return QA_ERR_INVALID;
+            }
+            xcd_pack128(src0, src0, K, [&](int g, int lane) { return aux + 64 * g + lane; }, out);
+            break;
+        default: set_error("qa_debug_lm_xcd_pack: kind %d", kind); return QA_ERR_INVALID;
+    }
+    return QA_OK;
 }
 
 int qa_sample_logits(const float* logits, int64_t B, int64_t width, int64_t ld, int32_t top_k, float top_p, float temperature,
