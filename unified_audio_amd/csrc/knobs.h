@@ -41,7 +41,7 @@ namespace qa {
     X(LM_NT_DOWN, "QA_LM_NT_DOWN", 0, "column-tile width of the down GEMV")                                                      \
     X(LM_MLP_FUSED, "QA_LM_MLP_FUSED", 1, "decode step: gate/up + SwiGLU + down of 16 activation columns per workgroup in one launch emitting K-slice partials, summed by a reduce launch (0: separate gate/up and down launches; 2: 8 columns per workgroup)") \
     X(LM_ATT_SPLIT, "QA_LM_ATT_SPLIT", 0, "decode step: keys per workgroup of the single-query attention, at most 4 splits (0: 256)")  \
-    X(LM_XCD, "QA_LM_XCD", 0, "1 (at qa_lm_create AND at the call): greedy generate of <= 32 sequences as one persistent launch per phase, a decode chain per XCD with team barriers instead of kernel boundaries (lm_xcd.hip; needs the extra tile-major weight copies made at create time): written at the end of round 3, NOT YET RUN - parity test behind QA_TEST_EXPERIMENTAL")  \
+    X(LM_XCD, "QA_LM_XCD", 0, "1 / 2 (at qa_lm_create AND at the call; 2 = with the next stage's weights prefetched across the team barriers): greedy generate of <= 32 sequences as one persistent launch per phase, a decode chain per XCD with team barriers instead of kernel boundaries (lm_xcd.hip; needs the extra tile-major weight copies made at create time): written at the end of round 3, NOT YET RUN - parity test behind QA_TEST_EXPERIMENTAL")  \
     X(LM_CHAINS, "QA_LM_CHAINS", 0, "generate: number of concurrent chains of <= 32 sequences on internal streams (0: ceil(B / 32))")
 
 enum Knob {

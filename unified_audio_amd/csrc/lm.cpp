@@ -636,6 +636,7 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
             xa.sy = lm->xcd_sync; xa.err_host = lm->xcd_err_dev;
             xa.spin_limit = (unsigned)std::max<long long>(64, std::min<long long>(knob(K_LSTM_SPIN_LIMIT), 1LL << 30));
             xa.fault = 0;
+            xa.prefetch = knob(K_LM_XCD) >= 2 ? 1 : 0;
             QA_TRY(launch_lm_xcd_decode(xa, ch.s));
             lm->xcd_used = true;
             pos += steps;

@@ -38,6 +38,7 @@ struct LmXcdArgs {
     unsigned* err_host;  // mapped pinned word: set by a kernel whose bounded barrier spin ran out
     unsigned spin_limit;
     int fault;           // tests: the barrier waits for one member more than exists
+    int prefetch;        // 1: the next stage's weights are loaded between arrival at a team barrier and the wait for the team
 };
 
 bool lm_xcd_supported(int d, int heads, int inter, int global_size, int semantic_size);

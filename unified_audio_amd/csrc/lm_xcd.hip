@@ -74,15 +74,17 @@ struct LmxSync {
     unsigned limit, members, epoch;
 };
 
-// every wave's hand-off stores are drained, the workgroup arrives, and nobody continues before the whole team has arrived
-__device__ __forceinline__ bool lmx_barrier(LmxSync& ts, int* s_ok, int tid) {
+// A team barrier in two halves, so that loads which do not depend on the team (the NEXT stage's weights) can be issued in between:
+// lmx_arrive - every wave's hand-off stores are drained and the workgroup reports the stage done; lmx_wait_team - nobody continues
+// before the whole team has arrived.
+__device__ __forceinline__ void lmx_arrive(LmxSync& ts, int tid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     ++ts.epoch;
-    if (tid == 0) {
-        (void)__hip_atomic_fetch_add(ts.cnt, 1u, QX_RLX);
-        *s_ok = lmx_spin_until(ts.cnt, ts.members * ts.epoch, ts.err, ts.err_host, ts.limit) ? 1 : 0;
-    }
+    if (tid == 0) (void)__hip_atomic_fetch_add(ts.cnt, 1u, QX_RLX);
+}
+__device__ __forceinline__ bool lmx_wait_team(LmxSync& ts, int* s_ok, int tid) {
+    if (tid == 0) *s_ok = lmx_spin_until(ts.cnt, ts.members * ts.epoch, ts.err, ts.err_host, ts.limit) ? 1 : 0;
     __syncthreads();
     asm volatile("" ::: "memory");
     return *s_ok != 0;
@@ -92,12 +94,15 @@ __device__ __forceinline__ bool lmx_barrier(LmxSync& ts, int* s_ok, int tid) {
 // 4 rb + i as the MFMA's A operand), K phase kp = b >> 2; wave w and phase kp own the K slice (4 w + kp) of K / 32 values; the B
 // operand is sequence i's slice of the staged activations.  Returns, valid in lanes < 16 (kp = 0): lane (rb, q) -> rows 4 rb + r.
 template <int K>
-__device__ __forceinline__ f32x4 lmx_gemv16(const float* __restrict__ wt, const float (*s_x)[LDX], int wave, int lane) {
-    constexpr int KW = K / 32, NJ = KW / 4;
+__device__ __forceinline__ void lmx_ld16(const float* __restrict__ wt, int wave, int lane, f32x4* w) {  // w[K / 128]
+    constexpr int NJ = K / 128;
     const float* wp = wt + ((size_t)wave * NJ * 64 + lane) * 4;
-    f32x4 w[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) w[j] = lmx_ldw(wp + (size_t)j * 256);
+}
+template <int K>
+__device__ __forceinline__ f32x4 lmx_mm16(const f32x4* w, const float (*s_x)[LDX], int wave, int lane) {
+    constexpr int KW = K / 32, NJ = KW / 4;
     const float* xp = &s_x[lane & 3][(wave * 4 + (lane >> 4)) * KW];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -118,17 +123,17 @@ __device__ __forceinline__ f32x4 lmx_gemv16(const float* __restrict__ wt, const 
 
 // 128 output rows (two groups of 64: wave w -> group w & 1, K slice w >> 1 of 128 values) x 512 inputs.  Lane = row of the group
 // (A operand), B = sequence (lane & 3).  Returns lane (block, q) -> rows 64 g + 4 block + r, partial over the wave's K slice.
-__device__ __forceinline__ f32x4 lmx_gemv128(const float* __restrict__ wt, const float (*s_x)[LDX], int wave, int lane) {
-    constexpr int NJ = 32;
+__device__ __forceinline__ void lmx_ld128(const float* __restrict__ wt, int wave, int lane, f32x4* w) {  // w[32]
     const int g = wave & 1, ks = wave >> 1;
-    const float* wp = wt + (((size_t)g * 4 + ks) * NJ * 64 + lane) * 4;
-    f32x4 w[NJ];
+    const float* wp = wt + (((size_t)g * 4 + ks) * 32 * 64 + lane) * 4;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) w[j] = lmx_ldw(wp + (size_t)j * 256);
-    const float* xp = &s_x[lane & 3][ks * 128];
+    for (int j = 0; j < 32; ++j) w[j] = lmx_ldw(wp + (size_t)j * 256);
+}
+__device__ __forceinline__ f32x4 lmx_mm128(const f32x4* w, const float (*s_x)[LDX], int wave, int lane) {
+    const float* xp = &s_x[lane & 3][(wave >> 1) * 128];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+    for (int j = 0; j < 32; ++j) {
         const f32x4 hb = *reinterpret_cast<const f32x4*>(xp + 4 * j);
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w[j].x, hb.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w[j].y, hb.y, acc, 0, 0, 0);
@@ -138,6 +143,9 @@ __device__ __forceinline__ f32x4 lmx_gemv128(const float* __restrict__ wt, const
     return acc;
 }
 
+// PF = the NEXT stage's weights are loaded between a workgroup's arrival at a team barrier and its wait for the team (they do not
+// depend on the team's activations), so a stage starts with its weight stream already in flight: QA_LM_XCD=2 (1: PF = false)
+template <bool PF>
 __global__ __launch_bounds__(512, 1) void lm_xcd_decode_kernel(const LmXcdArgs a) {
     __shared__ __attribute__((aligned(16))) float s_x[4][LDX];          // staged activations of the team's sequences
     __shared__ __attribute__((aligned(16))) float s_pb[3][8][16][4];    // 16-row GEMVs: [part][wave][row block * 4 + q][r]
@@ -174,6 +182,12 @@ __global__ __launch_bounds__(512, 1) void lm_xcd_decode_kernel(const LmXcdArgs a
 
     if (tid < 4) s_tok[tid] = (int)a.tok_init;
     __syncthreads();
+    f32x4 wr[32];  // the weights of the next GEMV stage (PF: loaded one team barrier early)
+    const auto load_s1 = [&](const LmXcdLayer& L) {
+#pragma unroll
+        for (int part = 0; part < 3; ++part) lmx_ld16<XD>(L.qkv + ((size_t)slot * 3 + part) * 16 * XD, wave, lane, wr + 4 * part);
+    };
+    if (PF) load_s1(a.layer[0]);
 
     for (int st = 0; st < a.steps; ++st) {
         const int pos = a.pos0 + st;
@@ -206,10 +220,10 @@ __global__ __launch_bounds__(512, 1) void lm_xcd_decode_kernel(const LmXcdArgs a
                     for (int of = 32; of > 0; of >>= 1) sq += __shfl_xor(sq, of, 64);
                     if (lane == 0) s_rs[wave] = rsqrtf(sq / XD + eps);
                 }
-                const float* wt = L.qkv + (size_t)slot * 3 * 16 * XD;
+                if (!PF) load_s1(L);
 #pragma unroll
                 for (int part = 0; part < 3; ++part) {
-                    const f32x4 acc = lmx_gemv16<XD>(wt + (size_t)part * 16 * XD, s_x, wave, lane);
+                    const f32x4 acc = lmx_mm16<XD>(wr + 4 * part, s_x, wave, lane);
                     if (lane < 16) *reinterpret_cast<f32x4*>(&s_pb[part][wave][lane][0]) = acc;
                 }
                 __syncthreads();
@@ -237,7 +251,9 @@ __global__ __launch_bounds__(512, 1) void lm_xcd_decode_kernel(const LmXcdArgs a
                         }
                     }
                 }
-                if (!lmx_barrier(ts, s_ok, tid)) return;
+                lmx_arrive(ts, tid);
+                if (PF) lmx_ld16<XD>(L.o + (size_t)slot * 16 * XD, wave, lane, wr);  // S3's weights ride through the attention stage
+                if (!lmx_wait_team(ts, s_ok, tid)) return;
             }
             // ================================================================ S2: attention (lm_attn_kernel's body, one work item per slot)
             if (slot < nq * XH * S) {
@@ -332,7 +348,8 @@ __global__ __launch_bounds__(512, 1) void lm_xcd_decode_kernel(const LmXcdArgs a
                     lmx_st1(rec + tid, tid < XHD ? accv : (tid == XHD ? m : lsum));
                 }
             }
-            if (!lmx_barrier(ts, s_ok, tid)) return;
+            lmx_arrive(ts, tid);
+            if (!lmx_wait_team(ts, s_ok, tid)) return;
             // ================================================================ S3: merge of the attention partials + o_proj + residual
             {
                 if (tid < 4 * (XD / 4)) {
@@ -367,7 +384,8 @@ __global__ __launch_bounds__(512, 1) void lm_xcd_decode_kernel(const LmXcdArgs a
                     *reinterpret_cast<f32x4*>(&s_x[sq][4 * c4]) = out;
                 }
                 __syncthreads();
-                const f32x4 acc = lmx_gemv16<XD>(L.o + (size_t)slot * 16 * XD, s_x, wave, lane);
+                if (!PF) lmx_ld16<XD>(L.o + (size_t)slot * 16 * XD, wave, lane, wr);
+                const f32x4 acc = lmx_mm16<XD>(wr, s_x, wave, lane);
                 if (lane < 16) *reinterpret_cast<f32x4*>(&s_pb[0][wave][lane][0]) = acc;
                 __syncthreads();
                 if (tid < 16) {
@@ -387,7 +405,9 @@ __global__ __launch_bounds__(512, 1) void lm_xcd_decode_kernel(const LmXcdArgs a
                         lmx_st4(a.xb + (size_t)b * XD + col, v);
                     }
                 }
-                if (!lmx_barrier(ts, s_ok, tid)) return;
+                lmx_arrive(ts, tid);
+                if (PF) lmx_ld128(L.gu + (size_t)slot * 128 * XD, wave, lane, wr);
+                if (!lmx_wait_team(ts, s_ok, tid)) return;
             }
             // ================================================================ S4: RMSNorm + gate / up + SwiGLU
             {
@@ -409,7 +429,8 @@ __global__ __launch_bounds__(512, 1) void lm_xcd_decode_kernel(const LmXcdArgs a
                     for (int of = 32; of > 0; of >>= 1) sq += __shfl_xor(sq, of, 64);
                     if (lane == 0) s_rs[wave] = rsqrtf(sq / XD + eps);
                 }
-                const f32x4 acc = lmx_gemv128(L.gu + (size_t)slot * 128 * XD, s_x, wave, lane);
+                if (!PF) lmx_ld128(L.gu + (size_t)slot * 128 * XD, wave, lane, wr);
+                const f32x4 acc = lmx_mm128(wr, s_x, wave, lane);
                 *reinterpret_cast<f32x4*>(&s_pa[wave >> 1][64 * (wave & 1) + lane][0]) = acc;
                 __syncthreads();
                 if (tid < 64) {  // lane (block, q): activation columns 64 slot + 4 block + r of sequence q
@@ -428,7 +449,9 @@ __global__ __launch_bounds__(512, 1) void lm_xcd_decode_kernel(const LmXcdArgs a
                         lmx_st4(a.act + (size_t)(team + 8 * q) * XI + 64 * slot + 4 * blk, act);
                     }
                 }
-                if (!lmx_barrier(ts, s_ok, tid)) return;
+                lmx_arrive(ts, tid);
+                if (PF) lmx_ld16<XI>(L.down + (size_t)slot * 16 * XI, wave, lane, wr);
+                if (!lmx_wait_team(ts, s_ok, tid)) return;
             }
             // ================================================================ S5: down_proj + residual
             {
@@ -446,7 +469,8 @@ __global__ __launch_bounds__(512, 1) void lm_xcd_decode_kernel(const LmXcdArgs a
                     *reinterpret_cast<f32x4*>(&s_x[f >> 9][4 * (f & 511)]) = av[i];
                 }
                 __syncthreads();
-                const f32x4 acc = lmx_gemv16<XI>(L.down + (size_t)slot * 16 * XI, s_x, wave, lane);
+                if (!PF) lmx_ld16<XI>(L.down + (size_t)slot * 16 * XI, wave, lane, wr);
+                const f32x4 acc = lmx_mm16<XI>(wr, s_x, wave, lane);
                 if (lane < 16) *reinterpret_cast<f32x4*>(&s_pb[0][wave][lane][0]) = acc;
                 __syncthreads();
                 if (tid < 16) {
@@ -460,7 +484,11 @@ __global__ __launch_bounds__(512, 1) void lm_xcd_decode_kernel(const LmXcdArgs a
                         lmx_st4(a.xa + (size_t)b * XD + col, v);
                     }
                 }
-                if (!lmx_barrier(ts, s_ok, tid)) return;
+                lmx_arrive(ts, tid);
+                // the next layer's QKV rows.  UNCONDITIONAL (the last layer re-loads its own, unused): a conditional re-definition of
+                // the weight registers makes every stale value live around the layer loop and the kernel spills (137 VGPRs measured)
+                if (PF) load_s1(a.layer[min(l + 1, a.n_layers - 1)]);
+                if (!lmx_wait_team(ts, s_ok, tid)) return;
             }
         }
         // ==================================================================== head: final RMSNorm + vocabulary slice + arg-max
@@ -476,7 +504,8 @@ __global__ __launch_bounds__(512, 1) void lm_xcd_decode_kernel(const LmXcdArgs a
             float best = -INFINITY;
             int bi = 0x7fffffff;
             for (int ch = 0; ch < n_chunk; ++ch) {
-                const f32x4 acc = lmx_gemv128(a.head + ((size_t)slot * rows_wg + (size_t)ch * 128) * XD, s_x, wave, lane);
+                lmx_ld128(a.head + ((size_t)slot * rows_wg + (size_t)ch * 128) * XD, wave, lane, wr);  // not prefetched (see S5)
+                const f32x4 acc = lmx_mm128(wr, s_x, wave, lane);
                 *reinterpret_cast<f32x4*>(&s_pa[wave >> 1][64 * (wave & 1) + lane][0]) = acc;
                 __syncthreads();
                 if (tid < 128) {  // (group g, block, q): rows 64 g + 4 block + r of this chunk (the positive RMS factor does not move the arg-max)
@@ -516,7 +545,9 @@ __global__ __launch_bounds__(512, 1) void lm_xcd_decode_kernel(const LmXcdArgs a
                     __hip_atomic_store(reinterpret_cast<unsigned*>(a.pidx + (size_t)b * 32 + slot), (unsigned)i, QX_RLX);
                 }
             }
-            if (!lmx_barrier(ts, s_ok, tid)) return;
+            lmx_arrive(ts, tid);
+            if (PF) load_s1(a.layer[0]);  // the next step's first stage (unconditional: unused after the last step)
+            if (!lmx_wait_team(ts, s_ok, tid)) return;
             if (wave < nq) {  // every workgroup folds its team's 32 slot maxima itself (one load per lane): no further barrier
                 const int b = team + 8 * wave;
                 float v = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(a.pmax + (size_t)b * 32 + (lane & 31)), QX_RLX));
@@ -559,9 +590,14 @@ int launch_lm_xcd_decode(const LmXcdArgs& a, hipStream_t s) {
     QA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     QA_REQUIRE(cus == 256, "lm_xcd: laid out for 8 XCDs x 32 CUs, this device has %d CUs", cus);
     const int pad = 64 * 1024;  // with the ~55 KB of static LDS: one workgroup per CU, so the 256-workgroup grid lands 32 per XCD
-    QA_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(lm_xcd_decode_kernel), pad));
     QA_HIP(hipMemsetAsync(a.sy, 0, lm_xcd_sync_bytes(), s));
-    hipLaunchKernelGGL(lm_xcd_decode_kernel, dim3(256), dim3(512), pad, s, a);
+    if (a.prefetch) {
+        QA_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(lm_xcd_decode_kernel<true>), pad));
+        hipLaunchKernelGGL(lm_xcd_decode_kernel<true>, dim3(256), dim3(512), pad, s, a);
+    } else {
+        QA_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(lm_xcd_decode_kernel<false>), pad));
+        hipLaunchKernelGGL(lm_xcd_decode_kernel<false>, dim3(256), dim3(512), pad, s, a);
+    }
     QA_LAUNCH_CHECK();
     return QA_OK;
 }
