@@ -744,6 +744,11 @@ def main():
             tf = iso[4 * di] / (iso[4 * di + 1] * 1e-3) / 1e12
             line["roofline"]["isolated"] = {"achieved": tf, "frac": tf / MFMA_F32_PEAK_TFLOPS,
                                             "avg_launch_us": 1e3 * iso[4 * di + 1] / iso[4 * di + 2]}
+        # the library's run-time switches as this process ran them (csrc/knobs.h): values that differ from the defaults come from the environment
+        kn = _lib.knobs()
+        line["knobs"] = {"non_default": {k: v[0] for k, v in kn.items() if v[0] != v[1]},
+                         "recurrence": {k: kn[k][0] for k in ("QA_LSTM_XCD", "QA_LSTM_PERSISTENT", "QA_LSTM_TEAM") if k in kn},
+                         "note": "QA_LSTM_XCD = 1: the d = 512 / 768 LSTMs run as the XCD-local in-launch recurrence (DESIGN.md section 3)"}
         line["pcie_inclusive"] = {"value": B * T / SR / pcie_elapsed, "unit": "audio-seconds/sec", "ms_per_step": 1e3 * pcie_elapsed,
                                   "note": "rank-0 only: wav+features H2D from pageable memory, codes D2H+H2D, waveform D2H included"}
         if lm_line is not None:
