@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the widened secondaries (H-Codec 2.0 share of configs[4], TSE share of "
                                                                "configs[3], second grouping point, LM CPU baseline)")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--bootstrap-selftest", action="store_true",
+                    help="tests/test_bench_bootstrap_cpu.py: run ONLY the rank bootstrap (self-launch, rendezvous), the ranks_seen all-gather and the "
+                         "scatter -> hot path -> gather exchange leg, on the gloo backend with host tensors and a STUB hot path (no codec, no "
+                         "GPU, no throughput: the line carries \"selftest\": true and value null)")
     return ap.parse_args()
 
 
@@ -400,6 +404,141 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n: int) -> None:
+    """`python bench.py --gpus N` as a PLAIN command (no RANK in the environment): re-execute this very command line under
+    torch.distributed.run with one rank per GPU - the form the driver uses for N > 1 - instead of refusing.  Never returns."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    log(f"--gpus {n} without a launcher: re-executing as `{' '.join(cmd[1:9])} bench.py ...`")
+    os.execv(sys.executable, cmd)
+
+
+def bootstrap(args):
+    """Rank bootstrap: -> (rank, local_rank, world, device, torch.distributed or None).  One process per GPU; RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* from the environment (torch.distributed.run); backend nccl (= RCCL over xGMI), gloo in the self-test."""
+    if "RANK" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    args.gpus = world
+    selftest = args.bootstrap_selftest
+    n_dev = 0 if selftest or not torch.cuda.is_available() else torch.cuda.device_count()
+    if not selftest and world == 1 and n_dev == 0:
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if not selftest and world > n_dev:
+            # every rank of a one-node launch sees the same devices, so every rank takes this branch: rendezvous on gloo (proves the
+            # launch + rendezvous path), say clearly what is missing, leave with a non-zero status - no rank is left waiting
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+            msg = (f"bench.py --gpus {world}: the {world} ranks met (rendezvous ok) but this node exposes only {n_dev} GPU(s); "
+                   f"ranks {list(range(n_dev, world))} have no device of their own. Run on a node with >= {world} MI355X or lower --gpus.")
+            if rank == 0:
+                print(json.dumps({"error": msg, "n_gpus": world, "devices_visible": n_dev, "rendezvous": "ok"}), flush=True)
+                log(msg)
+            dist.destroy_process_group()
+            raise SystemExit(3)
+    if selftest:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    if dist is not None:
+        if selftest:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    return rank, local_rank, world, dev, dist
+
+
+def collect_ranks_seen(dist, rank, local_rank, world, dev):
+    """Which devices the ranks really sit on (all-gather of their UUIDs): "did RCCL see N distinct GPUs" is answerable from the line."""
+    if dev.type == "cuda":
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "host": os.uname().nodename}
+    else:  # the gloo self-test: a rank's "device" is its process
+        mine = {"rank": rank, "local_rank": local_rank, "name": "cpu (bootstrap self-test)", "uuid": f"pid-{os.getpid()}", "pci_bus_id": None,
+                "host": os.uname().nodename}
+    seen = [None] * world
+    dist.all_gather_object(seen, mine)
+    return {"ranks": seen, "distinct_devices": len({(s["host"], s["uuid"], s["pci_bus_id"]) for s in seen})}
+
+
+def exchange_leg(dist, rank, world, dev, hot_path, make_inputs, n_inputs, pad_values, fence, scatter_bytes):
+    """The exchange step north_star names - scatter of the clips from rank 0, the per-GPU hot path, gather of codes + waveforms back
+    (unified_audio_amd.dist.run_sharded: packed point-to-point transfers, the code path the gloo tests exercise) - timed NEXT TO the hot
+    path, never inside `value`.  -> (exchange dict, gathered results on rank 0)"""
+    from unified_audio_amd import dist as qd
+
+    inputs = make_inputs() if rank == 0 else [None] * n_inputs
+    tm = {}
+    fence()
+    res = qd.run_sharded(hot_path, inputs, dev, pad_values=pad_values, timings=tm)
+    tt = torch.tensor([tm["scatter_s"], tm["compute_s"], tm["gather_s"]], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    exchange = {"scatter_ms": 1e3 * float(tt[0]), "compute_ms": 1e3 * float(tt[1]), "gather_ms": 1e3 * float(tt[2]),
+                "exchange_ms": 1e3 * float(tt[0] + tt[2]), "scatter_bytes": scatter_bytes,
+                "note": "max over ranks; rank 0 sends every other rank exactly its block of clips + SSL features and receives its codes + "
+                        "waveforms (grouped point-to-point send / recv over RCCL, no padding, no collective); reported beside the hot "
+                        "path, never inside `value`"}
+    return exchange, res
+
+
+def bootstrap_selftest(args):
+    """--bootstrap-selftest: everything of an N > 1 bench run that is NOT the codec - launch, rendezvous, ranks_seen, the exchange leg,
+    the max-over-ranks reduction, one JSON line from rank 0 - on gloo with a stub hot path (a fixed affine map of the clips, so the
+    gathered result is checkable).  No throughput is claimed: value is null."""
+    rank, local_rank, world, dev, dist = bootstrap(args)
+    B, T = 3, 64
+
+    def clips_of(r):
+        return torch.arange(B * T, dtype=torch.float32).reshape(B, T) + 1000.0 * r
+
+    def stub(w, f):
+        return (w[:, ::8] * 2).to(torch.int64), w * 0.5 + f[:, :1]
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+
+    line = {"metric": "bootstrap self-test (no throughput)", "value": None, "selftest": True, "n_gpus": world, "backend": "gloo",
+            "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"}
+    if dist is not None:
+        ranks_seen = collect_ranks_seen(dist, rank, local_rank, world, dev)
+
+        def make_inputs():
+            return [torch.cat([clips_of(r) for r in range(world)]), torch.cat([clips_of(r)[:, :4] + 0.25 for r in range(world)])]
+
+        exchange, res = exchange_leg(dist, rank, world, dev, stub, make_inputs, 2, None, fence, world * B * (T + 4) * 4)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        line["max_over_ranks"] = float(t.item())
+        if rank == 0:
+            want = stub(*make_inputs())
+            exchange["gathered_shapes"] = [list(r_.shape) for r_ in res]
+            exchange["gathered_equals_unsharded_run"] = bool(all(torch.equal(a, b) for a, b in zip(res, want)))
+        line["ranks_seen"], line["exchange"] = ranks_seen, exchange
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
@@ -408,24 +547,9 @@ def main():
             return _lm_cpu_worker(int(parts[1]), int(parts[2]), int(parts[3]), int(parts[4]))
         c, sec, reps, thr, mdl = parts
         return _cpu_baseline_worker(int(c), float(sec), int(reps), int(thr), mdl)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.bootstrap_selftest:
+        return bootstrap_selftest(args)
+    rank, local_rank, world, dev, dist = bootstrap(args)
 
     import unified_audio_amd as qa
     from unified_audio_amd import _lib, synth  # synthetic weights / inputs: data generation only; nothing under oracle/ is
@@ -495,18 +619,13 @@ def main():
     # `value`: in the timed region above every rank draws its own shard, like the reference's rank-strided file lists
     ranks_seen, exchange = None, None
     if dist is not None:
-        props = torch.cuda.get_device_properties(dev)
-        mine = {"rank": rank, "local_rank": local_rank, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
-                "pci_bus_id": getattr(props, "pci_bus_id", None), "host": os.uname().nodename}
-        seen = [None] * world
-        dist.all_gather_object(seen, mine)
-        ranks_seen = {"ranks": seen, "distinct_devices": len({(s["host"], s["uuid"], s["pci_bus_id"]) for s in seen})}
+        ranks_seen = collect_ranks_seen(dist, rank, local_rank, world, dev)
         try:
-            from unified_audio_amd import dist as qd
-
             K = spec.codebook_size
-            all_wav = torch.cat([(synth.synth_wav_fullband(7 + r, B, T) if args.model == "2.0" else synth.synth_wav(7 + r, B, T)) for r in range(world)]).to(dev) if rank == 0 else None
-            all_feats = torch.cat([synth.synth_feat(9 + r, B, T // hop_in, spec.sem_in).transpose(1, 2).contiguous() for r in range(world)]).to(dev) if rank == 0 else None
+
+            def make_inputs():
+                return [torch.cat([(synth.synth_wav_fullband(7 + r, B, T) if args.model == "2.0" else synth.synth_wav(7 + r, B, T)) for r in range(world)]).to(dev),
+                        torch.cat([synth.synth_feat(9 + r, B, T // hop_in, spec.sem_in).transpose(1, 2).contiguous() for r in range(world)]).to(dev)]
 
             def hot_path(w, f):
                 if adaptive:
@@ -515,22 +634,14 @@ def main():
                 a_, s_ = codec.encode(w.unsqueeze(1), f.transpose(1, 2))
                 return a_, s_, codec.decode(a_, s_)
 
-            tm = {}
-            fence()
-            res = qd.run_sharded(hot_path, [all_wav, all_feats], dev, pad_values=[-K, -K, 0.0] if adaptive else None, timings=tm)
-            tt = torch.tensor([tm["scatter_s"], tm["compute_s"], tm["gather_s"]], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            exchange = {"scatter_ms": 1e3 * float(tt[0]), "compute_ms": 1e3 * float(tt[1]), "gather_ms": 1e3 * float(tt[2]),
-                        "exchange_ms": 1e3 * float(tt[0] + tt[2]),
-                        "scatter_bytes": world * B * (T + (T // hop_in) * spec.sem_in) * 4,
-                        "note": "max over ranks; rank 0 scatters every rank's clips + SSL features and gathers codes + waveforms "
-                                "(torch.distributed scatter / gather over RCCL); reported beside the hot path, never inside `value`"}
+            exchange, res = exchange_leg(dist, rank, world, dev, hot_path, make_inputs, 2, [-K, -K, 0.0] if adaptive else None, fence,
+                                         world * B * (T + (T // hop_in) * spec.sem_in) * 4)
             if rank == 0:
                 own = hot_path(wav, feats)  # rank 0's block of the gathered result must be what rank 0 computes from its own shard
                 g0 = res[2][:B]
                 exchange["gathered_shapes"] = [list(r_.shape) for r_ in res]
                 exchange["rank0_block_matches_local_run"] = bool(torch.equal(g0[..., : own[2].shape[-1]], own[2]))
-            del all_wav, all_feats, res
+            del res
         except Exception as e:  # noqa: BLE001
             exchange = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
 
@@ -782,7 +893,8 @@ def main():
             line["ssl_frontend"] = ssl_line
         if args.model == "2.0":
             line["metric"] = "audio-seconds/sec H-Codec 2.0 encode+decode @48kHz (BASELINE configs[4], per-GPU share)"
-        if world == 1 and not args.no_cpu_baseline and not args.lean and args.model != "2.0":
+        if not args.no_cpu_baseline and not args.lean and args.model != "2.0":
+            # rank 0 only, AFTER every timed region (at N > 1 the other ranks have finished their GPU work and are leaving)
             log("cpu baseline ...")
             line["cpu_baseline"] = cpu_baseline(args.cpu_clips, args.seconds, model=args.model)
             if line["cpu_baseline"]["value"]:

@@ -33,45 +33,80 @@ def _meta_from_root(t: Optional[torch.Tensor], src: int, group=None):
     return meta[0]
 
 
+def _exchange(ops) -> None:
+    """Run a list of point-to-point operations as ONE group (RCCL: ncclGroupStart / End, so rank 0's transfers to its peers ride
+    their own xGMI links concurrently instead of one after the other) and wait for all of them."""
+    if not ops:
+        return
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+
+
 def scatter_clips(clips: Optional[torch.Tensor], device: torch.device, src: int = 0, group=None) -> torch.Tensor:
-    """rank `src` holds clips [N, ...]; every rank receives its contiguous block [n_r, ...] on `device`."""
+    """rank `src` holds clips [N, ...]; every rank receives its contiguous block [n_r, ...] on `device`.
+
+    Packed point-to-point form: rank `src` sends rank r exactly the rows [a_r, b_r) of `clips` - a contiguous view,
+    no padding to the widest block, no per-rank staging copy of the batch - and keeps its own block as a view (moved to `device`
+    only if `clips` lives elsewhere).  All sends of a call are posted as one group."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     shape, dtype = _meta_from_root(clips, src, group)
-    counts = shard_counts(shape[0], world)
-    width = max(counts)
-    out = torch.empty((width,) + tuple(shape[1:]), dtype=dtype, device=device)
-    chunks = None
+    a, b = shard_range(shape[0], rank, world)
     if rank == src:
-        chunks = []
+        clips = clips.contiguous()
+        ops = []
         for r in range(world):
-            a, b = shard_range(shape[0], r, world)
-            c = torch.zeros_like(out)
-            c[: b - a] = clips[a:b].to(device)
-            chunks.append(c)
-    dist.scatter(out, chunks, src=src, group=group)
-    return out[: counts[rank]]
+            ra, rb = shard_range(shape[0], r, world)
+            if r != src and rb > ra:
+                ops.append(dist.P2POp(dist.isend, clips[ra:rb].to(device), r, group))
+        _exchange(ops)
+        return clips[a:b].to(device)
+    out = torch.empty((b - a,) + tuple(shape[1:]), dtype=dtype, device=device)
+    if b > a:
+        _exchange([dist.P2POp(dist.irecv, out, src, group)])
+    return out
 
 
 def gather_ragged(local: torch.Tensor, dst: int = 0, group=None, pad_value=0) -> Optional[torch.Tensor]:
     """Concatenate per-rank results [n_r, ...] on rank `dst`, in rank order.  n_r may differ; trailing dimensions may differ too
     (H-Codec 1.5: the number of groups G of a batch is data dependent, so every rank's codes are [n_r, nq, G_r]) - they are
     right-padded with `pad_value` to the largest extent over the ranks (for length-injected codes pass -codebook_size: a group of
-    length 0, exactly what a batch's own shorter clips carry, codec_adaptive.py:68-80)."""
+    length 0, exactly what a batch's own shorter clips carry, codec_adaptive.py:68-80).
+
+    Packed point-to-point form: every rank sends its result in ITS OWN shape (no padding on the wire); `dst` receives a block
+    straight into its rows of the result when the trailing extents agree, through a staging tensor of the sender's shape otherwise."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     shp = torch.tensor(list(local.shape), dtype=torch.int64, device=local.device)
     shapes = [torch.zeros_like(shp) for _ in range(world)]
     dist.all_gather(shapes, shp, group=group)
     shapes = [[int(v) for v in t.tolist()] for t in shapes]
-    counts = [t[0] for t in shapes]
-    # a rank with an empty shard has no trailing extents of its own (run_sharded builds them from another rank's signature)
-    full = tuple(max(t[i] for t in shapes) for i in range(local.dim()))
-    padded = torch.full(full, pad_value, dtype=local.dtype, device=local.device)
-    padded[tuple(slice(0, n) for n in local.shape)] = local
-    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-    dist.gather(padded, bufs, dst=dst, group=group)
     if rank != dst:
+        if local.numel() > 0:
+            _exchange([dist.P2POp(dist.isend, local.contiguous(), dst, group)])
         return None
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    # a rank with an empty shard has no trailing extents of its own (run_sharded builds them from another rank's signature)
+    trail = tuple(max(t[i] for t in shapes) for i in range(1, local.dim()))
+    total = sum(t[0] for t in shapes)
+    ragged = any(tuple(t[1:]) != trail for t in shapes if t[0] > 0)
+    result = (torch.full if ragged else torch.empty)((total,) + trail, *((pad_value,) if ragged else ()), dtype=local.dtype, device=local.device)
+    ops, staged, at = [], [], 0
+    for r, t in enumerate(shapes):
+        n = t[0]
+        rows = result[at:at + n]
+        at += n
+        if n == 0 or (r != dst and min(t) == 0):
+            continue
+        if r == dst:
+            rows[tuple(slice(None) if i == 0 else slice(0, e) for i, e in enumerate(local.shape))] = local
+        elif tuple(t[1:]) == trail:
+            ops.append(dist.P2POp(dist.irecv, rows, r, group))
+        else:
+            buf = torch.empty(t, dtype=local.dtype, device=local.device)
+            ops.append(dist.P2POp(dist.irecv, buf, r, group))
+            staged.append((rows, buf))
+    _exchange(ops)
+    for rows, buf in staged:
+        rows[tuple(slice(None) if i == 0 else slice(0, e) for i, e in enumerate(buf.shape))] = buf
+    return result
 
 
 def _tick(device: torch.device) -> float:
@@ -168,9 +203,8 @@ def run_sharded_ragged(fn: Callable[[List[torch.Tensor]], Sequence[torch.Tensor]
     mine = parts[rank]
     # ---- scatter: one packed tensor per destination rank
     if rank == src:
-        for r in range(world):
-            if r != src and parts[r]:
-                dist.send(_pack([utterances[i] for i in parts[r]], device, dtype), dst=r, group=group)
+        _exchange([dist.P2POp(dist.isend, _pack([utterances[i] for i in parts[r]], device, dtype), r, group)
+                   for r in range(world) if r != src and parts[r]])
         local = [utterances[i].reshape(-1).to(device) for i in mine]
     else:
         packed = torch.empty(sum(lengths[i] for i in mine), dtype=dtype, device=device)
@@ -198,18 +232,18 @@ def run_sharded_ragged(fn: Callable[[List[torch.Tensor]], Sequence[torch.Tensor]
             dist.send(_pack(outs, device, outs[0].dtype), dst=src, group=group)
         return None
     result: List[Optional[torch.Tensor]] = [None] * len(lengths)
+    bufs = {r: torch.empty(sum(meta[r][0]), dtype=meta[r][1], device=device) for r in range(world) if r != src and meta[r][0]}
+    _exchange([dist.P2POp(dist.irecv, buf, r, group) for r, buf in bufs.items()])  # every peer's packed results as one group
     for r in range(world):
-        lens, odt = meta[r]
+        lens, _ = meta[r]
         if not lens:
             continue
         if r == src:
             pieces = outs
         else:
-            buf = torch.empty(sum(lens), dtype=odt, device=device)
-            dist.recv(buf, src=r, group=group)
             pieces, at = [], 0
             for n in lens:
-                pieces.append(buf[at:at + n])
+                pieces.append(bufs[r][at:at + n])
                 at += n
         for i, p in zip(parts[r], pieces):
             result[i] = p
