@@ -24,7 +24,9 @@ sys.path.insert(0, ROOT)
 
 SR = 16000
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD at 2.4 GHz
-CFG_NAMES = ["conv_gemm_kernel<128,32,4,1>", "conv_gemm_kernel<128,64,2,2>", "conv_gemm_kernel<128,128,2,2>"]
+CFG_NAMES = ["conv_gemm_kernel<128,32,4,1>", "conv_gemm_kernel<128,64,2,2>", "conv_gemm_kernel<128,128,2,2>", "conv_gemm_kernel<64,128,1,4>",
+             "conv_gemm_kernel<64,64,2,2>"]
+NPROF = 4 * len(CFG_NAMES)
 
 
 def parse():
@@ -262,11 +264,11 @@ def lm_bench(dev, rank, world, dist, batch, reps=2, task="se", n_enroll=0):
     lib.qa_profile_begin()  # only the prefill runs on conv_gemm (the decode steps are GEMV launches): 1 + 1 tokens keep every output non-empty
     lm.generate(task, mel1 if enr is not None else None, enr, mel1, mix, global_length=1, do_sample=False)
     torch.cuda.synchronize(dev)
-    prof = (C.c_double * 12)()
-    lib.qa_profile_end(prof, 12)
-    g_flop = sum(prof[4 * i] for i in range(3))
-    g_ms = sum(prof[4 * i + 1] for i in range(3))
-    g_n = int(sum(prof[4 * i + 2] for i in range(3)))
+    prof = (C.c_double * NPROF)()
+    lib.qa_profile_end(prof, NPROF)
+    g_flop = sum(prof[4 * i] for i in range(len(CFG_NAMES)))
+    g_ms = sum(prof[4 * i + 1] for i in range(len(CFG_NAMES)))
+    g_n = int(sum(prof[4 * i + 2] for i in range(len(CFG_NAMES))))
     prefill = {"ms": ms_prefill, "rows": batch * (2 + 250 + (1 + n_enroll if n_enroll else 0)),
                "roofline": {"bound": "mfma", "achieved": g_flop / (g_ms * 1e-3) / 1e12 if g_ms else None, "peak": MFMA_F32_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": g_flop / (g_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if g_ms else None,
@@ -605,8 +607,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
-    prof = (C.c_double * 12)()
-    _lib.check(lib.qa_profile_end(prof, 12))
+    prof = (C.c_double * NPROF)()
+    _lib.check(lib.qa_profile_end(prof, NPROF))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -647,13 +649,13 @@ def main():
 
     # the same kernels with the library's internal stream concurrency switched off (every launch alone on the device):
     # what a kernel achieves by itself, as opposed to while it shares the CUs with the other stream's kernels
-    iso = (C.c_double * 12)()
+    iso = (C.c_double * NPROF)()
     _lib.check(lib.qa_set_serial(1))
     _lib.check(lib.qa_profile_begin())
     for _ in range(0 if args.lean else 2):
         step()
     torch.cuda.synchronize(dev)
-    _lib.check(lib.qa_profile_end(iso, 12))
+    _lib.check(lib.qa_profile_end(iso, NPROF))
     _lib.check(lib.qa_set_serial(0))
 
     # secondary: the same step with host (pageable) tensors in and out, as HCodecTokenizer's __main__ moves them
@@ -821,7 +823,7 @@ def main():
                         traffic = v["hbm_bytes_per_launch"]
                         traffic_src = pmc.get("_source", "profiles/") + " (2*FETCH_SIZE + WRITE_SIZE, per launch; rocprofv3 --pmc passes of this command)"
                         mfma_busy = v["mfma_busy_frac"]
-        gemm_ms = sum(prof[4 * i + 1] for i in range(3))
+        gemm_ms = sum(prof[4 * i + 1] for i in range(len(CFG_NAMES)))
         line = {
             "metric": "audio-seconds/sec H-Codec encode+decode @16kHz b=32",
             "value": audio_s / elapsed,

@@ -23,6 +23,14 @@
  *     its kernels and keeps its own device copy).
  *   - work is enqueued on `stream` (a hipStream_t; NULL = the default stream) and is asynchronous;
  *     a handle owns its workspaces and must not be used from two streams / threads at once.
+ *     EXCEPTION (qa_hcodec_encode / _decode and their adaptive forms): a call that launched one of the in-launch
+ *     LSTM recurrences (knobs QA_LSTM_XCD - the default for d = 512 / 768 -, QA_LSTM_TEAM, QA_LSTM_PERSISTENT) waits
+ *     for `stream` on the host before it returns, because it must read that launch's own error word and, if a bounded
+ *     barrier spin ran out (device shared with another persistent kernel), re-run itself on the per-step kernels: such
+ *     a call is host-synchronous and cannot be issued under a caller's stream capture.  QA_LSTM_XCD=0 QA_LSTM_TEAM=0
+ *     QA_LSTM_PERSISTENT=0 restores fully asynchronous calls (launch-per-step recurrence).  The error word and the
+ *     launch count are per CALL (a ticket taken by the calling thread), so handles that share a device from
+ *     different threads never collect each other's failure.
  *   - there is no CPU fallback: on a machine without a gfx950 device every compute entry point fails.
  */
 #ifndef QUARKAUDIO_H_
@@ -34,7 +42,7 @@
 extern "C" {
 #endif
 
-#define QA_VERSION 102 /* 0.1.1 */
+#define QA_VERSION 103 /* 0.1.2 */
 
 typedef enum qa_status {
     QA_OK = 0,
@@ -207,8 +215,8 @@ int64_t qa_resolve_frame(int64_t r, int64_t L, int32_t max_pad, int32_t pad_mode
 /* ---- measurement hook (bench.py) ------------------------------------------------------------------------
  * Between qa_profile_begin() and qa_profile_end() every implicit-GEMM launch is bracketed by HIP events recorded on
  * the stream it is launched on.  qa_profile_end fills out[cfg*4 + {0,1,2,3}] = {algorithmic FLOPs, elapsed ms, launches,
- * algorithmic bytes (input frames + weights + outputs + fused residual / gate reads, each once)} for the three tile
- * configurations cfg = 0 (128x32), 1 (128x64), 2 (128x128); n_out >= 12.  Not thread-safe; process-wide. */
+ * algorithmic bytes (input frames + weights + outputs + fused residual / gate reads, each once)} for the five tile
+ * configurations cfg = 0 (128x32), 1 (128x64), 2 (128x128), 3 (64x128), 4 (64x64); n_out >= 20.  Not thread-safe; process-wide. */
 int qa_profile_begin(void);
 int qa_profile_end(double* out, int32_t n_out);
 /* qa_set_serial(1) (or QA_SERIAL=1 in the environment) collapses the library's internal streams onto the caller's, so that a

@@ -22,7 +22,7 @@ def test_header_symbols_are_exported_and_bound(qa_lib):
     for name in sorted(declared):
         assert hasattr(qa_lib, name), f"{name} declared in quarkaudio.h but not exported"
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
-    assert qa_lib.qa_version() == 102
+    assert qa_lib.qa_version() == 103
 
 
 def test_knob_table_is_enumerable_settable_and_documented(qa_lib):

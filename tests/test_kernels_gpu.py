@@ -99,6 +99,33 @@ def test_conv1d_cl_matches_torch(qa_lib, gpu_device, case):
     assert err < 2e-6, f"rel err {err}"  # fp32 tolerance: only the summation order differs
 
 
+@pytest.mark.parametrize("case", [4, 5, 6, 8, 10, 11, 13])
+def test_conv_gemm_tile_configurations_are_bit_identical(qa_lib, gpu_device, knob, case):
+    """Every tile configuration of conv_gemm (QA_GEMM_CFG 1 .. 4: 128x64, 128x128 and the 64-row tiles 64x128 / 64x64 of round 4)
+    accumulates an output element over k in the same order, so the choice of tile - which the cost model makes from M, i.e. from
+    the batch size - never changes a bit: required for `a clip's result does not depend on the batch it rides in`."""
+    c = CONV_CASES[case]
+    g = torch.Generator().manual_seed(23)
+    B, T, Cin, N, k = c["B"], c["T"], c["Cin"], c["N"], c["k"]
+    stride = c.get("stride", 1)
+    x = torch.randn(B, T, Cin, generator=g).to(gpu_device)
+    w = (torch.randn(N, k, Cin, generator=g) / (k * Cin) ** 0.5).to(gpu_device)
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    T_out = (T - k) // stride + 1  # no padding: geometry is covered by test_conv1d_cl_matches_torch
+    gamma = (torch.rand(N, generator=g) + 0.5).to(gpu_device) if c.get("gamma") else None
+    res = torch.randn(B, T_out, N, generator=g).to(gpu_device) if c.get("res") else None
+    gate = torch.randn(B, T_out, N, generator=g).to(gpu_device) if c.get("gate") else None
+    outs = {}
+    for cfg in (-1, 1, 2, 3, 4):
+        knob("QA_GEMM_CFG", cfg)
+        outs[cfg] = conv1d_cl(qa_lib, x, w, bias, stride=stride, act=c.get("act", 0), post_act=c.get("post", 0), gamma=gamma, residual=res,
+                              gate=gate, T_out=T_out).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[-1]).all()
+    for cfg in (1, 2, 3, 4):
+        assert torch.equal(outs[cfg], outs[-1]), f"QA_GEMM_CFG={cfg} differs from the cost model's choice"
+
+
 def _rvq_problem(n, Q, K, D, seed):
     rng = np.random.default_rng(seed)
     cb = np.stack([rng.standard_normal((K, D)).astype(np.float32) * (0.6 * 0.5 ** q) for q in range(Q)])

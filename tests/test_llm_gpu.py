@@ -122,7 +122,6 @@ def test_unfused_decode_step_matches_reference_goldens(qa_lib, gpu_device, knob,
     golden_stream_parity(name, gpu_device, audit=False)
 
 
-@pytest.mark.skipif(not os.environ.get("QA_TEST_EXPERIMENTAL"), reason="QA_LM_XCD was written without GPU time left (round 3): run with QA_TEST_EXPERIMENTAL=1, then tools/lm_bench.py under QA_LM_XCD=1")
 @pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("name", ["lm_unise_se", "lm_unise_tse", "lm_config3_se_b16", "lm_config4_tse_b8"])
 def test_xcd_decode_kernel_matches_reference_goldens(qa_lib, gpu_device, knob, name, mode):

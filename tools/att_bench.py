@@ -20,7 +20,7 @@ for name, B, N, H, hd, w in (("agg 32x283", 32, 283, 8, 64, 64), ("enc 32x500", 
                              ("dec 32x500 hd128", 32, 500, 8, 128, 2), ("h20 16x1500", 16, 1500, 24, 64, 0), ("wavlm 16x250 hd64 12h", 16, 250, 12, 64, 0),
                              ("dec10 32x500 hd96", 32, 500, 8, 96, 0)):
     d = H * hd
-    qkv = torch.randn(B, N, 3 * d, device=dev)
+    qkv = torch.randn(B, N, 3 * d, generator=torch.Generator().manual_seed(5)).to(dev)
     out = torch.empty(B, N, d, device=dev)
     args = (qkv.data_ptr(), 3 * d, qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, 3 * d, out.data_ptr(), d, B, N, N, N * 3 * d, H, hd, hd ** -0.5, 0, None)
     for _ in range(3):
@@ -33,5 +33,8 @@ for name, B, N, H, hd, w in (("agg 32x283", 32, 283, 8, 64, 64), ("enc 32x500", 
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     tot += us * w
-    print(f"{name:24s} {us:8.1f} us  {4.0 * B * H * N * N * hd / us / 1e6:6.1f} TFLOP/s")
+    import hashlib
+
+    digest = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:12]  # A/B builds (tools/variants.py) must agree bit for bit
+    print(f"{name:24s} {us:8.1f} us  {4.0 * B * H * N * N * hd / us / 1e6:6.1f} TFLOP/s  digest={digest}")
 print(f"weighted per H-Codec 1.5 step: {tot / 1e3:.2f} ms")

@@ -18,6 +18,8 @@ SHAPES = [  # name, M(rows), N, Cin, k, stride
     ("mimi.in_proj", 9056, 1536, 512, 1, 1), ("mimi.out_proj", 9056, 512, 512, 1, 1), ("mimi.lin1", 9056, 2048, 512, 1, 1),
     ("mimi.lin2", 9056, 512, 2048, 1, 1), ("bt.in_proj", 8000, 3072, 1024, 1, 1), ("bt.lin1", 8000, 2048, 1024, 1, 1),
     ("bt.lin2", 8000, 1024, 2048, 1, 1),
+    ("agg15.qkv", 9056, 1536, 512, 1, 1), ("agg15.half", 4528, 512, 512, 1, 1), ("wavlm.ffn1", 4000, 3072, 768, 1, 1), ("wavlm.ffn2", 4000, 768, 3072, 1, 1),
+    ("h20.pw1", 24000, 4608, 1536, 1, 1), ("h20.pw2", 24000, 1536, 4608, 1, 1),
     ("convnext.pw1", 16000, 2304, 768, 1, 1), ("convnext.pw2", 16000, 768, 2304, 1, 1),
     ("dec.k3", 16000, 768, 768, 3, 1), ("dec.lstm_ih", 16000, 3072, 768, 1, 1), ("dec.qkv", 16000, 2304, 768, 1, 1),
     ("dec.w2", 16000, 768, 3072, 1, 1), ("enc.lstm_ih", 16000, 2048, 512, 1, 1), ("enc.o", 16000, 512, 512, 1, 1),
@@ -27,28 +29,52 @@ SHAPES = [  # name, M(rows), N, Cin, k, stride
 ]
 
 
+def bench_shape(lib, dev, M, N, C, k, s, reps=5):
+    T = M * s  # one batch item; zero padding, enough frames for M outputs
+    x = torch.randn(1, T + k, C, device=dev)
+    w = torch.randn(N, k, C, device=dev) * 0.05
+    b = torch.randn(N, device=dev)
+    for _ in range(2):
+        y = conv1d_cl(lib, x, w, b, stride=s, T_out=M)
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(reps):
+        conv1d_cl(lib, x, w, b, stride=s, T_out=M)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, y
+
+
 def main():
     lib = load_library()
     dev = torch.device("cuda:0")
-    tot_t = tot_f = 0.0
     only = os.environ.get("QA_BENCH_ONLY")
-    for name, M, N, C, k, s in SHAPES:
-        if only and not any(name.startswith(o) for o in only.split(",")):
-            continue
-        T = M * s  # one batch item; zero padding, enough frames for M outputs
-        x = torch.randn(1, T + k, C, device=dev)
-        w = torch.randn(N, k, C, device=dev) * 0.05
-        b = torch.randn(N, device=dev)
-        for _ in range(2):
-            conv1d_cl(lib, x, w, b, stride=s, T_out=M)
-        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
-        reps = 5
-        e0.record()
-        for _ in range(reps):
-            conv1d_cl(lib, x, w, b, stride=s, T_out=M)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+    shapes = [sh for sh in SHAPES if not only or any(sh[0].startswith(o) for o in only.split(","))]
+    sweep = os.environ.get("QA_BENCH_CFGS")  # e.g. "-1,1,2,3,4": one column per forced tile configuration (qa_set_knob), -1 = cost model
+    if sweep:
+        cfgs = [int(c) for c in sweep.split(",")]
+        print("TFLOP/s per forced QA_GEMM_CFG (-1 = the cost model's choice); `same` = outputs bit-identical to the first column's")
+        print(f"{'shape':16s} {'M':>8s} {'N':>5s} {'K':>5s} " + " ".join(f"{'cfg' + str(c):>9s}" for c in cfgs) + "  same  best")
+        for name, M, N, C, k, s in shapes:
+            cols, ref, same = [], None, True
+            for c in cfgs:
+                if c == 0 and N > 64:  # 128x32 on wide layers: never chosen, slow to run
+                    cols.append(float("nan"))
+                    continue
+                lib.qa_set_knob(b"QA_GEMM_CFG", c)
+                ms, y = bench_shape(lib, dev, M, N, C, k, s, reps=3)
+                cols.append(2.0 * M * N * C * k / ms / 1e9)
+                if ref is None:
+                    ref = y.clone()
+                else:
+                    same = same and bool(torch.equal(ref, y))
+            lib.qa_set_knob(b"QA_GEMM_CFG", -1)
+            best = max(range(len(cfgs)), key=lambda i: -1.0 if cols[i] != cols[i] else cols[i])
+            print(f"{name:16s} {M:8d} {N:5d} {C * k:5d} " + " ".join(f"{v:9.1f}" for v in cols) + f"  {str(same):5s} cfg{cfgs[best]}", flush=True)
+        return
+    tot_t = tot_f = 0.0
+    for name, M, N, C, k, s in shapes:
+        ms, _ = bench_shape(lib, dev, M, N, C, k, s)
         fl = 2.0 * M * N * C * k
         tot_t += ms
         tot_f += fl

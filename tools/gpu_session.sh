@@ -13,6 +13,9 @@
 #   kab:ARGS          tools/knob_ab.py ARGS - in-process knob A/B (and --libs per-build A/B) of the codec hot path -> knob_ab.txt
 #   run:CMD           any shell command (log tail kept in run.log)
 #   smoke             __graft_entry__.smoke()
+# r04 lesson (25 GPU-minutes lost): `ab:...:python tools/x.py 32 2` used to reach cmd_of UNQUOTED, so only the word `python` came back
+# and three interactive interpreters sat on stdin until their time-outs - commands are now passed quoted, stdin is /dev/null, and
+# `DRY=1 bash tools/gpu_session.sh TAG STEP...` prints what each step would run (check every new session line with it first).
 TAG=${1:?tag}; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
@@ -27,6 +30,19 @@ cmd_of() {
     *) echo "$1" ;;
   esac
 }
+if [ -n "$DRY" ]; then  # print the command of every step instead of running it
+  for step in "$@"; do
+    kind=${step%%:*}; rest=${step#*:}; [ "$rest" = "$step" ] && rest=""
+    case "$kind" in
+      ab) IFS=: read -r kv what <<< "$rest"; echo "[$kind] for ${kv#*=} of ${kv%%=*}: $(cmd_of "$what")" ;;
+      trace|pmc) IFS=: read -r name what <<< "$rest"; echo "[$kind $name] $(cmd_of "$what")" ;;
+      kab) echo "[kab] python tools/knob_ab.py $rest" ;;
+      run) echo "[run] $rest" ;;
+      *) echo "[$kind] $rest" ;;
+    esac
+  done
+  exit 0
+fi
 for step in "$@"; do
   kind=${step%%:*}; rest=${step#*:}; [ "$rest" = "$step" ] && rest=""
   echo "=== $step" | tee -a $O/session.log
@@ -52,21 +68,21 @@ PY
       IFS=: read -r kv what <<< "$rest"; k=${kv%%=*}; vals=${kv#*=}
       for v in ${vals//,/ }; do
         echo "--- $k=$v  ($what)" | tee -a $O/ab.log
-        env $k=$v timeout 600 $(cmd_of $what) 2>&1 | tail -4 | cut -c1-600 | tee -a $O/ab.log
+        env $k=$v timeout ${STEP_TIMEOUT:-300} $(cmd_of "$what") < /dev/null 2>&1 | tail -4 | cut -c1-600 | tee -a $O/ab.log
       done ;;
     trace)
       IFS=: read -r name what <<< "$rest"
-      ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_$name -o t -- $(cmd_of $what) > $O/${name}_trace.log 2>&1 )
+      ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_$name -o t -- $(cmd_of "$what") < /dev/null > $O/${name}_trace.log 2>&1 )
       python tools/rocpd_stats.py /tmp/tr_$name/t_results.db $O/${name}_kernel_stats.md 2>&1 | tail -2 ;;
     pmc)
       IFS=: read -r name what <<< "$rest"; i=0
       for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
         i=$((i+1))
-        ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_${name}_$i -o b -- $(cmd_of $what) > $O/${name}_pmc$i.log 2>&1 )
+        ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_${name}_$i -o b -- $(cmd_of "$what") < /dev/null > $O/${name}_pmc$i.log 2>&1 )
       done
       python tools/pmc_summary.py $O/${name}_pmc_summary /tmp/pmc_${name}_1 /tmp/pmc_${name}_2 /tmp/pmc_${name}_3 2>&1 | tail -3 ;;
-    kab) timeout 600 python tools/knob_ab.py $rest 2>&1 | grep -v amdgpu.ids | tee -a $O/knob_ab.txt ;;
-    run) echo "$rest" >> $O/run.log; ( timeout 900 bash -c "$rest" 2>&1 | tail -${TAIL:-60} ) | tee -a $O/run.log ;;
+    kab) timeout ${STEP_TIMEOUT:-400} python tools/knob_ab.py $rest < /dev/null 2>&1 | grep -v amdgpu.ids | tee -a $O/knob_ab.txt ;;
+    run) echo "$rest" >> $O/run.log; ( timeout ${STEP_TIMEOUT:-600} bash -c "$rest" < /dev/null 2>&1 | tail -${TAIL:-60} ) | tee -a $O/run.log ;;
     profiles) bash tools/collect_profiles.sh $TAG ;;
     smoke) ( time timeout 900 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -8 ) 2>&1 | tee -a $O/smoke.log ;;
     *) echo "unknown step $step" ;;

@@ -151,7 +151,7 @@ int qa_profile_begin(void) {
     return QA_OK;
 }
 
-// out[cfg*4 + {0,1,2,3}] = {algorithmic FLOPs, elapsed ms, launches, algorithmic bytes} for cfg in {128x32, 128x64, 128x128}
+// out[cfg*4 + {0,1,2,3}] = {algorithmic FLOPs, elapsed ms, launches, algorithmic bytes} for cfg in {128x32, 128x64, 128x128, 64x128, 64x64}
 int qa_profile_end(double* out, int32_t n_out) {
     g_prof_on = false;
     if (!out || n_out < PROF_NCFG * 4) {
@@ -189,7 +189,7 @@ int qa_profile_end(double* out, int32_t n_out) {
         if (FILE* f = fopen(path, "w")) {
             double tot = 0.0;
             for (auto& a : agg) tot += a.ms;
-            fprintf(f, "| M | N | K | ksize | flags(res1 gate2 pro4 act8) | cfg(0=128x32 1=128x64 2=128x128) | launches | total ms | share | avg us | TFLOP/s |\n|---|---|---|---|---|---|---|---|---|---|---|\n");
+            fprintf(f, "| M | N | K | ksize | flags(res1 gate2 pro4 act8) | cfg(0=128x32 1=128x64 2=128x128 3=64x128 4=64x64) | launches | total ms | share | avg us | TFLOP/s |\n|---|---|---|---|---|---|---|---|---|---|---|\n");
             for (auto& a : agg)
                 fprintf(f, "| %d | %d | %d | %d | %d | %d | %ld | %.3f | %.3f | %.1f | %.1f |\n", a.M, a.N, a.K, a.ksize, a.flags, a.cfg, a.n, a.ms,
                         a.ms / tot, 1e3 * a.ms / a.n, a.flops / (a.ms * 1e-3) / 1e12);

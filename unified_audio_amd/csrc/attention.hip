@@ -50,11 +50,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
     // `wave` through readfirstlane: every wave-level test below (tile skips, mask tests) is then a SCALAR branch.  As a VGPR value
     // hipcc lowers them to exec-masked regions, and exec-masked VMEM next to register-staged prefetches is where ROCm 7.2 mis-tracks
     // outstanding loads (see fetch()).
-#if defined(QA_ATT_OLD) || (defined(QA_ATT_SWAVE) && QA_ATT_SWAVE == 0)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#else
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#endif
     const int ql = lane & 31, hh = lane >> 5;
     const int b = blockIdx.z, head = blockIdx.y;
     const int q_blk0 = blockIdx.x * 128;
@@ -113,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
     // is set on any tile that reaches n_keys) and their probability is exactly 0, so a finite stand-in row changes nothing - and
     // every load of the kernel is UNCONDITIONAL.  The round-2 form (`if (key < n_keys) load; else zeros`) put the prefetch into an
     // exec-masked region; with it hipcc (ROCm 7.2) re-used the staging registers while the loads were still in flight for
-    // HD = 64 at n_keys = 1500: half of all outputs differed from run to run (tools/diag_attention.py on the -DQA_ATT_OLD build,
+    // HD = 64 at n_keys = 1500: half of all outputs differed from run to run (tools/diag_attention.py on a build of that form,
     // profiles/r03_attention_determinism.txt).  Caught by the at-size parity test of H-Codec 2.0 (tests/test_at_size_gpu.py).
     constexpr int NLD = HD / 32;  // float4 per thread per operand: 32 keys x HD floats over 256 threads
     // native vector type, NOT float4: with float4 staging arrays hipcc funnels the unconditional loads through ONE temporary register
@@ -125,19 +121,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
         for (int j = 0; j < NLD; ++j) {
             const int i = tid + 256 * j;
             const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
-#ifdef QA_ATT_OLD  // diagnostic build only (tools/variants.py): the round-2 predicated prefetch
-            const int key = kt * 32 + row;
-            kreg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            vreg[j] = kreg[j];
-            if (key < n_keys) {
-                kreg[j] = *reinterpret_cast<const f32x4*>(kb + (long long)key * ldkv + c4);
-                vreg[j] = *reinterpret_cast<const f32x4*>(vb + (long long)key * ldkv + c4);
-            }
-#else
             const int key = min(kt * 32 + row, n_keys - 1);
             kreg[j] = *reinterpret_cast<const f32x4*>(kb + (long long)key * ldkv + c4);
             vreg[j] = *reinterpret_cast<const f32x4*>(vb + (long long)key * ldkv + c4);
-#endif
         }
     };
     fetch(kt0);
@@ -155,11 +141,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
         if (dbg & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // wave-uniform skips: the whole tile is masked for this wave, or the wave owns no query at all (the last query block of a
         // sequence that is not a multiple of 128: at N = 283 three of the four waves of block 3 would multiply clamped rows)
-#ifdef QA_ATT_OLD  // diagnostic build: the round-2 form of the two wave-level tests (tools/variants.py)
-        if (kt * 32 > wave_last_key || kt * 32 + 31 < wave_first_key || q_blk0 + wave * 32 >= n_q) continue;
-#else
         if (!(dbg & 8) && (kt * 32 > wave_last_key || kt * 32 + 31 < wave_first_key || q_blk0 + wave * 32 >= n_q)) continue;
-#endif
 
         // S^T = K Q^T
         f32x16 s;
@@ -199,11 +181,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
         // online softmax in base 2 (per lane = per query; the two halves of the wave hold interleaved key groups).  Masks are
         // evaluated only on tiles that can contain a hidden key for some query of this wave (wave-uniform test).
         const int q_first = q_blk0 + wave * 32, q_last = q_first + 31;
-#ifdef QA_ATT_OLD
-        const bool need_mask = ring || kt * 32 + 31 >= n_keys ||
-#else
         const bool need_mask = (dbg & 16) || ring || kt * 32 + 31 >= n_keys ||
-#endif
                                (lin_causal && (kt * 32 + 31 > q_first + off || (context > 0 && kt * 32 < q_last + off - context + 1)));
         float tmax = -INFINITY;
         if (BIAS || need_mask) {

@@ -131,10 +131,18 @@ struct ConvParams {
     const float* w2;
     const float* bias2;
     const float* gamma2;
+    // Arg-min epilogue (RVQ distance GEMM, rvq.hip): instead of storing y = x w^T, every group of 32 consecutive output columns of a row
+    // is reduced to its nearest code - dist = (am_x2[m] - 2 y[m, n]) + am_e2[n] (core_vq.py:225-229 association), lowest n on ties - and
+    // only (dist, n) goes to am_dist / am_idx [M, am_ld]: the [n_vec, K] product matrix never reaches memory.  y may be null.
+    const float* am_x2;
+    const float* am_e2;
+    float* am_dist;
+    int* am_idx;
+    int am_ld;
 };
 
 // Live measurement hook (bench.py): when enabled every conv_gemm launch is bracketed by HIP events on its own stream.
-enum { PROF_CFG_128x32 = 0, PROF_CFG_128x64 = 1, PROF_CFG_128x128 = 2, PROF_NCFG = 3 };
+enum { PROF_CFG_128x32 = 0, PROF_CFG_128x64 = 1, PROF_CFG_128x128 = 2, PROF_CFG_64x128 = 3, PROF_CFG_64x64 = 4, PROF_NCFG = 5 };
 bool profile_enabled();
 bool serial_mode();  // qa_set_serial / QA_SERIAL=1: no internal stream concurrency (every kernel alone on the device)
 void profile_record_begin(int cfg, double flops, double bytes, hipStream_t s, const ConvParams* p = nullptr);

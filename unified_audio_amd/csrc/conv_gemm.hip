@@ -93,7 +93,7 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const ConvParams& p, long lo
 // disappear from the main loop - about 20 of its ~50 non-MFMA instructions, each of which costs ~30 cycles beside the co-resident
 // workgroup's MFMAs.
 template <int BM, int BN, int WM, int WN, bool PRO_ELU, int BK = 32, bool LINEAR = false>
-__global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(const ConvParams p_in) {
+__global__ __launch_bounds__(256, (BM == 64 && (BK == 16 || BN == 64) ? 4 : (BK == 16 ? 3 : 2))) void conv_gemm_kernel(const ConvParams p_in) {
     ConvParams p = p_in;
     constexpr int LDS = BK + 4;
     constexpr int RPP = 256 / (BK / 4);  // rows staged per pass: 8 (BK=32) or 4 (BK=16) threads cover one row chunk
@@ -317,6 +317,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(cons
     constexpr int EP_C4 = BN / 4;          // float4 per row
     static_assert(EP_ROWS * EP_LD <= 2 * (BM + BN) * LDS, "epilogue staging must fit in the operand buffers");
     static_assert(256 % EP_C4 == 0, "a thread keeps its column group across iterations");
+    static_assert(EP_C4 % 8 == 0, "arg-min epilogue: the 8 lanes of a 32-column group are consecutive lanes of one wave");
     float* stage = smem;
     const int row_l = lane & 31, col_h = 4 * (lane >> 5);
     const int ep_c4 = tid % EP_C4, ep_r0 = tid / EP_C4;
@@ -341,6 +342,37 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_gemm_kernel(cons
 #pragma unroll 1
         for (int r = ep_r0; r < EP_ROWS; r += 256 / EP_C4) {
             const long long m = m0 + (r >> 5) * WTM + i * 32 + (r & 31);
+            if (p.am_dist) {  // launch-uniform: the RVQ arg-min epilogue (ConvParams::am_*); every lane takes part in the shuffles
+                float best = INFINITY;
+                int bi = 0x7fffffff;
+                if (m < p.M && ep_n < p.N) {
+                    const f32x4 sv = *reinterpret_cast<const f32x4*>(stage + r * EP_LD + 4 * ep_c4);
+                    const f32x4 e4 = *reinterpret_cast<const f32x4*>(p.am_e2 + ep_n);
+                    const float xx = p.am_x2[m];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {  // codes ascend: strict '<' keeps the first minimum
+                        const float dist = (xx - 2.f * sv[e]) + e4[e];
+                        if (dist < best) {
+                            best = dist;
+                            bi = ep_n + e;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) {  // the 8 lanes of a 32-column group are consecutive lanes of one wave (EP_C4 % 8 == 0)
+                    const float d2 = __shfl_xor(best, o, 64);
+                    const int i2 = __shfl_xor(bi, o, 64);
+                    if (d2 < best || (d2 == best && i2 < bi)) {
+                        best = d2;
+                        bi = i2;
+                    }
+                }
+                if ((ep_c4 & 7) == 0 && m < p.M && ep_n < p.N) {
+                    p.am_dist[m * p.am_ld + (ep_n >> 5)] = best;
+                    p.am_idx[m * p.am_ld + (ep_n >> 5)] = bi;
+                }
+                continue;
+            }
             if (m >= p.M || ep_n >= p.N) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * EP_LD + 4 * ep_c4);
             if (p.vec_epi) {  // N % 4 == 0, every leading dimension and pointer 16-byte aligned
@@ -380,10 +412,12 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
     const long long tiles = ng * ceil_div(p.M, BM) * ceil_div(p.N, BN);
     const bool prof = profile_enabled();
     if (prof) {
-        const int cfg = BN == 32 ? PROF_CFG_128x32 : (BN == 64 ? PROF_CFG_128x64 : PROF_CFG_128x128);
+        const int cfg = BM == 64 ? (BN == 64 ? PROF_CFG_64x64 : PROF_CFG_64x128) : (BN == 32 ? PROF_CFG_128x32 : (BN == 64 ? PROF_CFG_128x64 : PROF_CFG_128x128));
         const double n = p.algo_n ? p.algo_n : p.N, k = p.algo_k ? p.algo_k : p.K;
         // algorithmic bytes: every input frame, weight and output element once (+ fused residual / gate reads)
-        const double elems = (double)p.B * p.T_in * p.C_in + n * k + (double)p.M * n * (1.0 + (p.res ? 1.0 : 0.0) + (p.gate ? 1.0 : 0.0));
+        const double out_elems = p.am_dist ? 2.0 * (double)p.M * p.am_ld + p.M + n  // arg-min epilogue: (dist, idx) per 32 columns + |r|^2 + |e|^2
+                                            : (double)p.M * n * (1.0 + (p.res ? 1.0 : 0.0) + (p.gate ? 1.0 : 0.0));
+        const double elems = (double)p.B * p.T_in * p.C_in + n * k + out_elems;
         profile_record_begin(cfg, ng * 2.0 * (double)p.M * n * k, ng * 4.0 * elems, stream, &p);
     }
     // BK = 16 chunks need 45 KB / 35 KB of LDS, so 3-4 workgroups are co-resident per CU (BK = 32: 2) and cover each
@@ -444,6 +478,8 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
                                      (!p.y2 || (p.alpha2 && al16(p.alpha2) && al16(p.y2) && p.ldy2 % 4 == 0))),
                "conv_gemm: Snake activation / second output need the float4 epilogue and 16-byte aligned alpha vectors");
     QA_REQUIRE(p.dilation <= 1 || (p.pad_mode == PAD_ZERO && p.in_rep <= 1), "conv_gemm: dilation needs zero padding");
+    QA_REQUIRE(!p.am_dist || (q.vec_epi && p.am_idx && p.am_x2 && p.am_e2 && al16(p.am_e2) && p.am_ld >= (p.N + 31) / 32 && !p.y2 && p.groups <= 1),
+               "conv_gemm: the arg-min epilogue needs N %% 4 == 0, x2 / e2 / dist / idx and am_ld >= ceil(N / 32)");
     QA_REQUIRE(!p.rope || (q.vec_epi && p.rope_hd % 4 == 0 && p.rope_n % 4 == 0 && p.rope_T > 0 && al16(p.rope)),
                "conv_gemm: fused RoPE needs the float4 epilogue (N, strides, pointers multiples of 4 / 16 B)");
     int cfg;
@@ -463,6 +499,8 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
     switch (cfg) {
         case PROF_CFG_128x32: return launch_cfg<128, 32, 4, 1>(q, stream);
         case PROF_CFG_128x64: return launch_cfg<128, 64, 2, 2>(q, stream);
+        case PROF_CFG_64x128: return launch_cfg<64, 128, 1, 4>(q, stream);
+        case PROF_CFG_64x64: return launch_cfg<64, 64, 2, 2>(q, stream);
         default: return launch_cfg<128, 128, 2, 2>(q, stream);
     }
 }

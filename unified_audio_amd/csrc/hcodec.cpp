@@ -1216,18 +1216,20 @@ static int ensure_masked_streams(qa_hcodec* h) {
 // valid results, and the device stops choosing the persistent kernel by itself.
 template <typename F>
 static int run_graph_checked(qa_hcodec* h, Ctx& c, F&& graph) {
-    const unsigned long long before = lstm_persistent_count(h->device);
+    void* ticket = nullptr;
+    QA_TRY(lstm_call_begin(h->device, &ticket));
     {
         const int st = graph();
         if (st != QA_OK) {  // error path only: internal streams (aggregator side stream, CU-masked streams) may still run out of the workspace
             c.lstm_stream = nullptr;
             (void)hipDeviceSynchronize();
+            bool ignored = false;
+            (void)lstm_call_end(ticket, c.stream, &ignored);
             return st;
         }
     }
-    if (lstm_persistent_count(h->device) == before) return QA_OK;
     bool failed = false;
-    QA_TRY(lstm_persistent_collect(h->device, c.stream, &failed));
+    QA_TRY(lstm_call_end(ticket, c.stream, &failed));  // host-synchronous only for a call that launched an in-launch recurrence
     if (!failed) return QA_OK;
     std::fprintf(stderr, "libquarkaudio_hip: the grid barrier of the persistent LSTM recurrence timed out on device %d (shared device?); "
                          "re-running the call on the per-step kernels\n", h->device);

@@ -72,8 +72,8 @@ int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_st
                 hipStream_t s, bool eager = false);
 // persistent-recurrence bookkeeping for the model graphs: launches so far on `dev`; wait for `s` and report (and clear) a barrier
 // time-out; make this thread's next launch_lstm calls take the per-step kernels
-unsigned long long lstm_persistent_count(int dev);
-int lstm_persistent_collect(int dev, hipStream_t s, bool* failed);
+int lstm_call_begin(int dev, void** ticket);                  // open a model-graph call: own error word + launch count (thread-local)
+int lstm_call_end(void* ticket, hipStream_t s, bool* failed);  // syncs `s` only if the call launched an in-launch recurrence
 void lstm_force_per_step(bool on);
 
 // rvq.hip

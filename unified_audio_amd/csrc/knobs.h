@@ -11,7 +11,7 @@ namespace qa {
 
 #define QA_KNOB_TABLE(X)                                                                                                           \
     X(SERIAL, "QA_SERIAL", 0, "1: no internal stream concurrency (every kernel alone on the device; = qa_set_serial)")           \
-    X(GEMM_CFG, "QA_GEMM_CFG", -1, "force the conv_gemm tile: 0 = 128x32, 1 = 128x64, 2 = 128x128 (-1: cost model)")             \
+    X(GEMM_CFG, "QA_GEMM_CFG", -1, "force the conv_gemm tile: 0 = 128x32, 1 = 128x64, 2 = 128x128, 3 = 64x128, 4 = 64x64 (-1: cost model)")             \
     X(GEMM_BK16, "QA_GEMM_BK16", 1 << 30, "largest K that takes the BK = 16 K-chunk variant")                                     \
     X(GEMM_BK16_MIN_TILES, "QA_GEMM_BK16_MIN_TILES", 384, "fewest tiles of a launch that take BK = 16")                          \
     X(GEMM_LINEAR, "QA_GEMM_LINEAR", 1, "table-free K loop for ksize-1 layers")                                                  \

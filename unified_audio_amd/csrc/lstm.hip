@@ -214,7 +214,7 @@ namespace {
 // sync words, one per 128-byte line: grp_cnt[8] | top_cnt | top_gen | grp_gen[8] | err
 enum { SY_GRP_CNT = 0, SY_TOP_CNT = 8, SY_TOP_GEN = 9, SY_GRP_GEN = 10, SY_ERR = 18, SY_WORDS = 19, SY_STRIDE = 32 };
 // spin bound of the barrier polls: QA_LSTM_SPIN_LIMIT, default 2^21 x (s_sleep + one L2 round trip) ~ seconds, then the barrier is declared broken
-constexpr int LSTM_SYNC_RING = 8;
+constexpr int LSTM_SYNC_RING = 64;  // launches in flight on one device before a sync block is re-armed (several handles share the ring)
 }  // namespace
 
 #define QA_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -602,33 +602,64 @@ __global__ __launch_bounds__(NW * 64, 1) void lstm_team_kernel(const float* __re
 }
 
 namespace {
+// One model-graph call's view of the in-launch recurrences it issued (the error word and the launch counter used to be
+// per DEVICE, so of two handles sharing a device the one that synchronised first collected - and cleared - the other's failure).
+// A call takes a ticket (lstm_call_begin): its own mapped pinned error word out of the device's pool and its own launch count;
+// every in-launch recurrence the calling thread issues until lstm_call_end reports into that word and nowhere else.
+struct LstmCall {
+    unsigned* err_host = nullptr;
+    unsigned* err_dev = nullptr;
+    unsigned launches = 0;
+    int dev = -1, slot = -1;
+};
+constexpr int LSTM_ERR_POOL = 64;  // error words (= concurrent model-graph calls) per device; further calls share the device word
 struct LstmPersistentDev {
     unsigned* sync = nullptr;      // LSTM_SYNC_RING blocks of SY_WORDS * SY_STRIDE words (device)
-    unsigned* err_host = nullptr;  // pinned, mapped: written by a kernel whose barrier timed out
+    unsigned* err_host = nullptr;  // pinned, mapped: LSTM_ERR_POOL + 1 words; [LSTM_ERR_POOL] = the device word of ticket-less callers
     unsigned* err_dev = nullptr;   // device alias of err_host
+    unsigned long long pool_busy = 0;  // bit i: pool word i belongs to a live call
     int cus = 0, next = 0;
-    unsigned long long launches = 0;  // persistent launches so far (the model graphs compare it around a call)
+    unsigned long long launches = 0;  // persistent launches so far on this device (diagnostics)
     bool degraded = false;            // a barrier timed out on this device: the auto mode stops choosing the persistent kernel
 };
 LstmPersistentDev g_lstm_p[16];
 std::mutex g_lstm_mu;  // guards the persistent-device table and the step-graph cache
 thread_local bool t_lstm_per_step = false;  // lstm_force_per_step(): the re-run of a call whose persistent recurrence failed
+thread_local LstmCall* t_lstm_call = nullptr;  // the calling thread's open model-graph call (lstm_call_begin .. lstm_call_end)
 
 // -1 auto (widths whose per-step weight stream dominates: d >= 1536), 0 off, 1 on for every supported width
 int lstm_persistent_mode() { return (int)knob(K_LSTM_PERSISTENT); }
+
+// the error word a launch of the calling thread reports into, and the book-keeping of one launch
+unsigned* lstm_err_word(LstmPersistentDev& P, int dev) {
+    if (t_lstm_call && t_lstm_call->dev == dev && t_lstm_call->err_dev) return t_lstm_call->err_dev;
+    return P.err_dev + LSTM_ERR_POOL;
+}
+void lstm_count_launch(LstmPersistentDev& P, int dev) {
+    ++P.launches;
+    if (t_lstm_call && t_lstm_call->dev == dev) ++t_lstm_call->launches;
+}
 }  // namespace
+
+static int lstm_err_pool_init(LstmPersistentDev& P) {
+    if (P.err_host) return QA_OK;
+    QA_HIP(hipHostMalloc(reinterpret_cast<void**>(&P.err_host), sizeof(unsigned) * (LSTM_ERR_POOL + 1), hipHostMallocMapped));
+    for (int i = 0; i <= LSTM_ERR_POOL; ++i) P.err_host[i] = 0u;
+    QA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&P.err_dev), P.err_host, 0));
+    return QA_OK;
+}
 
 // sync ring + error word of a device (first use), and the backstop for a caller that did not collect an earlier failure
 static int lstm_persistent_prepare(LstmPersistentDev& P, int dev) {
     if (!P.sync) {
         QA_HIP(hipDeviceGetAttribute(&P.cus, hipDeviceAttributeMultiprocessorCount, dev));
         QA_HIP(hipMalloc(reinterpret_cast<void**>(&P.sync), sizeof(unsigned) * LSTM_SYNC_RING * SY_WORDS * SY_STRIDE));
-        QA_HIP(hipHostMalloc(reinterpret_cast<void**>(&P.err_host), sizeof(unsigned), hipHostMallocMapped));
-        *P.err_host = 0u;
-        QA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&P.err_dev), P.err_host, 0));
     }
-    if (*static_cast<volatile unsigned*>(P.err_host) != 0u) {  // backstop: a caller that did not collect (lstm_persistent_collect)
-        *P.err_host = 0u;
+    QA_TRY(lstm_err_pool_init(P));
+    // backstop for launches made OUTSIDE a model-graph call (no ticket: they report into the device word and nobody collects it)
+    volatile unsigned* dw = P.err_host + LSTM_ERR_POOL;
+    if (*dw != 0u) {
+        *dw = 0u;
         P.degraded = true;
         set_error("lstm: the grid barrier of an earlier persistent LSTM call on device %d timed out (its outputs are invalid): the kernel "
                   "needs every workgroup resident at once - another persistent kernel was sharing the device; set QA_LSTM_PERSISTENT=0", dev);
@@ -657,6 +688,7 @@ static int launch_lstm_persistent(const float* xw, const float* w_hh_ug, float* 
     // QA_LSTM_FAULT (tests): the barrier waits for one workgroup more than exists, i.e. what a starved launch looks like
     const int nwg = d / U, ngrp = 8, per_grp = nwg / ngrp + (knob(K_LSTM_FAULT) ? 1 : 0);
     const unsigned spin_limit = (unsigned)std::max<long long>(64, std::min<long long>(knob(K_LSTM_SPIN_LIMIT), 1LL << 30));
+    unsigned* const err_word = lstm_err_word(P, dev);
     for (int b0 = 0; b0 < B; b0 += 32) {
         const int bn = std::min(32, B - b0);
         const float* xw_b = xw + (long long)b0 * T * 4 * d;
@@ -666,7 +698,7 @@ static int launch_lstm_persistent(const float* xw, const float* w_hh_ug, float* 
         P.next = (P.next + 1) % LSTM_SYNC_RING;
         QA_HIP(hipMemsetAsync(sy, 0, sizeof(unsigned) * SY_WORDS * SY_STRIDE, s));  // every polled word, before EVERY launch
 #define QA_LP(MT, NT_, NI) \
-    hipLaunchKernelGGL((lstm_persistent_kernel<MT, NT_, NI>), dim3(nwg), dim3(512), 0, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, U, sy, ngrp, per_grp, P.err_dev, spin_limit)
+    hipLaunchKernelGGL((lstm_persistent_kernel<MT, NT_, NI>), dim3(nwg), dim3(512), 0, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, U, sy, ngrp, per_grp, err_word, spin_limit)
         const bool two = bn > 16;
         if (d == 1536) { if (two) QA_LP(2, 2, 12); else QA_LP(1, 2, 12); }
         else if (d == 1024 && NT == 2) { if (two) QA_LP(2, 2, 8); else QA_LP(1, 2, 8); }
@@ -677,7 +709,7 @@ static int launch_lstm_persistent(const float* xw, const float* w_hh_ug, float* 
         else { if (two) QA_LP(2, 1, 4); else QA_LP(1, 1, 4); }
 #undef QA_LP
         QA_LAUNCH_CHECK();
-        ++P.launches;
+        lstm_count_launch(P, dev);
     }
     *done = true;
     return QA_OK;
@@ -709,12 +741,12 @@ static int launch_lstm_xcd(const float* xw, const float* w_hh_ug, float* h_out, 
         const dim3 grid((unsigned)(n_teams * per_team));
         if (d == 512)
             hipLaunchKernelGGL((lstm_xcd_kernel<512, 8>), grid, dim3(512), pad, s, xw_b, w_hh_ug, h_b, c_b, bn, T, sy, per_team + fault, n_teams,
-                               P.err_dev, spin_limit, mode >= 2 ? 1 : 0);
+                               lstm_err_word(P, dev), spin_limit, mode >= 2 ? 1 : 0);
         else
             hipLaunchKernelGGL((lstm_xcd_kernel<768, 12>), grid, dim3(768), pad, s, xw_b, w_hh_ug, h_b, c_b, bn, T, sy, per_team + fault, n_teams,
-                               P.err_dev, spin_limit, mode >= 2 ? 1 : 0);
+                               lstm_err_word(P, dev), spin_limit, mode >= 2 ? 1 : 0);
         QA_LAUNCH_CHECK();
-        ++P.launches;
+        lstm_count_launch(P, dev);
     }
     *done = true;
     return QA_OK;
@@ -722,7 +754,7 @@ static int launch_lstm_xcd(const float* xw, const float* w_hh_ug, float* h_out, 
 
 // QA_LSTM_TEAM: d = 1024 on 4 teams of 64 workgroups - see lstm_team_kernel; *done as above
 template <int D, int PT>
-static int launch_lstm_team_t(LstmPersistentDev& P, const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T,
+static int launch_lstm_team_t(LstmPersistentDev& P, int dev, const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T,
                               hipStream_t s) {
     constexpr int SG = 2;
     const int n_teams = P.cus / PT;
@@ -738,9 +770,9 @@ static int launch_lstm_team_t(LstmPersistentDev& P, const float* xw, const float
         P.next = (P.next + 1) % LSTM_SYNC_RING;
         QA_HIP(hipMemsetAsync(sy, 0, sizeof(unsigned) * SY_WORDS * SY_STRIDE, s));
         hipLaunchKernelGGL((lstm_team_kernel<D, 8, PT, SG>), dim3((unsigned)(n_teams * PT)), dim3(512), dyn, s, xw + (long long)b0 * T * 4 * D, w_hh_ug,
-                           h_out + (long long)b0 * T * D, c_state + (long long)b0 * D, bn, T, sy, n_teams, fault, P.err_dev, spin_limit);
+                           h_out + (long long)b0 * T * D, c_state + (long long)b0 * D, bn, T, sy, n_teams, fault, lstm_err_word(P, dev), spin_limit);
         QA_LAUNCH_CHECK();
-        ++P.launches;
+        lstm_count_launch(P, dev);
     }
     return QA_OK;
 }
@@ -754,31 +786,61 @@ static int launch_lstm_team(const float* xw, const float* w_hh_ug, float* h_out,
     if (t_lstm_per_step || knob(K_LSTM_TEAM) <= 0 || d != 1024 || P.degraded || T < 2) return QA_OK;
     QA_TRY(lstm_persistent_prepare(P, dev));
     if (P.cus != 256) return QA_OK;  // the team size is laid out for 256 CUs
-    QA_TRY((launch_lstm_team_t<1024, 64>(P, xw, w_hh_ug, h_out, c_state, B, T, s)));
+    QA_TRY((launch_lstm_team_t<1024, 64>(P, dev, xw, w_hh_ug, h_out, c_state, B, T, s)));
     *done = true;
     return QA_OK;
 }
 
-// ---- what the model graphs (hcodec.cpp) do about a timed-out barrier: a call that launched the persistent kernel waits for its
-// stream before returning, reads the error word, and - if a barrier broke - runs itself again on the per-step kernels, so the
-// call that HIT the failure still returns valid results (the error used to surface one call late, or never).
-unsigned long long lstm_persistent_count(int dev) {
+// ---- what the model graphs (hcodec.cpp) do about a timed-out barrier: a call opens a ticket (lstm_call_begin), and if it launched an
+// in-launch recurrence it waits for its stream before returning (lstm_call_end), reads ITS error word, and - if a barrier broke - runs
+// itself again on the per-step kernels, so the call that HIT the failure still returns valid results (the error used to
+// surface one call late, or never; ADVICE r03: per call, not per device - two handles on two threads cannot collect each other's word).
+int lstm_call_begin(int dev, void** ticket) {
+    *ticket = nullptr;
+    if (dev < 0 || dev >= 16) return QA_OK;
     std::lock_guard<std::mutex> lock(g_lstm_mu);
-    return (dev >= 0 && dev < 16) ? g_lstm_p[dev].launches : 0ull;
+    LstmPersistentDev& P = g_lstm_p[dev];
+    QA_TRY(lstm_err_pool_init(P));
+    LstmCall* c = new LstmCall();
+    c->dev = dev;
+    for (int i = 0; i < LSTM_ERR_POOL; ++i)  // more than LSTM_ERR_POOL concurrent calls: the rest share the device word
+        if (!(P.pool_busy >> i & 1ull)) {
+            P.pool_busy |= 1ull << i;
+            c->slot = i;
+            c->err_host = P.err_host + i;
+            c->err_dev = P.err_dev + i;
+            *c->err_host = 0u;
+            break;
+        }
+    t_lstm_call = c;
+    *ticket = c;
+    return QA_OK;
 }
 
-int lstm_persistent_collect(int dev, hipStream_t s, bool* failed) {
+int lstm_call_end(void* ticket, hipStream_t s, bool* failed) {
     *failed = false;
-    QA_HIP(hipStreamSynchronize(s));
+    LstmCall* c = static_cast<LstmCall*>(ticket);
+    if (!c) return QA_OK;
+    if (t_lstm_call == c) t_lstm_call = nullptr;
+    int st = QA_OK;
+    if (c->launches) {  // only a call that launched such a kernel pays the host synchronisation
+        if (hipStreamSynchronize(s) != hipSuccess) {
+            set_error("lstm: hipStreamSynchronize failed while collecting an in-launch recurrence");
+            st = QA_ERR_HIP;
+        }
+    }
     std::lock_guard<std::mutex> lock(g_lstm_mu);
-    if (dev < 0 || dev >= 16) return QA_OK;
-    LstmPersistentDev& P = g_lstm_p[dev];
-    if (P.err_host && *static_cast<volatile unsigned*>(P.err_host) != 0u) {
-        *P.err_host = 0u;
+    LstmPersistentDev& P = g_lstm_p[c->dev];
+    // a ticket without a pool word (pool exhausted) reported into the device word (lstm_err_word)
+    volatile unsigned* w = c->err_host ? c->err_host : (P.err_host ? P.err_host + LSTM_ERR_POOL : nullptr);
+    if (st == QA_OK && c->launches && w && *w != 0u) {
+        *w = 0u;
         if (knob(K_LSTM_FAULT) == 0) P.degraded = true;  // an injected fault (tests) says nothing about the device
         *failed = true;
     }
-    return QA_OK;
+    if (c->slot >= 0) P.pool_busy &= ~(1ull << c->slot);
+    delete c;
+    return st;
 }
 
 void lstm_force_per_step(bool on) { t_lstm_per_step = on; }

@@ -6,11 +6,13 @@
 //
 // Main path (D a multiple of 32): per stage the distance products  S = R E_q^T  ([n_vec, K], K = 1024 codes x D = 512) are a
 // plain contraction and run on the library's implicit-GEMM kernel (conv_gemm.hip: code rows and residual rows staged through
-// LDS, fp32 MFMA, >= 256 workgroups even for ~1000 vectors because the tile grid covers vectors x codes), then ONE wave per
-// vector (rvq_pick_kernel) forms dist = (|r|^2 - 2 s) + |e|^2 with the reference's association, reduces the arg-min over the K
-// codes with wave shuffles (lowest index on ties), writes the index, subtracts the chosen code from the residual and leaves
-// the new |r|^2 for the next stage.  The stages are sequential by definition (core_vq.py:394-404), so a stage = 2 launches;
-// vectors are processed in chunks of 16384 so S (64 MB) stays inside the Infinity Cache between the two.
+// LDS, fp32 MFMA, >= 256 workgroups even for ~1000 vectors because the tile grid covers vectors x codes) - with the ARG-MIN IN ITS
+// EPILOGUE (ConvParams::am_*, round 4): dist = (|r|^2 - 2 s) + |e|^2 with the reference's association is formed on the tile while
+// it sits in LDS and every group of 32 codes is reduced to its (dist, index) winner, lowest index on ties, so S itself never
+// reaches memory (round 3 wrote and re-read 4 KB per vector and stage; now 256 B).  Then ONE wave per vector (rvq_pick_kernel)
+// folds the K / 32 group winners in ascending code order, writes the index, subtracts the chosen code from the residual and
+// leaves the new |r|^2 for the next stage.  The stages are sequential by definition (core_vq.py:394-404), so a stage = 2
+// launches; vectors are processed in chunks of 16384.
 // Fallback (other D): all Q stages in ONE launch - a workgroup keeps the residuals of 32 vectors in LDS (fp32), each of its 4
 // waves sweeps a quarter of the codebook 32 codes at a time with v_mfma_f32_32x32x2_f32 (A = residual tile from LDS, B = code
 // rows straight from L2), keeps a per-lane running arg-min, then the winners are reduced with wave shuffles and one LDS
@@ -159,28 +161,24 @@ __global__ __launch_bounds__(256) void rvq_prep_kernel(const float* __restrict__
     if (lane == 0) x2[v] = s;
 }
 
-// One wave per vector: arg-min over the K codes of dist = (|r|^2 - 2 r.e) + |e|^2 (core_vq.py:225-229 association), lowest
+// One wave per vector: arg-min over the K / 32 group winners the distance GEMM's epilogue left (dist = (|r|^2 - 2 r.e) + |e|^2,
+// core_vq.py:225-229 association; a group's winner is its lowest index of minimal distance, and groups ascend with the lane), lowest
 // index on ties (torch.max returns the first maximum of the negated distance); then r <- r - e[idx], |r|^2 refreshed.
-__global__ __launch_bounds__(256) void rvq_pick_kernel(const float* __restrict__ S, long long ldS, float* __restrict__ x2,
-                                                       const float* __restrict__ e2q, const float* __restrict__ cbq,
-                                                       float* __restrict__ R, long long n, int K, int D,
-                                                       long long* __restrict__ indices, int Q, int q) {
+__global__ __launch_bounds__(256) void rvq_pick_kernel(const float* __restrict__ pd, const int* __restrict__ pi, int n_groups,
+                                                       float* __restrict__ x2, const float* __restrict__ cbq, float* __restrict__ R,
+                                                       long long n, int D, long long* __restrict__ indices, int Q, int q) {
     const int lane = threadIdx.x & 63;
     const long long v = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= n) return;
-    const float xx = x2[v];
-    const float* row = S + v * ldS;
     float best = INFINITY;
     int bi = 0x7fffffff;
-    for (int c = lane * 4; c < K; c += 256) {  // codes ascend per lane: strict '<' keeps the first minimum
-        const float4 s4 = *reinterpret_cast<const float4*>(row + c);
-        const float4 e4 = *reinterpret_cast<const float4*>(e2q + c);
-        const float d0 = (xx - 2.f * s4.x) + e4.x, d1 = (xx - 2.f * s4.y) + e4.y, d2 = (xx - 2.f * s4.z) + e4.z,
-                    d3 = (xx - 2.f * s4.w) + e4.w;
-        if (d0 < best) { best = d0; bi = c; }
-        if (d1 < best) { best = d1; bi = c + 1; }
-        if (d2 < best) { best = d2; bi = c + 2; }
-        if (d3 < best) { best = d3; bi = c + 3; }
+    for (int g = lane; g < n_groups; g += 64) {  // groups ascend per lane: strict '<' keeps the first minimum
+        const float d = pd[v * n_groups + g];
+        const int i = pi[v * n_groups + g];
+        if (d < best) {
+            best = d;
+            bi = i;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -262,9 +260,11 @@ int launch_rvq_search(const float* x, long long n_vec, const float* codebooks, c
     if (rvq_gemm_ok(K, D) && knob(K_RVQ_LEGACY) == 0) {
         QA_REQUIRE(scratch != nullptr, "rvq_search: the GEMM path needs rvq_scratch_floats() floats of workspace");
         const long long ch = std::min(n_vec, RVQ_CHUNK);
+        const int ng = (K + 31) / 32;
         float* R = scratch;                  // [ch, D] residuals
-        float* S = R + (size_t)ch * D;       // [ch, K] residual . code products
-        float* x2 = S + (size_t)ch * K;      // [ch]
+        float* pd = R + (size_t)ch * D;      // [ch, K / 32] group winners: distance ...
+        int* pi = reinterpret_cast<int*>(pd + (size_t)ch * ng);  // ... and code index
+        float* x2 = pd + (size_t)ch * K;     // [ch]  (the layout rvq_scratch_floats has always promised: [ch, K] behind R)
         for (long long v0 = 0; v0 < n_vec; v0 += ch) {
             const long long n = std::min(ch, n_vec - v0);
             const unsigned grid = (unsigned)ceil_div(n, 4);
@@ -273,15 +273,15 @@ int launch_rvq_search(const float* x, long long n_vec, const float* codebooks, c
             for (int q = 0; q < Q; ++q) {
                 const float* cbq = codebooks + (long long)q * K * D;
                 qa_conv_args a{};
-                a.x = R; a.w = cbq; a.y = S;
+                a.x = R; a.w = cbq; a.y = pd;  // y is not written in arg-min mode (any non-null aligned pointer)
                 a.B = 1; a.T_in = n; a.C_in = D; a.T_out = n; a.N = K;
                 a.ldx = D; a.ldy = K; a.ldr = K; a.ldg = K;
                 a.ksize = 1; a.stride = 1;
                 ConvParams p;
                 QA_TRY(conv_params_from_args(a, &p));
+                p.am_x2 = x2; p.am_e2 = e2 + (long long)q * K; p.am_dist = pd; p.am_idx = pi; p.am_ld = ng;
                 QA_TRY(launch_conv_gemm(p, s));
-                hipLaunchKernelGGL(rvq_pick_kernel, dim3(grid), dim3(256), 0, s, S, (long long)K, x2, e2 + (long long)q * K, cbq, R, n, K, D,
-                                   indices + v0 * Q, Q, q);
+                hipLaunchKernelGGL(rvq_pick_kernel, dim3(grid), dim3(256), 0, s, pd, pi, ng, x2, cbq, R, n, D, indices + v0 * Q, Q, q);
                 QA_LAUNCH_CHECK();
             }
         }
