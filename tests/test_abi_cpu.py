@@ -100,18 +100,3 @@ def test_resolve_frame_matches_reference_pad1d(qa_lib, L, left, right):
     assert got == ref.tolist()
     zero = [qa_lib.qa_resolve_frame(p, L, max(left, right), 0) for p in range(-left, L + right)]
     assert zero == [-1] * left + list(range(L)) + [-1] * right
-
-
-def test_experiment_transforms_still_apply_to_the_kernel_source():
-    """tools/experiments/*.py rewrite conv_gemm.hip for variant builds (tools/variants.py --transform); every replacement asserts that
-    its anchor occurs exactly once, so an edit of the kernel that silently breaks an experiment shows up here, on the CPU."""
-    import importlib.util
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = open(os.path.join(root, "unified_audio_amd", "csrc", "conv_gemm.hip")).read()
-    spec = importlib.util.spec_from_file_location("pf2", os.path.join(root, "tools", "experiments", "pf2.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    for fn in (mod.transform, mod.transform_interleaved):
-        out = fn(src)
-        assert out != src and "constexpr bool PF2 = BK == 16;" in out and out.count("QA_LOAD_GLOBAL(nx2_)") == 1

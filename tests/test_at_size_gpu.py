@@ -242,16 +242,17 @@ def test_team_lstm_d1024_matches_per_step_and_torch(qa_lib, gpu_device, knob, ca
     assert torch.equal(codec.tap(name).view(3, T, d), outs[1][0].view(B, T, d)[:3])
 
 
-def test_persistent_lstm_barrier_timeout_is_recovered_in_the_same_call(qa_lib, gpu_device, knob, capfd):
+@pytest.mark.parametrize("d,kernels", [(512, ("QA_LSTM_PERSISTENT", "QA_LSTM_XCD")), (1024, ("QA_LSTM_TEAM",))])
+def test_persistent_lstm_barrier_timeout_is_recovered_in_the_same_call(qa_lib, gpu_device, knob, capfd, d, kernels):
     """a persistent-LSTM call whose grid barrier times out (the kernel needs every workgroup resident; a shared device
     starves it) used to return garbage with QA_OK and report the error one LSTM call later.  Now the call that hit it waits for
-    its stream, sees the error word and re-runs on the per-step kernels.  QA_LSTM_FAULT makes the barrier wait for a workgroup that
-    does not exist; QA_LSTM_SPIN_LIMIT shortens the bounded spin from seconds to milliseconds."""
+    its stream, sees ITS error word and re-runs on the per-step kernels.  QA_LSTM_FAULT makes the barrier wait for a workgroup that
+    does not exist; QA_LSTM_SPIN_LIMIT shortens the bounded spin from seconds to milliseconds.  All three in-launch recurrences:
+    lstm_persistent_kernel, lstm_xcd_kernel (d = 512) and lstm_team_kernel (d = 1024, the default of the H-Codec 1.5 decoder)."""
     import dataclasses
 
     import unified_audio_amd as qa
 
-    d = 512
     ospec = dataclasses.replace(R.SPEC_10, dec_dim=d, dec_heads=8, dec_layers=1, convnext_layers=1, dec_inter=2 * d)
     sd = synth.hcodec10_state_dict(92, ospec)
     kw = {f: getattr(ospec, f) for f in ospec.__dataclass_fields__}
@@ -259,10 +260,10 @@ def test_persistent_lstm_barrier_timeout_is_recovered_in_the_same_call(qa_lib, g
     gen = torch.Generator().manual_seed(3)
     ac = torch.randint(0, 1024, (4, 4, 20), generator=gen).to(gpu_device)
     sc = torch.randint(0, 1024, (4, 4, 20), generator=gen).to(gpu_device)
-    knob("QA_LSTM_XCD", 0)
-    knob("QA_LSTM_PERSISTENT", 0)
+    for k in ("QA_LSTM_XCD", "QA_LSTM_PERSISTENT", "QA_LSTM_TEAM"):
+        knob(k, 0)
     want = codec.decode(ac, sc).clone()
-    for which in ("QA_LSTM_PERSISTENT", "QA_LSTM_XCD"):  # both in-launch recurrences share the error word and the re-run
+    for which in kernels:  # the in-launch recurrences share the ticket / re-run machinery
         knob("QA_LSTM_FAULT", 0)
         knob("QA_LSTM_SPIN_LIMIT", 1 << 21)
         knob(which, 1)
@@ -278,7 +279,7 @@ def test_persistent_lstm_barrier_timeout_is_recovered_in_the_same_call(qa_lib, g
         knob(which, 0)
     knob("QA_LSTM_FAULT", 0)
     knob("QA_LSTM_SPIN_LIMIT", 1 << 21)
-    knob("QA_LSTM_XCD", 1)
+    knob(kernels[-1], 1)
     assert torch.equal(codec.decode(ac, sc), ok)  # and the device is usable afterwards (an injected fault does not degrade it)
 
 

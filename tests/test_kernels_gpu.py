@@ -99,7 +99,7 @@ def test_conv1d_cl_matches_torch(qa_lib, gpu_device, case):
     assert err < 2e-6, f"rel err {err}"  # fp32 tolerance: only the summation order differs
 
 
-@pytest.mark.parametrize("case", [4, 5, 6, 8, 10, 11, 13])
+@pytest.mark.parametrize("case", [0, 1, 5, 7, 8, 9, 11, 13, 14, 16])
 def test_conv_gemm_tile_configurations_are_bit_identical(qa_lib, gpu_device, knob, case):
     """Every tile configuration of conv_gemm (QA_GEMM_CFG 1 .. 4: 128x64, 128x128 and the 64-row tiles 64x128 / 64x64 of round 4)
     accumulates an output element over k in the same order, so the choice of tile - which the cost model makes from M, i.e. from
@@ -118,8 +118,8 @@ def test_conv_gemm_tile_configurations_are_bit_identical(qa_lib, gpu_device, kno
     outs = {}
     for cfg in (-1, 1, 2, 3, 4):
         knob("QA_GEMM_CFG", cfg)
-        outs[cfg] = conv1d_cl(qa_lib, x, w, bias, stride=stride, act=c.get("act", 0), post_act=c.get("post", 0), gamma=gamma, residual=res,
-                              gate=gate, T_out=T_out).clone()
+        outs[cfg] = conv1d_cl(qa_lib, x, w, bias, stride=stride, prologue=c.get("prologue", 0), act=c.get("act", 0), post_act=c.get("post", 0),
+                              gamma=gamma, residual=res, gate=gate, T_out=T_out).clone()
     torch.cuda.synchronize()
     assert torch.isfinite(outs[-1]).all()
     for cfg in (1, 2, 3, 4):

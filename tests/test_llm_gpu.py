@@ -122,16 +122,6 @@ def test_unfused_decode_step_matches_reference_goldens(qa_lib, gpu_device, knob,
     golden_stream_parity(name, gpu_device, audit=False)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
-@pytest.mark.parametrize("name", ["lm_unise_se", "lm_unise_tse", "lm_config3_se_b16", "lm_config4_tse_b8"])
-def test_xcd_decode_kernel_matches_reference_goldens(qa_lib, gpu_device, knob, name, mode):
-    """QA_LM_XCD=1 / 2 (csrc/lm_xcd.hip; 2 = weights prefetched across the team barriers): the greedy decode loop as one persistent
-    launch per phase, a decode chain per XCD - through the reference's own token streams, incl. the BASELINE configs[2] / configs[3]
-    shapes."""
-    knob("QA_LM_XCD", mode)  # read at qa_lm_create (extra weight layouts) and at the call
-    golden_stream_parity(name, gpu_device, audit=False)
-
-
 def test_generate_argument_errors(qa_lib, gpu_device):
     import unified_audio_amd as qa
 

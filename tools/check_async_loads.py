@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Build-time guard for the split `load ... wait` inline-asm idiom of the persistent kernels (lstm.hip, lm_xcd.hip).
+"""Build-time guard for the split `load ... wait` inline-asm idiom of the persistent kernels (lstm.hip).
 
 The hand-off loads are written as one asm statement that ISSUES `global_load_dwordx4 vX, ..., off sc1` and a later one that
 WAITS (`s_waitcnt vmcnt(0)` with the value as a "+v" operand).  Between the two the destination registers are being written
@@ -7,7 +7,7 @@ asynchronously, which the compiler does not know: it may legally copy or spill t
 compiles the given sources to gfx950 assembly and proves, per kernel, that no instruction reads or writes the destination
 registers of an `sc1` load between the load and the first following `s_waitcnt vmcnt(0)`.
 
-    python tools/check_async_loads.py [file.hip ...]      (default: lstm.hip lm_xcd.hip)
+    python tools/check_async_loads.py [file.hip ...]      (default: lstm.hip)
 
 Exit status 0 = the invariant holds in every kernel; used by tests/test_sanitizer_cpu.py.
 """
@@ -90,7 +90,7 @@ def check(asm: str) -> tuple[int, list[str]]:
 
 
 def main(argv):
-    files = argv or ["lstm.hip", "lm_xcd.hip"]
+    files = argv or ["lstm.hip"]
     rc = 0
     for f in files:
         path = f if os.path.exists(f) else os.path.join(CSRC, f)

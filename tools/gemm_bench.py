@@ -31,9 +31,10 @@ SHAPES = [  # name, M(rows), N, Cin, k, stride
 
 def bench_shape(lib, dev, M, N, C, k, s, reps=5):
     T = M * s  # one batch item; zero padding, enough frames for M outputs
-    x = torch.randn(1, T + k, C, device=dev)
-    w = torch.randn(N, k, C, device=dev) * 0.05
-    b = torch.randn(N, device=dev)
+    g = torch.Generator(device=dev).manual_seed(M + N + C)  # the same operands for every configuration of a sweep
+    x = torch.randn(1, T + k, C, device=dev, generator=g)
+    w = torch.randn(N, k, C, device=dev, generator=g) * 0.05
+    b = torch.randn(N, device=dev, generator=g)
     for _ in range(2):
         y = conv1d_cl(lib, x, w, b, stride=s, T_out=M)
     e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)

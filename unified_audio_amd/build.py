@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libquarkaudio_hip.so")
-SOURCES = ["api.cpp", "conv_gemm.hip", "ew.hip", "attention.hip", "lstm.hip", "rvq.hip", "lm_kernels.hip", "lm_decode.hip", "lm_xcd.hip", "ssl_kernels.hip", "bicodec_kernels.hip", "seanet_front.hip", "hcodec.cpp", "lm.cpp", "ssl.cpp", "bicodec.cpp"]
+SOURCES = ["api.cpp", "conv_gemm.hip", "ew.hip", "attention.hip", "lstm.hip", "rvq.hip", "lm_kernels.hip", "lm_decode.hip", "ssl_kernels.hip", "bicodec_kernels.hip", "seanet_front.hip", "hcodec.cpp", "lm.cpp", "ssl.cpp", "bicodec.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I", INCLUDE, "-I", CSRC]
 
 

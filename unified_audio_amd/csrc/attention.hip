@@ -148,27 +148,6 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         const float* kp = sK + ql * LD + 4 * hh;
-#if QA_ATT_PIPE  // experiment (tools/variants.py -DQA_ATT_PIPE=1): the K fragment of group g + 1 is read from LDS before the MFMAs of group g
-        float4 ak[2];
-        ak[0] = *reinterpret_cast<const float4*>(kp);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) ak[(g + 1) & 1] = *reinterpret_cast<const float4*>(kp + 8 * (g + 1));
-            const float4 a = ak[g & 1];
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * g + 0], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * g + 1], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * g + 2], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * g + 3], s, 0, 0, 0);
-        }
-        // pin the order (hipcc otherwise sinks every read to just before its MFMAs again): two reads, then 4 MFMAs + the read after next
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-        for (int g = 0; g < NG - 2; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-#else
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const float4 a = *reinterpret_cast<const float4*>(kp + 8 * g);
@@ -177,7 +156,6 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * g + 2], s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * g + 3], s, 0, 0, 0);
         }
-#endif
         // online softmax in base 2 (per lane = per query; the two halves of the wave hold interleaved key groups).  Masks are
         // evaluated only on tiles that can contain a hidden key for some query of this wave (wave-uniform test).
         const int q_first = q_blk0 + wave * 32, q_last = q_first + 31;
@@ -224,36 +202,6 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
                 for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
         }
         // O^T += V^T P^T ; k-slot (step st, half h) <-> key (st&3) + 8*(st>>2) + 4*h
-#if QA_ATT_PIPE  // the V fragments of the next 4 steps are read from LDS before the MFMAs of the current 4 (same order of the products)
-        float vf[2][4][DT];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int t = 0; t < DT; ++t) vf[0][u][t] = sV[(u + 4 * hh) * LD + ql + 32 * t];
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            if (gq + 1 < 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int t = 0; t < DT; ++t) vf[(gq + 1) & 1][u][t] = sV[(u + 8 * (gq + 1) + 4 * hh) * LD + ql + 32 * t];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[gq & 1][u][t], s[4 * gq + u], o[t], 0, 0, 0);
-        }
-        {  // reads of two groups first, then the MFMAs of a group + the reads of the group after next
-            constexpr int RPG = DT >= 2 ? 4 * (DT / 2) : 4;  // LDS read instructions per group (ds_read2_b32 pairs the t's)
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * RPG, 0);
-#pragma unroll
-            for (int gq = 0; gq < 2; ++gq) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * DT, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, RPG, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 8 * DT, 0);
-        }
-#else
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
             const int key = (st & 3) + 8 * (st >> 2) + 4 * hh;
@@ -261,7 +209,6 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 #pragma unroll
             for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * t], s[st], o[t], 0, 0, 0);
         }
-#endif
         if (dbg & 2) __syncthreads();
     }
 

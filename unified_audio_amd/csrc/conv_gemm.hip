@@ -487,14 +487,31 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
     else if (p.N <= 32) cfg = PROF_CFG_128x32;
     else if (p.N <= 64) cfg = PROF_CFG_128x64;
     else {
-        // Tiles of one launch are dealt round-robin over 256 CUs (two co-resident workgroups share a CU's matrix pipes), so
-        // the makespan is (tiles on the busiest CU) x (work per tile) / (sustained efficiency of the configuration:
-        // measured ~92 TFLOP/s for 128x128 vs ~75 for 128x64 on long-K shapes).
+        // Tiles of one launch are dealt round-robin over 256 CUs (the co-resident workgroups of a CU share its matrix pipes), so the
+        // makespan is (tiles on the busiest CU) x (work per tile) / (sustained efficiency of the tile).  Round 4 adds the 64-row
+        // tiles: the aggregator stacks of H-Codec 1.5 (M = 9056 = 70.75 x 128) and the 4000-row SSL / BiCodec layers lose up to a
+        // third of the machine to tile quantisation with 128-row tiles (852 tiles of 128 x 128 = 3.33 per CU: a fourth round for a
+        // third of the CUs).  Efficiencies from the square 8192 x 4096 x 4096 problem, where every tile divides the grid evenly
+        // (profiles/r04_gemm_tile_sweep.txt: 133.1 / 121.5 / 121.6 / 115.9 TFLOP/s); ties go to the larger tile (less L2 traffic).
+        // Every configuration accumulates an output element over k in the same order, so this choice - which depends on M, i.e.
+        // on the batch size - never changes a bit (tests/test_kernels_gpu.py::test_conv_gemm_tile_configurations_are_bit_identical).
         const long long ngc = p.groups > 1 ? p.groups : 1;
-        const long long t128 = ngc * ceil_div(p.M, 128) * ceil_div(p.N, 128), t64 = ngc * ceil_div(p.M, 128) * ceil_div(p.N, 64);
-        const double c128 = (double)ceil_div(t128, 256) * 128 * 128 / 1.0;
-        const double c64 = (double)ceil_div(t64, 256) * 128 * 64 / 0.82;
-        cfg = c64 < c128 ? PROF_CFG_128x64 : PROF_CFG_128x128;
+        struct Cand { int cfg, bm, bn; double eff; };
+        static const Cand cands[] = {{PROF_CFG_128x128, 128, 128, 1.0}, {PROF_CFG_64x128, 64, 128, 0.914}, {PROF_CFG_128x64, 128, 64, 0.913},
+                                     {PROF_CFG_64x64, 64, 64, 0.871}};
+        double best = 0.0;
+        cfg = PROF_CFG_128x128;
+        for (const Cand& c : cands) {
+            if (ngc > 1 && c.bm != 128) continue;  // grouped launches were tuned on the 128-row tiles only
+            const long long tiles = ngc * ceil_div(p.M, c.bm) * ceil_div(p.N, c.bn);
+            // a launch that gives a CU at most ONE workgroup has nobody to cover that workgroup's barriers, prologue and epilogue: the
+            // 256-tile 4032 x 512 x 512 launch runs 8 % faster as 504 tiles of 64 x 64 although those need two rounds (same sweep)
+            const double cost = (double)ceil_div(tiles, 256) * c.bm * c.bn / c.eff * (tiles <= 256 ? 1.25 : 1.0);
+            if (best == 0.0 || cost < best * 0.995) {
+                best = cost;
+                cfg = c.cfg;
+            }
+        }
     }
     switch (cfg) {
         case PROF_CFG_128x32: return launch_cfg<128, 32, 4, 1>(q, stream);

@@ -28,7 +28,7 @@ namespace qa {
     X(LSTM_PERSISTENT, "QA_LSTM_PERSISTENT", -1, "persistent recurrence kernel: -1 auto (d >= 1536), 0 off, 1 on for every supported width") \
     X(LSTM_PERSISTENT_U, "QA_LSTM_PERSISTENT_U", 0, "persistent recurrence: hidden units per workgroup (0: the fewest that fit the CU count; 8 halves the workgroups at d = 1024)") \
     X(LSTM_XCD, "QA_LSTM_XCD", 1, "XCD-local LSTM recurrence for d = 512 / 768 (one launch, W_hh in the registers of every XCD's 32 CUs, sequences dealt to the XCDs, 32-member step barrier per XCD): 0 off (the per-step kernels; use it when several handles drive one device concurrently), 1 agent-scope hand-off forms, 2 XCD-local forms (h stores that stay in the XCD's L2; H-Codec 1.0: 42.7 against 43.3 ms)") \
-    X(LSTM_TEAM, "QA_LSTM_TEAM", 0, "1: the team recurrence for d = 1024 (4 teams of 64 workgroups, W_hh resident in registers, 8 sequences per team, agent-scope hand-offs): written at the end of round 3, NOT YET MEASURED - off until its parity test (QA_TEST_EXPERIMENTAL) and an A/B have run") \
+    X(LSTM_TEAM, "QA_LSTM_TEAM", 1, "team recurrence for d = 1024 (one launch: 4 teams of 64 workgroups, W_hh resident in registers, 8 sequences per team, agent-scope hand-offs; H-Codec 1.5 decoder: 134.1 -> 128.3 ms per step, profiles/r04_lstm_team_ab.txt): 0 = the per-step kernels (use it when several handles drive one device concurrently)") \
     X(LSTM_CUS, "QA_LSTM_CUS", 0, "H-Codec 1.0 / 1.5 encode: CUs reserved (hipExtStreamCreateWithCUMask) for the encoder's LSTM step launches while the semantic encoder runs on the other CUs (0: off, everything on one stream)") \
     X(LSTM_SPIN_LIMIT, "QA_LSTM_SPIN_LIMIT", 1 << 21, "persistent recurrence: polls of a barrier word before the barrier is declared broken") \
     X(LSTM_FAULT, "QA_LSTM_FAULT", 0, "1 (tests): the persistent kernel's barrier waits for a workgroup that does not exist, like a starved launch") \
@@ -41,7 +41,6 @@ namespace qa {
     X(LM_NT_DOWN, "QA_LM_NT_DOWN", 0, "column-tile width of the down GEMV")                                                      \
     X(LM_MLP_FUSED, "QA_LM_MLP_FUSED", 1, "decode step: gate/up + SwiGLU + down of 16 activation columns per workgroup in one launch emitting K-slice partials, summed by a reduce launch (0: separate gate/up and down launches; 2: 8 columns per workgroup)") \
     X(LM_ATT_SPLIT, "QA_LM_ATT_SPLIT", 0, "decode step: keys per workgroup of the single-query attention, at most 4 splits (0: 256)")  \
-    X(LM_XCD, "QA_LM_XCD", 0, "1 / 2 (at qa_lm_create AND at the call; 2 = with the next stage's weights prefetched across the team barriers): greedy generate of <= 32 sequences as one persistent launch per phase, a decode chain per XCD with team barriers instead of kernel boundaries (lm_xcd.hip; needs the extra tile-major weight copies made at create time): written at the end of round 3, NOT YET RUN - parity test behind QA_TEST_EXPERIMENTAL")  \
     X(LM_CHAINS, "QA_LM_CHAINS", 0, "generate: number of concurrent chains of <= 32 sequences on internal streams (0: ceil(B / 32))")
 
 enum Knob {

@@ -14,7 +14,6 @@
 
 #include "host_util.h"
 #include "lm_decode.h"
-#include "lm_xcd.h"
 
 namespace qa {
 int launch_assemble_prompt(float* x, const float* task_vec, const float* enroll_sos, const float* enroll_emb,
@@ -47,7 +46,6 @@ struct LMLayer {
     const float* qkv_dec = nullptr;
     const float* gu_dec = nullptr;
     const float* down_dec = nullptr;  // fused MLP: W_down slice-major [I / 16][d][16] (slice j = columns 16 j .. 16 j + 15 of every row)
-    LmXcdLayer xcd{};                 // QA_LM_XCD: tile-major per-slot layouts of the per-XCD persistent decode kernel (lm_xcd.hip)
 };
 constexpr int LM_MAX_POS = 4096;  // max_position_embeddings (conf/config.yaml:146)
 constexpr int LM_MAX_CHAINS = 16;
@@ -80,10 +78,6 @@ struct qa_lm {
     std::vector<hipEvent_t> chain_join;
     hipEvent_t ev_fork = nullptr;
     unsigned long long calls = 0;
-    bool xcd = false;                        // QA_LM_XCD at create time and a spec lm_xcd.hip is laid out for
-    bool xcd_used = false;                   // this call launched that kernel: its error word is collected before the call returns
-    const float* xcd_head[2] = {nullptr, nullptr};  // head slices of the two phases in that kernel's layout
-    unsigned *xcd_sync = nullptr, *xcd_err_host = nullptr, *xcd_err_dev = nullptr;
     WeightStore store;
     const float *task_emb = nullptr, *enroll_sos = nullptr, *mix_sos = nullptr, *codec_emb = nullptr, *ones = nullptr,
                 *rope = nullptr;  // `ones`: unit RMSNorm weight (the learned ones are folded into the projections)
@@ -119,40 +113,6 @@ int lm_linear(Ctx& c, const float* x, int64_t rows, const ConvW& w, float* y, co
     return launch_conv_gemm(p, c.stream);
 }
 
-// ---- QA_LM_XCD weight layouts (lm_xcd.hip): what a lane of the kernel loads with ONE coalesced float4 is contiguous in memory.
-// 16-row block (lmx_gemv16): [wave 8][j K/128][lane 64][4]; lane = (block b, i): row 4 (b & 3) + i, K slice 4 wave + (b >> 2)
-template <typename RowOf>
-void xcd_pack16(const float* W, int K, RowOf row_of, float* out) {
-    const int KW = K / 32, NJ = KW / 4;
-    for (int w = 0; w < 8; ++w)
-        for (int j = 0; j < NJ; ++j)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int b = lane >> 2, i = lane & 3, rb = b & 3, kp = b >> 2;
-                const size_t row = (size_t)row_of(4 * rb + i);
-                std::memcpy(out + (((size_t)w * NJ + j) * 64 + lane) * 4, W + row * K + (size_t)(4 * w + kp) * KW + 4 * j, sizeof(float) * 4);
-            }
-}
-// 128-row block (lmx_gemv128, K = 512): [group 2][K slice 4][j 32][lane 64][4]; lane = row of the group
-template <typename RowOf>
-void xcd_pack128(const float* W0, const float* W1, int K, RowOf row_of, float* out) {
-    for (int g = 0; g < 2; ++g)
-        for (int ks = 0; ks < 4; ++ks)
-            for (int j = 0; j < 32; ++j)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const size_t row = (size_t)row_of(g, lane);
-                    std::memcpy(out + ((((size_t)g * 4 + ks) * 32 + j) * 64 + lane) * 4, (g ? W1 : W0) + row * K + (size_t)ks * 128 + 4 * j,
-                                sizeof(float) * 4);
-                }
-}
-
-// source row of local row lr (0..15) of slot's QKV block: part 0 / 1 = q / k (8 rotary pairs: rows 2 p, 2 p + 1 = dims jj, jj + hd / 2 of
-// head h, pair P = 8 slot + p = 32 h + jj), part 2 = v (rows 16 slot + lr)
-int xcd_row_qkv(int slot, int part, int lr, int hd) {
-    if (part == 2) return slot * 16 + lr;
-    const int P = slot * 8 + (lr >> 1), h = P / (hd / 2), jj = P % (hd / 2);
-    return h * hd + jj + (lr & 1) * (hd / 2);
-}
-
 int build_lm(qa_lm* lm, const HostTable& tab) {
     const qa_lm_spec& sp = lm->spec;
     const int d = sp.hidden, V = vocab_of(sp), I = sp.intermediate;
@@ -174,8 +134,6 @@ int build_lm(qa_lm* lm, const HostTable& tab) {
     lm->att_split = knob(K_LM_ATT_SPLIT) >= 32 ? (int)knob(K_LM_ATT_SPLIT) : 256;
     lm->fused_ok = lm_gemv_supported(d, I) && d % lm->nt_qkv == 0 && hd % lm->nt_qkv == 0 && d % lm->nt_o == 0 &&
                    (2 * I) % lm->nt_gu == 0 && hd % 8 == 0 && knob(K_LM_UNFUSED) == 0;
-    lm->xcd = knob(K_LM_XCD) != 0 && lm->fused_ok && sp.n_layers <= LM_XCD_MAX_LAYERS &&
-              lm_xcd_supported(d, sp.n_heads, I, sp.global_size, sp.semantic_size);
     WeightStore& st = lm->store;
     bool ok = true;
     std::vector<std::pair<const float**, size_t>> pend;
@@ -212,20 +170,6 @@ int build_lm(qa_lm* lm, const HostTable& tab) {
         std::vector<float> hw;
         if (folded("output_head.weight", V, tab.get("norm.weight", d), &hw)) {
             pend.push_back({&lm->head.w, st.add(hw)});
-            if (lm->xcd) {  // the two phases' vocabulary slices, rows [lo, lo + width) dealt to the 32 slots in blocks of width / 32
-                const int los[2] = {3, 3 + sp.global_size}, widths[2] = {sp.global_size, sp.semantic_size};
-                for (int ph = 0; ph < 2; ++ph) {
-                    const int rows_wg = widths[ph] / 32;
-                    std::vector<float> hx((size_t)widths[ph] * d);
-                    for (int slot = 0; slot < 32; ++slot)
-                        for (int ch = 0; ch < rows_wg / 128; ++ch) {
-                            const int base = los[ph] + slot * rows_wg + ch * 128;
-                            xcd_pack128(hw.data(), hw.data(), d, [&](int g, int lane) { return base + 64 * g + lane; },
-                                        &hx[((size_t)slot * rows_wg + (size_t)ch * 128) * d]);
-                        }
-                    pend.push_back({&lm->xcd_head[ph], st.add(hx)});
-                }
-            }
         } else {
             ok = false;
         }
@@ -260,27 +204,6 @@ int build_lm(qa_lm* lm, const HostTable& tab) {
                             }
             pend.push_back({&L.qkv_dec, st.add(wd)});
         }
-        if (lm->xcd) {  // slot s: 8 q rotary pairs (rows 2 p, 2 p + 1 = dims jj, jj + 32 of head h; pair P = 8 s + p), 8 k pairs, v rows 16 s ..
-            std::vector<float> wx((size_t)3 * d * d);
-            for (int slot = 0; slot < 32; ++slot)
-                for (int part = 0; part < 3; ++part)
-                    xcd_pack16(&wq[(size_t)part * d * d], d, [&](int lr) { return xcd_row_qkv(slot, part, lr, hd); },
-                               &wx[((size_t)slot * 3 + part) * 16 * d]);
-            pend.push_back({&L.xcd.qkv, st.add(wx)});
-            const float* wo = tab.get(p + ".self_attn.o_proj.weight", (int64_t)d * d);
-            const float* wdn = tab.get(p + ".mlp.down_proj.weight", (int64_t)I * d);
-            if (wo && wdn) {
-                std::vector<float> ox((size_t)d * d), dx((size_t)d * I);
-                for (int slot = 0; slot < 32; ++slot) {
-                    xcd_pack16(wo, d, [&](int lr) { return slot * 16 + lr; }, &ox[(size_t)slot * 16 * d]);
-                    xcd_pack16(wdn, I, [&](int lr) { return slot * 16 + lr; }, &dx[(size_t)slot * 16 * I]);
-                }
-                pend.push_back({&L.xcd.o, st.add(ox)});
-                pend.push_back({&L.xcd.down, st.add(dx)});
-            } else {
-                ok = false;
-            }
-        }
         L.o.N = d; L.o.C_in = d;
         vec(&L.o.w, p + ".self_attn.o_proj.weight", (int64_t)d * d);
         L.gate.N = I; L.gate.C_in = d;
@@ -306,12 +229,6 @@ int build_lm(qa_lm* lm, const HostTable& tab) {
                         std::memcpy(&gd[(size_t)(t * 2 * hp + hp) * d], &u[(size_t)(t * hp) * d], sizeof(float) * hp * d);
                     }
                     pend.push_back({&L.gu_dec, st.add(gd)});
-                }
-                if (lm->xcd) {  // slot s: gate rows 64 s .. + 63 (group 0) and up rows 64 s .. + 63 (group 1)
-                    std::vector<float> gx((size_t)2 * I * d);
-                    for (int slot = 0; slot < 32; ++slot)
-                        xcd_pack128(g.data(), u.data(), d, [&](int, int lane) { return slot * 64 + lane; }, &gx[(size_t)slot * 128 * d]);
-                    pend.push_back({&L.xcd.gu, st.add(gx)});
                 }
             } else {
                 ok = false;
@@ -359,9 +276,6 @@ struct LMBuffers {
     int *pidx, *state;
     long long *ids_g, *ids_s;
     int cap, S_att;
-    // QA_LM_XCD: hand-off buffers of the per-XCD persistent decode kernel
-    float *xa = nullptr, *xb = nullptr, *xact = nullptr, *xatt = nullptr, *xpmax = nullptr;
-    int* xpidx = nullptr;
 };
 
 struct SampleCfg {
@@ -530,14 +444,6 @@ int chain_alloc(qa_lm* lm, Ctx& c, Chain& ch, int L, int cap, int G, int S, int 
     b.state = c.arena.alloc<int>(ST_WORDS);
     b.ids_g = c.arena.alloc<long long>((size_t)B * std::max(G, 1));
     b.ids_s = c.arena.alloc<long long>((size_t)B * std::max(S, 1));
-    if (lm->xcd) {
-        b.xa = c.arena.alloc<float>((size_t)B * d);
-        b.xb = c.arena.alloc<float>((size_t)B * d);
-        b.xact = c.arena.alloc<float>((size_t)B * I);
-        b.xatt = c.arena.alloc<float>((size_t)B * H * 4 * (d / H + 4));
-        b.xpmax = c.arena.alloc<float>((size_t)B * 32);
-        b.xpidx = c.arena.alloc<int>((size_t)B * 32);
-    }
     ch.emix = c.arena.alloc<float>((size_t)B * Nm * d);
     ch.eenr = enroll ? c.arena.alloc<float>((size_t)B * Ne * d) : nullptr;
     return QA_OK;
@@ -613,35 +519,6 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
         const int ids_ld = keep;
         for (Chain& ch : chains)
             QA_TRY(launch_lm_phase_init(ch.b.tok, first_id, ch.B, ch.b.state, pos, which == 0, sc.seed, ch.b0, ch.s));
-        if (lm->xcd && knob(K_LM_XCD) != 0 && fused && !multi && !sc.do_sample && B <= 32) {
-            // ONE persistent launch for the whole phase: a decode chain per XCD (lm_xcd.hip)
-            Chain& ch = chains[0];
-            LmXcdArgs xa{};
-            for (int l = 0; l < sp.n_layers; ++l) xa.layer[l] = lm->layers[l].xcd;
-            xa.n_layers = sp.n_layers;
-            xa.head = lm->xcd_head[which];
-            xa.emb = lm->codec_emb;
-            xa.rope = lm->rope;
-            xa.kc = ch.b.kc; xa.vc = ch.b.vc;
-            xa.kv_bstride = (long long)cap * d;
-            xa.kv_lstride = (long long)ch.B * cap * d;
-            xa.xa = ch.b.xa; xa.xb = ch.b.xb; xa.qbuf = ch.b.q; xa.act = ch.b.xact; xa.att_part = ch.b.xatt;
-            xa.pmax = ch.b.xpmax; xa.pidx = ch.b.xpidx;
-            xa.tok = ch.b.tok;
-            xa.ids = which == 0 ? ch.b.ids_g : ch.b.ids_s;
-            xa.ids_ld = ids_ld; xa.keep = keep;
-            xa.B = ch.B; xa.pos0 = pos; xa.steps = steps; xa.lo = lo; xa.width = width;
-            xa.tok_init = first_id;
-            xa.rms_eps = sp.rms_eps;
-            xa.sy = lm->xcd_sync; xa.err_host = lm->xcd_err_dev;
-            xa.spin_limit = (unsigned)std::max<long long>(64, std::min<long long>(knob(K_LSTM_SPIN_LIMIT), 1LL << 30));
-            xa.fault = 0;
-            xa.prefetch = knob(K_LM_XCD) >= 2 ? 1 : 0;
-            QA_TRY(launch_lm_xcd_decode(xa, ch.s));
-            lm->xcd_used = true;
-            pos += steps;
-            return QA_OK;
-        }
         if (fused && graphs && steps > 0) {
             if ((int)lm->graphs.size() < 2 * nc) lm->graphs.resize(2 * nc);
             for (int i = 0; i < nc; ++i) {
@@ -761,22 +638,6 @@ int qa_lm_create(qa_lm** out, const qa_lm_spec* spec, const qa_tensor* tensors, 
         lm->store.release();
         return st;
     }
-    if (lm->xcd) {
-        const auto fail = [&](hipError_t e) {
-            set_error("qa_lm_create: %s", hipGetErrorString(e));
-            lm->store.release();
-            if (lm->xcd_sync) (void)hipFree(lm->xcd_sync);
-            if (lm->xcd_err_host) (void)hipHostFree(lm->xcd_err_host);
-            return QA_ERR_HIP;
-        };
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&lm->xcd_sync), lm_xcd_sync_bytes());
-        if (e != hipSuccess) return fail(e);
-        e = hipHostMalloc(reinterpret_cast<void**>(&lm->xcd_err_host), sizeof(unsigned), hipHostMallocMapped);
-        if (e != hipSuccess) return fail(e);
-        *lm->xcd_err_host = 0u;
-        e = hipHostGetDevicePointer(reinterpret_cast<void**>(&lm->xcd_err_dev), lm->xcd_err_host, 0);
-        if (e != hipSuccess) return fail(e);
-    }
     *out = lm.release();
     return QA_OK;
 }
@@ -792,8 +653,6 @@ void qa_lm_destroy(qa_lm* lm) {
     if (lm->ev_fork) (void)hipEventDestroy(lm->ev_fork);
     lm->store.release();
     if (lm->ws) (void)hipFree(lm->ws);
-    if (lm->xcd_sync) (void)hipFree(lm->xcd_sync);
-    if (lm->xcd_err_host) (void)hipHostFree(lm->xcd_err_host);
     delete lm;
 }
 
@@ -820,21 +679,8 @@ static int lm_generate_impl(qa_lm* lm, int32_t task, const float* enroll_feats, 
     QA_TRY(ensure_ws(lm, c.arena.peak()));
     c.dry = false;
     c.arena.begin(lm->ws, lm->ws_cap);
-    lm->xcd_used = false;
     int st = generate_graph(lm, c, task, enroll_feats, (int)n_enroll, mix_feats, (int)n_mix, (int)B, global_length, semantic_length,
                             (long long*)global_ids, (long long*)semantic_ids, sc);
-    if (st == QA_OK && lm->xcd_used) {  // the persistent kernel's bounded barrier spins report through a pinned word: collect it now
-        const hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
-        if (e != hipSuccess) {
-            set_error("qa_lm_generate: %s", hipGetErrorString(e));
-            st = QA_ERR_HIP;
-        } else if (*static_cast<volatile unsigned*>(lm->xcd_err_host) != 0u) {
-            *lm->xcd_err_host = 0u;
-            set_error("qa_lm_generate: a team barrier of the per-XCD decode kernel timed out (QA_LM_XCD needs every one of its 256 workgroups "
-                      "resident: is the device shared?); the token buffers are invalid - set QA_LM_XCD=0");
-            st = QA_ERR_HIP;
-        }
-    }
     if (st != QA_OK) {  // an error between the fork and the join of a multi-chain call: the chains' streams may still be running out of the
         c.stream = static_cast<hipStream_t>(stream);  // workspace the next call re-uses - quiesce them (error path only)
         for (hipStream_t cs : lm->chain_streams) (void)hipStreamSynchronize(cs);
@@ -856,37 +702,6 @@ int qa_lm_generate_sampled(qa_lm* lm, int32_t task, const float* enroll_feats, i
     const SampleCfg sc{1, top_k, top_p, temperature, (unsigned long long)seed};
     return lm_generate_impl(lm, task, enroll_feats, n_enroll, mix_feats, n_mix, B, global_length, semantic_length, sc, global_ids,
                             semantic_ids, stream);
-}
-
-// Test hook (host memory only, no device needed): the weight layouts of lm_xcd.hip exactly as build_lm lays them out, one workgroup
-// block at a time, so that a CPU emulation of the kernel's lane arithmetic can be checked against a plain Llama step
-// (tests/test_llm_xcd_layout_cpu.py).  kind 0: QKV part `aux` of `slot` (src0 = that section's [512][K] matrix); 1: plain 16-row block
-// (o_proj / down_proj); 2: gate (src0) / up (src1) 128-row block; 3: head block whose first row is `aux` (src0 = output_head).
-int qa_debug_lm_xcd_pack(int32_t kind, const float* src0, const float* src1, int32_t K, int32_t slot, int32_t aux, float* out) {
-    if (!src0 || !out || K <= 0 || K % 128 || slot < 0 || slot >= 32) {
-        set_error("qa_debug_lm_xcd_pack: bad argument");
-        return QA_ERR_INVALID;
-    }
-    switch (kind) {
-        case 0: xcd_pack16(src0, K, [&](int lr) { return xcd_row_qkv(slot, aux, lr, 64); }, out); break;
-        case 1: xcd_pack16(src0, K, [&](int lr) { return slot * 16 + lr; }, out); break;
-        case 2:
-            if (!src1 || K != 512) {
-                set_error("qa_debug_lm_xcd_pack: gate / up need two matrices with K = 512");
-                return QA_ERR_INVALID;
-            }
-            xcd_pack128(src0, src1, K, [&](int, int lane) { return slot * 64 + lane; }, out);
-            break;
-        case 3:
-            if (K != 512) {
-                set_error("qa_debug_lm_xcd_pack: the head block has K = 512");
-                return QA_ERR_INVALID;
-            }
-            xcd_pack128(src0, src0, K, [&](int g, int lane) { return aux + 64 * g + lane; }, out);
-            break;
-        default: set_error("qa_debug_lm_xcd_pack: kind %d", kind); return QA_ERR_INVALID;
-    }
-    return QA_OK;
 }
 
 int qa_sample_logits(const float* logits, int64_t B, int64_t width, int64_t ld, int32_t top_k, float top_p, float temperature,
