@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SR = 16000
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD at 2.4 GHz
 CFG_NAMES = ["conv_gemm_kernel<128,32,4,1>", "conv_gemm_kernel<128,64,2,2>", "conv_gemm_kernel<128,128,2,2>", "conv_gemm_kernel<64,128,1,4>",
              "conv_gemm_kernel<64,64,2,2>"]
@@ -650,13 +651,23 @@ def main():
     # the same kernels with the library's internal stream concurrency switched off (every launch alone on the device):
     # what a kernel achieves by itself, as opposed to while it shares the CUs with the other stream's kernels
     iso = (C.c_double * NPROF)()
+    n_hbm = lib.qa_profile_hbm_kinds()
+    hbm = (C.c_double * (3 * n_hbm))()
     _lib.check(lib.qa_set_serial(1))
-    _lib.check(lib.qa_profile_begin())
+    _lib.check(lib.qa_profile_begin_ex(3))  # + the byte-bound kernels, each with its algorithmic bytes (qa_profile_end_hbm)
     for _ in range(0 if args.lean else 2):
         step()
     torch.cuda.synchronize(dev)
+    _lib.check(lib.qa_profile_end_hbm(hbm, 3 * n_hbm))
     _lib.check(lib.qa_profile_end(iso, NPROF))
     _lib.check(lib.qa_set_serial(0))
+    hbm_rows = []
+    for k in range(n_hbm):
+        by, ms, n = hbm[3 * k], hbm[3 * k + 1], hbm[3 * k + 2]
+        if n:
+            hbm_rows.append({"kernel": lib.qa_profile_hbm_name(k).decode(), "launches_per_step": n / 2, "avg_us": 1e3 * ms / n,
+                             "algorithmic_bytes_per_launch": by / n, "achieved_GBps": by / (ms * 1e-3) / 1e9, "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "ms_per_step": ms / 2})
 
     # secondary: the same step with host (pageable) tensors in and out, as HCodecTokenizer's __main__ moves them
     # (audio_tokenizer.py:79,84: wav.to(device) ... wav_rec.cpu()); never `value`
@@ -852,6 +863,18 @@ def main():
                                  "CUs, so their durations overlap (shares can sum past 1). `isolated` = the same kernel with "
                                  "qa_set_serial(1), alone on the device (what rocprofv3 under QA_SERIAL=1 reports)"},
         }
+        if hbm_rows:
+            # the byte-bound side of the path (north_star: "rocprof HBM GB/s"): every elementwise / norm / gather kernel alone on the device
+            # (qa_set_serial), ALGORITHMIC bytes (each input and output element once) / HIP-event duration against the 8 TB/s HBM3E peak.
+            # The entry's headline is the kernel with the most time per step among them; `all` lists every kind.
+            top = max(hbm_rows, key=lambda r_: r_["ms_per_step"])
+            line["roofline_hbm"] = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                    "frac": top["frac"], "traffic": None, "avg_launch_us": top["avg_us"], "launches_per_step": top["launches_per_step"],
+                                    "share_of_step_time": top["ms_per_step"] / (1e3 * elapsed / args.steps),
+                                    "all": sorted(hbm_rows, key=lambda r_: -r_["ms_per_step"]),
+                                    "byte_bound_ms_per_step": sum(r_["ms_per_step"] for r_ in hbm_rows),
+                                    "note": "isolated pass (qa_set_serial(1)); bytes are algorithmic, so a two-pass kernel (GroupNorm) or one that is VALU-bound "
+                                            "(the fused SEANet front: 3 small convolutions per sample on the vector ALUs) shows as a low fraction"}
         di = CFG_NAMES.index(dom["kernel"])
         if iso[4 * di + 2]:
             tf = iso[4 * di] / (iso[4 * di + 1] * 1e-3) / 1e12

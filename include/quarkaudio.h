@@ -219,6 +219,15 @@ int64_t qa_resolve_frame(int64_t r, int64_t L, int32_t max_pad, int32_t pad_mode
  * configurations cfg = 0 (128x32), 1 (128x64), 2 (128x128), 3 (64x128), 4 (64x64); n_out >= 20.  Not thread-safe; process-wide. */
 int qa_profile_begin(void);
 int qa_profile_end(double* out, int32_t n_out);
+/* qa_profile_begin_ex(mask): bit 0 = the implicit-GEMM launches (= qa_profile_begin), bit 1 = the byte-bound kernels (norms, depthwise
+ * conv, RoPE, ISTFT, RVQ look-up / pick, the fused SEANet front ...), each recorded with its ALGORITHMIC bytes (every input and output
+ * element once).  qa_profile_end_hbm (call it before qa_profile_end) fills out[kind*3 + {0,1,2}] = {bytes, elapsed ms, launches} for
+ * kind in [0, qa_profile_hbm_kinds()); n_out >= 3 * kinds; qa_profile_hbm_name(kind) names the kernel.  bytes / ms = achieved GB/s
+ * against the HBM roofline (bench.py's `roofline_hbm`). */
+int qa_profile_begin_ex(int32_t mask);
+int qa_profile_hbm_kinds(void);
+const char* qa_profile_hbm_name(int32_t kind);
+int qa_profile_end_hbm(double* out, int32_t n_out);
 /* qa_set_serial(1) (or QA_SERIAL=1 in the environment) collapses the library's internal streams onto the caller's, so that a
  * profiler sees every kernel alone on the device; results are bit-identical either way.  Process-wide. */
 int qa_set_serial(int32_t on);

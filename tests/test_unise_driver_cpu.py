@@ -77,6 +77,45 @@ def test_driver_batches_segments_of_several_utterances():
         drv.enhance("se", [a])
 
 
+def test_micro_batches_of_max_segments_keep_results_and_enrollment_tiling():
+    """UniSE(max_segments=m): the segments of a call go through the three stages m at a time (default 64); with batch-invariant stages the
+    tokens and the waveforms do not depend on m, a micro-batch that starts in the middle of an utterance still gets THAT utterance's
+    enrollment, and detokenize is chunked the same way."""
+    log = []
+
+    class FakeSSL:
+        def __call__(self, wavs):
+            return wavs[:, :6:2].unsqueeze(-1).repeat(1, 1, 4)
+
+    class FakeLM:
+        def generate(self, task_name, enroll_mel, enroll_feats, mix_mel, mix_feats, do_sample):
+            B = mix_feats.shape[0]
+            log.append(B)
+            tag = mix_feats[:, 0, 0] * 1000 + (0 if enroll_feats is None else enroll_feats[:, 0, 0])  # depends on the segment AND its enrollment
+            return tag.view(B, 1).repeat(1, 32).round().long(), tag.view(B, 1).repeat(1, mix_mel.size(1)).round().long()
+
+    def detok(g, s):
+        log.append(("detok", g.shape[0]))
+        return (g[:, 0, :1].float() + s[:, :1].float()).view(-1, 1, 1).repeat(1, 1, 80000)
+
+    utts = [torch.randn(1, n) for n in (90000, 250000, 80000, 170000)]  # 2 + 4 + 1 + 3 = 10 segments
+    enr = [torch.full((1, 48000), float(i + 1)) for i in range(4)]
+    ref_drv = U.UniSE(FakeLM(), FakeSSL(), detokenize=detok, max_segments=64)
+    ref_tok = ref_drv.enhance_tokens("tse", utts, enr)
+    ref_wav = ref_drv.enhance("tse", utts, enr)
+    assert 10 in log
+    for m in (1, 3, 4, 7):
+        log.clear()
+        drv = U.UniSE(FakeLM(), FakeSSL(), detokenize=detok, max_segments=m)
+        tok = drv.enhance_tokens("tse", utts, enr)
+        assert [b for b in log if isinstance(b, int)] == [min(m, 10 - a) for a in range(0, 10, m)]
+        for (g0, s0), (g1, s1) in zip(ref_tok, tok):
+            assert torch.equal(g0, g1) and torch.equal(s0, s1)
+        wav = drv.enhance("tse", utts, enr)
+        assert max(b[1] for b in log if isinstance(b, tuple)) <= m
+        assert all(torch.equal(a, b) for a, b in zip(ref_wav, wav))
+
+
 def test_ss_mode_runs_the_three_passes_of_the_reference():
     """model.py:223-290: SE on the first 5 s -> detokenize -> peak-normalised enrollment (x 0.99) -> TSE and rTSE over all segments
     with that enrollment tiled; two waveforms per mixture, each cut to the mixture's length."""

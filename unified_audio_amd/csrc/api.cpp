@@ -44,15 +44,21 @@ void knob_set(Knob k, long long v) {
     g_knob_val[k].store(v, std::memory_order_relaxed);
 }
 int raise_dynamic_lds(const void* kernel, int bytes) {
+    struct Raised { const void* kernel; int dev, bytes; };
     static std::mutex mu;
-    static std::vector<std::pair<const void*, int>> done;  // (kernel, device) pairs already raised
+    static std::vector<Raised> done;  // largest size raised so far per (kernel, device): a later, larger request raises again
     int dev = 0;
     QA_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(mu);
-    for (const auto& kd : done)
-        if (kd.first == kernel && kd.second == dev) return QA_OK;
+    for (Raised& r : done)
+        if (r.kernel == kernel && r.dev == dev) {
+            if (bytes <= r.bytes) return QA_OK;
+            QA_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+            r.bytes = bytes;
+            return QA_OK;
+        }
     QA_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    done.emplace_back(kernel, dev);
+    done.push_back(Raised{kernel, dev, bytes});
     return QA_OK;
 }
 static thread_local char g_err[1024] = "";
@@ -72,7 +78,11 @@ struct ProfRec {
     double flops, bytes;
     int M, N, K, ksize, flags;  // shape of the launch (QA_GEMM_SHAPES report)
 };
-static bool g_prof_on = false;
+static bool g_prof_on = false;   // conv_gemm launches
+static bool g_prof_hbm = false;  // byte-bound kernels (HbmKind): recorded as cfg = PROF_NCFG + kind
+static const char* const g_hbm_names[HK_NKINDS] = {"rownorm_kernel (RMSNorm / LayerNorm)", "dwconv_kernel (+ LayerNorm)", "gn_partial + gn_apply (GroupNorm)",
+                                                   "rope_kernel", "istft_spec_kernel", "istft_ola_kernel", "stft_post_kernel", "rvq_lookup_kernel",
+                                                   "rvq_pick_kernel", "seanet_block_kernel<32> (fused conv0 + block)", "conv_in_kernel"};
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_pool;
 static hipEvent_t prof_event() {
@@ -86,6 +96,13 @@ static hipEvent_t prof_event() {
     return e;
 }
 bool profile_enabled() { return g_prof_on; }
+bool profile_hbm_enabled() { return g_prof_hbm; }
+HbmProf::HbmProf(int kind, double bytes, hipStream_t stream) : s(stream), on(g_prof_hbm) {
+    if (on) profile_record_begin(PROF_NCFG + kind, 0.0, bytes, s, nullptr);
+}
+HbmProf::~HbmProf() {
+    if (on) profile_record_end(s);
+}
 bool serial_mode() { return knob(K_SERIAL) != 0; }
 void profile_record_begin(int cfg, double flops, double bytes, hipStream_t s, const ConvParams* p) {
     ProfRec r{prof_event(), prof_event(), cfg, flops, bytes, 0, 0, 0, 0, 0};
@@ -141,25 +158,53 @@ int qa_get_knob(const char* name, int64_t* value) {
     return QA_OK;
 }
 
-int qa_profile_begin(void) {
+int qa_profile_begin_ex(int32_t mask) {
     for (auto& r : g_prof) {
         g_pool.push_back(r.a);
         g_pool.push_back(r.b);
     }
     g_prof.clear();
-    g_prof_on = true;
+    g_prof_on = (mask & 1) != 0;
+    g_prof_hbm = (mask & 2) != 0;
+    return QA_OK;
+}
+int qa_profile_begin(void) { return qa_profile_begin_ex(1); }
+
+int qa_profile_hbm_kinds(void) { return HK_NKINDS; }
+const char* qa_profile_hbm_name(int32_t kind) { return (kind >= 0 && kind < HK_NKINDS) ? g_hbm_names[kind] : ""; }
+
+// out[kind*3 + {0,1,2}] = {algorithmic bytes, elapsed ms, launches} of the byte-bound kernels recorded since qa_profile_begin_ex(2 | ..);
+// call BEFORE qa_profile_end (which closes the recording); does not clear.
+int qa_profile_end_hbm(double* out, int32_t n_out) {
+    if (!out || n_out < HK_NKINDS * 3) {
+        set_error("qa_profile_end_hbm: need room for %d doubles", HK_NKINDS * 3);
+        return QA_ERR_INVALID;
+    }
+    for (int i = 0; i < HK_NKINDS * 3; ++i) out[i] = 0.0;
+    for (auto& r : g_prof) {
+        if (r.cfg < PROF_NCFG) continue;
+        QA_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        QA_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        const int k = r.cfg - PROF_NCFG;
+        out[k * 3 + 0] += r.bytes;
+        out[k * 3 + 1] += ms;
+        out[k * 3 + 2] += 1.0;
+    }
     return QA_OK;
 }
 
 // out[cfg*4 + {0,1,2,3}] = {algorithmic FLOPs, elapsed ms, launches, algorithmic bytes} for cfg in {128x32, 128x64, 128x128, 64x128, 64x64}
 int qa_profile_end(double* out, int32_t n_out) {
     g_prof_on = false;
+    g_prof_hbm = false;
     if (!out || n_out < PROF_NCFG * 4) {
         set_error("qa_profile_end: need room for %d doubles", PROF_NCFG * 4);
         return QA_ERR_INVALID;
     }
     for (int i = 0; i < PROF_NCFG * 4; ++i) out[i] = 0.0;
     for (auto& r : g_prof) {
+        if (r.cfg >= PROF_NCFG) continue;  // byte-bound kernels: qa_profile_end_hbm
         QA_HIP(hipEventSynchronize(r.b));
         float ms = 0.f;
         QA_HIP(hipEventElapsedTime(&ms, r.a, r.b));
@@ -173,6 +218,7 @@ int qa_profile_end(double* out, int32_t n_out) {
         struct Agg { int M, N, K, ksize, flags, cfg; double ms, flops; long n; };
         std::vector<Agg> agg;
         for (auto& r : g_prof) {
+            if (r.cfg >= PROF_NCFG) continue;
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, r.a, r.b);
             Agg* hit = nullptr;

@@ -144,6 +144,17 @@ struct ConvParams {
 // Live measurement hook (bench.py): when enabled every conv_gemm launch is bracketed by HIP events on its own stream.
 enum { PROF_CFG_128x32 = 0, PROF_CFG_128x64 = 1, PROF_CFG_128x128 = 2, PROF_CFG_64x128 = 3, PROF_CFG_64x64 = 4, PROF_NCFG = 5 };
 bool profile_enabled();
+// Byte-bound kernels (north_star: "rocprof HBM GB/s"): with qa_profile_begin_ex(2 | ...) their launches are bracketed by HIP events too,
+// each with its ALGORITHMIC bytes (every input and output element once), reduced per kind by qa_profile_end_hbm.
+enum HbmKind { HK_ROWNORM = 0, HK_DWCONV_LN, HK_GROUPNORM, HK_ROPE, HK_ISTFT_SPEC, HK_ISTFT_OLA, HK_STFT_POST, HK_RVQ_LOOKUP, HK_RVQ_PICK,
+               HK_SEANET_FRONT, HK_CONV_IN, HK_NKINDS };
+bool profile_hbm_enabled();
+struct HbmProf {  // scope guard around ONE launch (or the launches of one logical pass) on stream s
+    hipStream_t s;
+    bool on;
+    HbmProf(int kind, double bytes, hipStream_t stream);
+    ~HbmProf();
+};
 bool serial_mode();  // qa_set_serial / QA_SERIAL=1: no internal stream concurrency (every kernel alone on the device)
 void profile_record_begin(int cfg, double flops, double bytes, hipStream_t s, const ConvParams* p = nullptr);
 void profile_record_end(hipStream_t s);

@@ -42,6 +42,7 @@ int launch_conv_in(const float* x, const float* w_kc, const float* bias, float* 
     const int max_pad = left > right ? left : right;
     const int Lp = (T <= max_pad) ? max_pad + 1 : T;
     const long long total = (long long)B * T * (Cout / 4);
+    HbmProf prof_(HK_CONV_IN, 4.0 * ((double)B * T + (double)B * T * Cout), s);
     hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, x, w_kc, bias, y, B, T,
                        Cout, ksize, left, Lp);
     QA_LAUNCH_CHECK();
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
 
 int launch_rmsnorm(const float* x, const float* w, float* y, long long rows, int C, float eps, hipStream_t s) {
     QA_REQUIRE(C % 4 == 0 && C <= 256 * MAX_V4, "rmsnorm: C=%d unsupported", C);
+    HbmProf prof_(HK_ROWNORM, 8.0 * (double)rows * C, s);
     hipLaunchKernelGGL(rownorm_kernel<0>, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, s, x, w, nullptr, y, rows,
                        C, eps);
     QA_LAUNCH_CHECK();
@@ -118,6 +120,7 @@ int launch_rmsnorm(const float* x, const float* w, float* y, long long rows, int
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, long long rows, int C, float eps,
                      hipStream_t s) {
     QA_REQUIRE(C % 4 == 0 && C <= 256 * MAX_V4, "layernorm: C=%d unsupported", C);
+    HbmProf prof_(HK_ROWNORM, 8.0 * (double)rows * C, s);
     hipLaunchKernelGGL(rownorm_kernel<1>, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, s, x, w, b, y, rows, C,
                        eps);
     QA_LAUNCH_CHECK();
@@ -195,6 +198,7 @@ int launch_dwconv(const float* x, const float* w_kc, const float* bias, const fl
                ksize, pad_left);
     const unsigned grid = (unsigned)ceil_div((long long)B * T, 4);
     const int pad = pad_left >= 0 ? pad_left : ksize / 2;
+    HbmProf prof_(HK_DWCONV_LN, 8.0 * (double)B * T * C, s);
     if (lnw)
         hipLaunchKernelGGL(dwconv_kernel<true>, dim3(grid), dim3(256), 0, s, x, w_kc, bias, lnw, lnb, y, B, T, C, ksize,
                            eps, pad);
@@ -293,6 +297,7 @@ int launch_groupnorm(const float* x, const float* w, const float* bias, float* y
                      int G, float eps, int swish, hipStream_t s) {
     QA_REQUIRE(C % 4 == 0 && C % G == 0, "groupnorm: C=%d G=%d unsupported", C, G);
     const int nchunk = (int)ceil_div(T, GN_ROWS);
+    HbmProf prof_(HK_GROUPNORM, 8.0 * (double)B * T * C, s);  // algorithmic: x once in, y once out (the two-pass form reads x twice)
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 2 * C * sizeof(float), s, x, scratch, T, C, G);
     QA_LAUNCH_CHECK();
     const long long n4 = (long long)T * (C / 4);
@@ -334,6 +339,7 @@ __global__ __launch_bounds__(256) void rope_kernel(float* __restrict__ qkv, cons
 int launch_rope(float* qkv, const float* cos_sin, int B, int N, int H, int hd, long long ld, int pos0, hipStream_t s,
                 int interleaved) {
     const long long total = (long long)B * N * H * (hd / 2);
+    HbmProf prof_(HK_ROPE, 16.0 * (double)B * N * H * hd, s);  // q and k parts: read + write
     hipLaunchKernelGGL(rope_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, qkv, cos_sin, B, N, H, hd, ld,
                        pos0, interleaved);
     QA_LAUNCH_CHECK();
@@ -427,6 +433,7 @@ __global__ __launch_bounds__(256) void istft_spec_kernel(const float* __restrict
 int launch_istft_spec(const float* y, float* S, long long rows, int nb, int ldy, int ldS, hipStream_t s) {
     QA_REQUIRE(ldS >= 2 * nb, "istft_spec: ldS=%d < 2*nb=%d", ldS, 2 * nb);
     const long long total = rows * (long long)(ldS - nb);
+    HbmProf prof_(HK_ISTFT_SPEC, 4.0 * (double)rows * (2.0 * nb + ldS), s);
     hipLaunchKernelGGL(istft_spec_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, y, S, rows, nb, ldy,
                        ldS);
     QA_LAUNCH_CHECK();
@@ -453,6 +460,7 @@ __global__ __launch_bounds__(256) void stft_post_kernel(const float* __restrict_
 int launch_stft_post(const float* ri, float* out, long long rows, int nb, int ldi, int ldo, hipStream_t s) {
     QA_REQUIRE(ldo >= 2 * nb, "stft_post: ldo=%d < 2*nb", ldo);
     const long long total = rows * (long long)(ldo - nb);
+    HbmProf prof_(HK_STFT_POST, 4.0 * (double)rows * (2.0 * nb + ldo), s);
     hipLaunchKernelGGL(stft_post_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, ri, out, rows, nb, ldi, ldo);
     QA_LAUNCH_CHECK();
     return QA_OK;
@@ -486,6 +494,7 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
 int launch_istft_ola(const float* frames, const float* win, float* out, int B, int T, int n_fft, int hop, hipStream_t s) {
     const long long total = (long long)B * T * hop;
     if (total == 0) return QA_OK;
+    HbmProf prof_(HK_ISTFT_OLA, 4.0 * ((double)B * T * n_fft + (double)B * T * hop), s);
     hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, frames, win, out, B, T,
                        n_fft, hop);
     QA_LAUNCH_CHECK();

@@ -281,6 +281,7 @@ int launch_rvq_search(const float* x, long long n_vec, const float* codebooks, c
                 QA_TRY(conv_params_from_args(a, &p));
                 p.am_x2 = x2; p.am_e2 = e2 + (long long)q * K; p.am_dist = pd; p.am_idx = pi; p.am_ld = ng;
                 QA_TRY(launch_conv_gemm(p, s));
+                HbmProf prof_(HK_RVQ_PICK, (double)n * (8.0 * ng + 12.0 * D + 16.0), s);  // group winners, residual read + write, code row
                 hipLaunchKernelGGL(rvq_pick_kernel, dim3(grid), dim3(256), 0, s, pd, pi, ng, x2, cbq, R, n, D, indices + v0 * Q, Q, q);
                 QA_LAUNCH_CHECK();
             }
@@ -301,6 +302,7 @@ int launch_rvq_lookup(const long long* indices, long long n_vec, const float* co
                       long long ldo, hipStream_t s) {
     QA_REQUIRE(D % 4 == 0, "rvq_lookup: D=%d must be a multiple of 4", D);
     if (n_vec <= 0) return QA_OK;
+    HbmProf prof_(HK_RVQ_LOOKUP, (double)n_vec * (8.0 * Q + 4.0 * D * (Q + 1)), s);  // indices + Q gathered code rows + the sum
     hipLaunchKernelGGL(rvq_lookup_kernel, dim3((unsigned)ceil_div(n_vec * (D / 4), 256)), dim3(256), 0, s, indices, n_vec,
                        codebooks, Q, K, D, out, ldo);
     QA_LAUNCH_CHECK();

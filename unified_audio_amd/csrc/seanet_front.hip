@@ -244,6 +244,7 @@ int launch_seanet_front(const float* wav, const float* w0, const float* b0, cons
     const long long n_tiles = (long long)B * ceil_div(L, 128);
     const unsigned grid = (unsigned)std::min<long long>(n_tiles, 512);  // persistent: two workgroups per CU, weights staged once each
     QA_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(seanet_block_kernel<32>), (int)lds));
+    HbmProf prof_(HK_SEANET_FRONT, 4.0 * ((double)B * L + (double)B * L * C), s);  // wav in, the block output `a` written once
     hipLaunchKernelGGL((seanet_block_kernel<32>), dim3(grid), dim3(256), lds, s, p);
     QA_LAUNCH_CHECK();
     return QA_OK;
