@@ -26,7 +26,7 @@ cmd_of() {
     bench-lean) echo "python $R/bench.py --steps 3 --warmup 1 --lean" ;;
     bench-serial) echo "env QA_SERIAL=1 python $R/bench.py --steps 3 --warmup 1 --lean" ;;
     hc10) echo "python $R/bench.py --steps 5 --warmup 2 --lean --model 1.0" ;;
-    hc20) echo "python $R/bench.py --steps 2 --warmup 1 --lean --model 2.0" ;;
+    hc20) echo "python $R/bench.py --steps 2 --warmup 1 --lean --model 2.0 --batch 16 --seconds 30" ;;
     *) echo "$1" ;;
   esac
 }

@@ -63,11 +63,15 @@ def main(out_prefix, *dirs):
                                                      "hbm_bytes_per_launch": w("hbm_bytes_per_launch"), "mfma_busy_frac": w("mfma_busy_frac")}
     order = sorted(rows, key=lambda k: -(rows[k]["avg_us"] or 0) * rows[k]["launches"])
     f = lambda v, fmt: "-" if v is None else fmt % v
-    lines = ["| kernel | launches | avg us | FETCH KiB/launch | WRITE KiB/launch | HBM MB/launch (2F+W) | MFMA busy frac |", "|---|---|---|---|---|---|---|"]
-    for k in order[:24]:
+    lines = ["| kernel | launches | avg us | FETCH KiB/launch | WRITE KiB/launch | HBM MB/launch (2F+W) | HBM GB/s (traffic / duration) | MFMA busy frac |",
+             "|---|---|---|---|---|---|---|---|"]
+    for k in order[:40]:
         v = rows[k]
-        lines.append("| `%s` | %d | %s | %s | %s | %s | %s |" % (k[:90], v["launches"], f(v["avg_us"], "%.1f"), f(v["fetch_kib"], "%.0f"), f(v["write_kib"], "%.0f"),
-                                                               f(v["hbm_bytes_per_launch"] and v["hbm_bytes_per_launch"] / 1e6, "%.1f"), f(v["mfma_busy_frac"], "%.3f")))
+        gbps = v["hbm_bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9 if v["hbm_bytes_per_launch"] is not None and v["avg_us"] else None
+        v["hbm_gbps"] = gbps
+        lines.append("| `%s` | %d | %s | %s | %s | %s | %s | %s |" % (k[:90], v["launches"], f(v["avg_us"], "%.1f"), f(v["fetch_kib"], "%.0f"), f(v["write_kib"], "%.0f"),
+                                                                    f(v["hbm_bytes_per_launch"] and v["hbm_bytes_per_launch"] / 1e6, "%.1f"), f(gbps, "%.0f"),
+                                                                    f(v["mfma_busy_frac"], "%.3f")))
     open(out_prefix + ".md", "w").write("\n".join(lines) + "\n")
     json.dump({k: rows[k] for k in order}, open(out_prefix + ".json", "w"), indent=1)
     print("\n".join(lines[:12]))
