@@ -174,6 +174,10 @@ int qa_rvq_lookup(const int64_t* indices, int64_t n_vec, const float* codebooks,
  * assert on a GPU): *bad = number of entries of codes[0..n) outside [0, limit).  One tiny kernel + one 4-byte copy; synchronises
  * `stream`.  The decode entry points themselves never synchronise and clamp indices for memory safety. */
 int qa_codes_check(const int64_t* codes, int64_t n, int64_t limit, int64_t* bad, void* stream);
+/* The same check without a host synchronisation: *bad_count_dev (DEVICE int64, zeroed by the caller) += number of entries of
+ * codes[0..n) outside [lo, limit).  The caller reads the counter after whatever synchronisation it performs anyway (the Python mirror
+ * reads it behind the decode call's own: one host round trip per decode instead of two). */
+int qa_codes_check_async(const int64_t* codes, int64_t n, int64_t lo, int64_t limit, int64_t* bad_count_dev, void* stream);
 
 /* torchaudio.transforms.Resample(orig_freq, new_freq) with its defaults (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99),
  * the 48 kHz -> 16 kHz step in front of HuBERT in H-Codec 2.0 (HCodec-2.0/audio_tokenizer.py:44,51).

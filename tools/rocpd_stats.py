@@ -18,9 +18,10 @@ def timeline(cur):
     span0 = ev[0][0]
     for st, en, name in ev:
         if st > cur_end:  # nothing was running between cur_end and st: charge the gap to the kernel that ended last
-            g = gaps.setdefault(prev_name[:70], [0, 0])
+            g = gaps.setdefault(prev_name[:70], [0, 0, []])
             g[0] += st - cur_end
             g[1] += 1
+            g[2].append(st - cur_end)
             cur_end = st
         if en > cur_end:
             busy += en - cur_end
@@ -28,9 +29,10 @@ def timeline(cur):
     span = cur_end - span0
     out = ["", "## device timeline", f"span first kernel -> last kernel {span / 1e6:.3f} ms; at least one kernel running {busy / 1e6:.3f} ms "
            f"({100.0 * busy / span:.1f} %); idle {(span - busy) / 1e6:.3f} ms (includes the host-side setup between warm-up and timed steps)", "",
-           "| idle after kernel | gaps | total idle ms | avg us |", "|---|---|---|---|"]
-    for name, (tot, n) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:12]:
-        out.append(f"| `{name}` | {n} | {tot / 1e6:.3f} | {tot / n / 1e3:.2f} |")
+           "| idle after kernel | gaps | total idle ms | median us | max us |", "|---|---|---|---|---|"]
+    for name, (tot, n, each) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:14]:
+        each.sort()
+        out.append(f"| `{name}` | {n} | {tot / 1e6:.3f} | {each[len(each) // 2] / 1e3:.2f} | {each[-1] / 1e3:.2f} |")
     return out
 
 

@@ -98,6 +98,7 @@ SYMBOLS = {
                                             C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_float,
                                             C.c_void_p]),
     "qa_codes_check": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
+    "qa_codes_check_async": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "qa_resample_length": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "qa_resample": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "qa_hcodec_adaptive_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),

@@ -308,6 +308,16 @@ int qa_conv1d_cl(const qa_conv_args* args, void* stream) {
     return launch_conv_gemm(p, static_cast<hipStream_t>(stream));
 }
 
+int qa_codes_check_async(const int64_t* codes, int64_t n, int64_t lo, int64_t limit, int64_t* bad_count_dev, void* stream) {
+    if (!codes || !bad_count_dev) {
+        set_error("qa_codes_check_async: null argument");
+        return QA_ERR_INVALID;
+    }
+    QA_REQUIRE(n >= 0 && limit > lo, "qa_codes_check_async: bad argument");
+    return launch_codes_count(reinterpret_cast<const long long*>(codes), n, lo, limit, reinterpret_cast<unsigned long long*>(bad_count_dev),
+                              static_cast<hipStream_t>(stream));
+}
+
 int qa_codes_check(const int64_t* codes, int64_t n, int64_t limit, int64_t* bad, void* stream) {
     if (!codes || !bad) {
         set_error("qa_codes_check: null argument");

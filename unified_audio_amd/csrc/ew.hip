@@ -719,12 +719,12 @@ int launch_deaggregate(const long long* codes, const long long* len_codes, long 
 
 // ---------------------------------------------------------------------------------------------------------------
 // number of codes outside [0, limit): what F.embedding would refuse (Codec.decode, vq/codec.py:183-184)
-__global__ __launch_bounds__(256) void codes_check_kernel(const long long* __restrict__ codes, long long n, long long limit,
+__global__ __launch_bounds__(256) void codes_check_kernel(const long long* __restrict__ codes, long long n, long long lo, long long limit,
                                                           unsigned long long* __restrict__ bad) {
     unsigned long long local = 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const long long c = codes[i];
-        local += (c < 0 || c >= limit) ? 1ull : 0ull;
+        local += (c < lo || c >= limit) ? 1ull : 0ull;
     }
     local += __shfl_xor(local, 32, 64);
     local += __shfl_xor(local, 16, 64);
@@ -736,9 +736,13 @@ __global__ __launch_bounds__(256) void codes_check_kernel(const long long* __res
 }
 int launch_codes_check(const long long* codes, long long n, long long limit, unsigned long long* bad, hipStream_t s) {
     QA_HIP(hipMemsetAsync(bad, 0, sizeof(unsigned long long), s));
+    return launch_codes_count(codes, n, 0, limit, bad, s);
+}
+// *bad += number of entries outside [lo, limit): no memset, no copy, no synchronisation (qa_codes_check_async)
+int launch_codes_count(const long long* codes, long long n, long long lo, long long limit, unsigned long long* bad, hipStream_t s) {
     if (n <= 0) return QA_OK;
     const unsigned grid = (unsigned)std::min<long long>(ceil_div(n, 256), 1024);
-    hipLaunchKernelGGL(codes_check_kernel, dim3(grid), dim3(256), 0, s, codes, n, limit, bad);
+    hipLaunchKernelGGL(codes_check_kernel, dim3(grid), dim3(256), 0, s, codes, n, lo, limit, bad);
     QA_LAUNCH_CHECK();
     return QA_OK;
 }

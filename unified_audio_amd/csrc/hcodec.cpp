@@ -871,6 +871,7 @@ int decode_tail(qa_hcodec* h, Ctx& c, const float* cat, int B, int N, float* wav
 int read_scalar(Ctx& c, qa_hcodec* h, const int* dev, int* out) {
     QA_HIP(hipMemcpyAsync(h->host_sync, dev, sizeof(int), hipMemcpyDeviceToHost, c.stream));
     QA_HIP(hipStreamSynchronize(c.stream));  // data-dependent shape: the reference syncs here too (modeling_flexicodec_new.py:910)
+    lstm_call_note_sync();                   // ... which also puts every recurrence launched so far behind a host synchronisation
     *out = *h->host_sync;
     return QA_OK;
 }

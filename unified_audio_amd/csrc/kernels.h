@@ -46,6 +46,7 @@ int launch_istft_spec(const float* y, float* S, long long rows, int nb, int ldy,
 int launch_istft_ola(const float* frames, const float* win, float* out, int B, int T, int n_fft, int hop, hipStream_t s);
 
 int launch_codes_check(const long long* codes, long long n, long long limit, unsigned long long* bad, hipStream_t s);
+int launch_codes_count(const long long* codes, long long n, long long lo, long long limit, unsigned long long* bad, hipStream_t s);
 int launch_resample(const float* wav, const float* taps, float* out, int B, long long T, long long T_out, int orig, int nw, int width,
                     int ktaps, hipStream_t s);
 
@@ -73,7 +74,8 @@ int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_st
 // persistent-recurrence bookkeeping for the model graphs: launches so far on `dev`; wait for `s` and report (and clear) a barrier
 // time-out; make this thread's next launch_lstm calls take the per-step kernels
 int lstm_call_begin(int dev, void** ticket);                  // open a model-graph call: own error word + launch count (thread-local)
-int lstm_call_end(void* ticket, hipStream_t s, bool* failed);  // syncs `s` only if the call launched an in-launch recurrence
+int lstm_call_end(void* ticket, hipStream_t s, bool* failed);  // syncs `s` only if a recurrence of the call is still in flight
+void lstm_call_note_sync();                                    // the graph synchronised the call's stream itself: collect now
 void lstm_force_per_step(bool on);
 
 // rvq.hip

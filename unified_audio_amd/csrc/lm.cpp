@@ -463,8 +463,17 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
     QA_REQUIRE(max_len <= LM_MAX_POS, "generate: %d positions exceed max_position_embeddings %d", max_len, LM_MAX_POS);
     const int cap = (int)round_up(max_len, 64);  // cache row stride: shapes that round alike share their captured step graphs
     const bool tiles = lm->fused_ok && head_nt(sp.global_size) && head_nt(sp.semantic_size);
+    // A caller that is CAPTURING its stream into a hipGraph gets the plain single-chain launches on that stream only: no
+    // internal streams, no capture of our own inside theirs (the multi-chain replay path would fail there where the eager path works).
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c.stream, &cap_status) != hipSuccess) {
+        (void)hipGetLastError();
+        cap_status = hipStreamCaptureStatusNone;
+    }
+    const bool capturing = cap_status == hipStreamCaptureStatusActive;
     int nc = (int)knob(K_LM_CHAINS);
     if (nc <= 0) nc = tiles ? (int)ceil_div(B, 32) : 1;
+    if (capturing) nc = 1;
     nc = std::max(1, std::min(std::min(nc, B), LM_MAX_CHAINS));
     const int cb = (int)ceil_div(B, nc);
     nc = (int)ceil_div(B, cb);
@@ -514,7 +523,7 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
 
     // ---- decode: G+1 global tokens (the last is fed to the cache but discarded), then S semantic tokens
     int pos = L;
-    const bool graphs = fused && (multi || use_graphs());
+    const bool graphs = fused && !capturing && (multi || use_graphs());
     auto phase = [&](int which, long long first_id, int steps, int lo, int width, int keep) -> int {
         const int ids_ld = keep;
         for (Chain& ch : chains)

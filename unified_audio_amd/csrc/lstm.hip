@@ -609,7 +609,9 @@ namespace {
 struct LstmCall {
     unsigned* err_host = nullptr;
     unsigned* err_dev = nullptr;
-    unsigned launches = 0;
+    unsigned launches = 0;  // in-launch recurrences this call issued
+    unsigned pending = 0;   // ... of which not yet behind a host synchronisation of the call's stream
+    bool failed = false;    // an observed synchronisation found the error word set
     int dev = -1, slot = -1;
 };
 constexpr int LSTM_ERR_POOL = 64;  // error words (= concurrent model-graph calls) per device; further calls share the device word
@@ -637,7 +639,10 @@ unsigned* lstm_err_word(LstmPersistentDev& P, int dev) {
 }
 void lstm_count_launch(LstmPersistentDev& P, int dev) {
     ++P.launches;
-    if (t_lstm_call && t_lstm_call->dev == dev) ++t_lstm_call->launches;
+    if (t_lstm_call && t_lstm_call->dev == dev) {
+        ++t_lstm_call->launches;
+        ++t_lstm_call->pending;
+    }
 }
 }  // namespace
 
@@ -817,13 +822,30 @@ int lstm_call_begin(int dev, void** ticket) {
     return QA_OK;
 }
 
+// The model graph just synchronised the call's stream on the host for a reason of its own (H-Codec 1.5 reads the data-dependent group
+// count back, hcodec.cpp read_scalar): every recurrence launched so far has finished, so its error word can be read NOW and the call
+// need not synchronise again at its end unless it launches another one - encode of H-Codec 1.5 returns asynchronously again (its
+// LSTMs sit in front of the alignment), which hides the host's preparation of the next call behind ~40 ms of aggregator kernels.
+void lstm_call_note_sync() {
+    LstmCall* c = t_lstm_call;
+    if (!c || !c->pending) return;
+    std::lock_guard<std::mutex> lock(g_lstm_mu);
+    LstmPersistentDev& P = g_lstm_p[c->dev];
+    volatile unsigned* w = c->err_host ? c->err_host : (P.err_host ? P.err_host + LSTM_ERR_POOL : nullptr);
+    if (w && *w != 0u) {
+        *w = 0u;
+        c->failed = true;
+    }
+    c->pending = 0;
+}
+
 int lstm_call_end(void* ticket, hipStream_t s, bool* failed) {
     *failed = false;
     LstmCall* c = static_cast<LstmCall*>(ticket);
     if (!c) return QA_OK;
     if (t_lstm_call == c) t_lstm_call = nullptr;
     int st = QA_OK;
-    if (c->launches) {  // only a call that launched such a kernel pays the host synchronisation
+    if (c->pending) {  // only a call with a recurrence still in flight pays the host synchronisation
         if (hipStreamSynchronize(s) != hipSuccess) {
             set_error("lstm: hipStreamSynchronize failed while collecting an in-launch recurrence");
             st = QA_ERR_HIP;
@@ -833,8 +855,8 @@ int lstm_call_end(void* ticket, hipStream_t s, bool* failed) {
     LstmPersistentDev& P = g_lstm_p[c->dev];
     // a ticket without a pool word (pool exhausted) reported into the device word (lstm_err_word)
     volatile unsigned* w = c->err_host ? c->err_host : (P.err_host ? P.err_host + LSTM_ERR_POOL : nullptr);
-    if (st == QA_OK && c->launches && w && *w != 0u) {
-        *w = 0u;
+    if (st == QA_OK && c->launches && ((w && *w != 0u) || c->failed)) {
+        if (w) *w = 0u;
         if (knob(K_LSTM_FAULT) == 0) P.degraded = true;  // an injected fault (tests) says nothing about the device
         *failed = true;
     }

@@ -255,18 +255,27 @@ class Codec(torch.nn.Module):
         if not self._handle.value:
             raise _lib.QuarkAudioError(-3, "Codec has no weights: call load_state_dict first")
 
-    def _check_range(self, tensors, limit: int, offset: int = 0):
-        """F.embedding's range check (reference: IndexError on the host, device-side assert on a GPU) with ONE host sync for all
-        code tensors of a decode call; `check_codes=False` skips it (the kernels clamp indices for memory safety)."""
+    def _check_range_begin(self, tensors, limit: int, lo: int = 0):
+        """F.embedding's range check (reference: IndexError on the host, device-side assert on a GPU), first half: one tiny counting kernel
+        per code tensor into a device counter - NO host synchronisation here.  `_check_range_end` reads the counter behind a
+        synchronisation the decode performs anyway (the in-launch LSTM's ticket, or H-Codec 1.5's frame-count read-back), so a decode costs
+        one host round trip less than with the synchronous check of round 3.  `check_codes=False` skips it (the kernels clamp indices for
+        memory safety)."""
         if not self.check_codes:
+            return None
+        bad = torch.zeros(1, dtype=torch.int64, device=self.device)
+        for t in tensors:
+            _lib.check(self._lib.qa_codes_check_async(t.data_ptr(), t.numel(), lo, limit, bad.data_ptr(), _stream_ptr(self.device)))
+        return bad, lo, limit
+
+    @staticmethod
+    def _check_range_end(pending):
+        if pending is None:
             return
-        flat = torch.cat([t.reshape(-1) for t in tensors]) if len(tensors) > 1 else tensors[0].reshape(-1)
-        if offset:
-            flat = flat + offset
-        bad = C.c_int64(0)
-        _lib.check(self._lib.qa_codes_check(flat.data_ptr(), flat.numel(), limit, C.byref(bad), _stream_ptr(self.device)))
-        if bad.value:
-            raise IndexError(f"{bad.value} code indices out of range [{-offset}, {limit - offset})")
+        bad, lo, limit = pending
+        n = int(bad.item())
+        if n:
+            raise IndexError(f"{n} code indices out of range [{lo}, {limit})")
 
     # -- hot path ------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -314,11 +323,12 @@ class Codec(torch.nn.Module):
                                            f"{tuple(acoustic_codes.shape)} / {tuple(semantic_codes.shape)}")
         ac = acoustic_codes.to(device=self.device, dtype=torch.int64).contiguous()
         sc = semantic_codes.to(device=self.device, dtype=torch.int64).contiguous()
-        self._check_range((ac, sc), self.spec.codebook_size)
+        pending = self._check_range_begin((ac, sc), self.spec.codebook_size)
         B, _, N = ac.shape
         wav = torch.empty((B, N * self.spec.dec_upsample * self.spec.hop), dtype=torch.float32, device=self.device)
         _lib.check(self._lib.qa_hcodec_decode(self._handle, ac.data_ptr(), sc.data_ptr(), B, N, wav.data_ptr(),
                                               _stream_ptr(self.device)))
+        self._check_range_end(pending)  # IndexError like the reference's F.embedding, raised behind the decode's own synchronisation
         return wav
 
     def enable_taps(self, on: bool = True):
@@ -338,9 +348,10 @@ class Codec(torch.nn.Module):
             ac, sc = (tl - 1) * K + ac, (tl - 1) * K + sc
         B, _, G = ac.shape
         # length-injected: code + (len - 1) * K with len in 0..max_tokens (len 0 = the padding groups of shorter clips: [-K, 0))
-        self._check_range((ac, sc), K * (self.spec.max_tokens_per_group + 1), offset=K)
+        pending = self._check_range_begin((ac, sc), K * self.spec.max_tokens_per_group, lo=-K)
         frames = C.c_int64(0)
         _lib.check(self._lib.qa_hcodec_adaptive_frames(self._handle, sc.data_ptr(), B, G, C.byref(frames), _stream_ptr(self.device)))
+        self._check_range_end(pending)  # the frame count's read-back just synchronised the stream: the counter is there, before any decode work
         n = int(frames.value)
         wav = torch.empty((B, n * 2 * self.spec.hop), dtype=torch.float32, device=self.device)
         _lib.check(self._lib.qa_hcodec_decode_adaptive(self._handle, ac.data_ptr(), sc.data_ptr(), B, G, n, wav.data_ptr(),
