@@ -139,18 +139,6 @@ struct ConvParams {
     float* am_dist;
     int* am_idx;
     int am_ld;
-    // LayerNorm fused across two GEMMs (round 4; mimi layers: norm -> Linear).  PRODUCER side: st_out [M, N / 32, 2] receives, per output row
-    // and per group of 32 consecutive output columns, (mean_g, M2_g = sum (y - mean_g)^2) of the FINAL values the epilogue stores (after
-    // residual / gamma) - two-pass inside the group, so as accurate as a two-pass LayerNorm, and at a FIXED 32-column granularity, so the
-    // result does not depend on the tile configuration (i.e. on the batch size).  CONSUMER side (LINEAR layers only): st_in [M, K / 32, 2]
-    // (the producer's st_out of the same rows) is folded per row with Chan's combination into (mean, rstd = rsqrt(M2 / K + ln_eps)) and the
-    // A operand is normalised while it is staged into LDS: a = (x - mean) * rstd * ln_g[k] + ln_b[k] - the op order of rownorm_kernel.
-    // The normalised activation never exists in HBM and the rownorm launch between the two GEMMs disappears.
-    float* st_out;
-    const float* st_in;
-    const float* ln_g;
-    const float* ln_b;
-    float ln_eps;
 };
 
 // Live measurement hook (bench.py): when enabled every conv_gemm launch is bracketed by HIP events on its own stream.

@@ -92,7 +92,7 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const ConvParams& p, long lo
 // x + m * ldx, so the per-chunk source-frame lookup (LDS read, clamp, select, 64-bit address build) and the padding multiply
 // disappear from the main loop - about 20 of its ~50 non-MFMA instructions, each of which costs ~30 cycles beside the co-resident
 // workgroup's MFMAs.
-template <int BM, int BN, int WM, int WN, bool PRO_ELU, int BK = 32, bool LINEAR = false, bool NORM_A = false>
+template <int BM, int BN, int WM, int WN, bool PRO_ELU, int BK = 32, bool LINEAR = false>
 __global__ __launch_bounds__(256, (BM == 64 && (BK == 16 || BN == 64) ? 4 : (BK == 16 ? 3 : 2))) void conv_gemm_kernel(const ConvParams p_in) {
     ConvParams p = p_in;
     constexpr int LDS = BK + 4;
@@ -177,27 +177,6 @@ __global__ __launch_bounds__(256, (BM == 64 && (BK == 16 || BN == 64) ? 4 : (BK 
     };
     if (!LINEAR) build_taps(0);
     int jbase = 0;
-    if (NORM_A) {
-        // row statistics of this tile's BM rows from the producer's 32-column groups (ConvParams::st_in), Chan's combination in a fixed
-        // order; the table lives in the (unused: LINEAR) tap-table memory: s_tap[2 r] = mean, s_tap[2 r + 1] = rstd as float bits
-        float* s_stat = reinterpret_cast<float*>(s_tap);
-        const int ngrp = p.K >> 5;
-        for (int r = tid; r < BM; r += 256) {
-            const long long m = min(m0 + r, p.M - 1);
-            const float2* sp = reinterpret_cast<const float2*>(p.st_in) + m * ngrp;
-            float msum = 0.f;
-            for (int g = 0; g < ngrp; ++g) msum += sp[g].x;
-            const float mean = msum / (float)ngrp;
-            float m2 = 0.f;
-            for (int g = 0; g < ngrp; ++g) {
-                const float2 st = sp[g];
-                const float dlt = st.x - mean;
-                m2 += st.y + 32.f * dlt * dlt;
-            }
-            s_stat[2 * r] = mean;
-            s_stat[2 * r + 1] = rsqrtf(m2 / (float)p.K + p.ln_eps);
-        }
-    }
 
     const float* a_ptr[A_IT];  // clip base + this thread's column offset inside a chunk
     int a_tab[A_IT];           // byte offset of the row's table line
@@ -227,18 +206,12 @@ __global__ __launch_bounds__(256, (BM == 64 && (BK == 16 || BN == 64) ? 4 : (BK 
     // iteration loads (the last one re-loads chunk nk-1, harmlessly).
     f32x4 a_reg[A_IT], b_reg[B_IT];
     float a_keep[A_IT];  // 0 for frames that fall into zero padding (select on the data at LDS-store time, not on the load)
-    f32x4 ln_g4 = {1.f, 1.f, 1.f, 1.f}, ln_b4 = {0.f, 0.f, 0.f, 0.f};  // NORM_A: LayerNorm weight / bias of this thread's 4 k of the staged chunk
-    float a_mean[A_IT], a_rstd[A_IT];                                   // NORM_A: statistics of the rows this thread stages
 
 #define QA_LOAD_GLOBAL(KC)                                                                                     \
     {                                                                                                          \
         const int k0_ = (KC) * BK;                                                                             \
         if (LINEAR) {                                                                                          \
             _Pragma("unroll") for (int i = 0; i < A_IT; ++i) a_reg[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + k0_); \
-            if (NORM_A) {                                                                                      \
-                ln_g4 = *reinterpret_cast<const f32x4*>(p.ln_g + k0_ + ld_c4);                                 \
-                ln_b4 = *reinterpret_cast<const f32x4*>(p.ln_b + k0_ + ld_c4);                                 \
-            }                                                                                                  \
         } else {                                                                                               \
             const int j_ = k0_ / p.C_in;                                                                       \
             const int c_ = k0_ - j_ * p.C_in;                                                                  \
@@ -261,7 +234,6 @@ __global__ __launch_bounds__(256, (BM == 64 && (BK == 16 || BN == 64) ? 4 : (BK 
         float* b_ = sB + (BUF) * BN * LDS;                                                                     \
         _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                                     \
             f32x4 v = LINEAR ? a_reg[i] : a_reg[i] * a_keep[i];                                                \
-            if (NORM_A) v = (v - a_mean[i]) * a_rstd[i] * ln_g4 + ln_b4; /* rownorm_kernel's op order */       \
             if (PRO_ELU) {                                                                                     \
                 v.x = elu_f(v.x); v.y = elu_f(v.y); v.z = elu_f(v.z); v.w = elu_f(v.w);                        \
             }                                                                                                  \
@@ -271,15 +243,7 @@ __global__ __launch_bounds__(256, (BM == 64 && (BK == 16 || BN == 64) ? 4 : (BK 
             *reinterpret_cast<f32x4*>(b_ + (ld_row + RPP * i) * LDS + ld_c4) = b_reg[i];                       \
     }
 
-    __syncthreads();  // tap table (NORM_A: row statistics) visible
-    if (NORM_A) {
-        const float* s_stat = reinterpret_cast<const float*>(s_tap);
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            a_mean[i] = s_stat[2 * (ld_row + RPP * i)];
-            a_rstd[i] = s_stat[2 * (ld_row + RPP * i) + 1];
-        }
-    }
+    __syncthreads();  // tap table visible
     QA_LOAD_GLOBAL(0)
     QA_STORE_LDS(0)
     __syncthreads();
@@ -414,20 +378,6 @@ __global__ __launch_bounds__(256, (BM == 64 && (BK == 16 || BN == 64) ? 4 : (BK 
             if (p.vec_epi) {  // N % 4 == 0, every leading dimension and pointer 16-byte aligned
                 v = epilogue4(v, p, m, ep_n, bias4, gamma4);
                 *reinterpret_cast<f32x4*>(p.y + m * p.ldy + ep_n) = v;
-                if (p.st_out) {  // launch-uniform; N % 32 == 0, so the 8 lanes of a 32-column group are active together (same row)
-                    float gs = (v.x + v.y) + (v.z + v.w);
-#pragma unroll
-                    for (int o = 1; o < 8; o <<= 1) gs += __shfl_xor(gs, o, 64);
-                    const float gmean = gs * (1.f / 32.f);
-                    const float d0 = v.x - gmean, d1 = v.y - gmean, d2 = v.z - gmean, d3 = v.w - gmean;
-                    float gq = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-#pragma unroll
-                    for (int o = 1; o < 8; o <<= 1) gq += __shfl_xor(gq, o, 64);
-                    if ((ep_c4 & 7) == 0) {
-                        const float2 st = {gmean, gq};
-                        reinterpret_cast<float2*>(p.st_out)[m * (p.N >> 5) + (ep_n >> 5)] = st;
-                    }
-                }
             } else {
                 for (int e = 0; e < 4 && ep_n + e < p.N; ++e) {
                     const int n = ep_n + e;
@@ -484,14 +434,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
                         (p.dilation <= 1);
     QA_REQUIRE(ng == 1 || (linear && ng == 2 && p.w2 && !p.y2), "conv_gemm: a grouped launch needs a Linear layer (ksize 1, QA_GEMM_LINEAR) and w2");
     const bool bk16 = BN >= 64 && p.prologue != ACT_ELU && ((p.K <= bk16_max_k && tiles >= bk16_min_tiles) || p.C_in % 32 != 0);
-    if (p.st_in) {  // LayerNorm applied while A is staged: LINEAR layers on the four MFMA tile shapes (launch_conv_gemm checks)
-        if constexpr (BN >= 64) {
-            if (bk16)
-                hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, 16, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
-            else
-                hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, 32, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
-        }
-    } else if (bk16 && linear)
+    if (bk16 && linear)
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, (BN >= 64 ? 16 : 32), true>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
     else if (bk16)
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, (BN >= 64 ? 16 : 32)>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
@@ -537,12 +480,6 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
     QA_REQUIRE(p.dilation <= 1 || (p.pad_mode == PAD_ZERO && p.in_rep <= 1), "conv_gemm: dilation needs zero padding");
     QA_REQUIRE(!p.am_dist || (q.vec_epi && p.am_idx && p.am_x2 && p.am_e2 && al16(p.am_e2) && p.am_ld >= (p.N + 31) / 32 && !p.y2 && p.groups <= 1),
                "conv_gemm: the arg-min epilogue needs N %% 4 == 0, x2 / e2 / dist / idx and am_ld >= ceil(N / 32)");
-    QA_REQUIRE(!p.st_out || (q.vec_epi && p.N % 32 == 0 && !p.am_dist && !p.y2 && !p.rope && p.post_act == ACT_NONE),
-               "conv_gemm: the LayerNorm-statistics epilogue needs the float4 epilogue and N %% 32 == 0 (N=%d)", p.N);
-    QA_REQUIRE(!p.st_in || (p.ksize == 1 && p.stride == 1 && p.pad_left == 0 && p.in_rep <= 1 && p.T_in == p.T_out && p.dilation <= 1 &&
-                            knob(K_GEMM_LINEAR) != 0 && p.prologue == ACT_NONE && p.K % 32 == 0 && p.N > 32 && p.groups <= 1 && p.ln_g && p.ln_b &&
-                            al16(p.ln_g) && al16(p.ln_b) && ((uintptr_t)p.st_in % 8) == 0),
-               "conv_gemm: a fused LayerNorm needs a Linear layer (ksize 1, QA_GEMM_LINEAR, N > 32, K %% 32 == 0) and 16-byte aligned weight / bias");
     QA_REQUIRE(!p.rope || (q.vec_epi && p.rope_hd % 4 == 0 && p.rope_n % 4 == 0 && p.rope_T > 0 && al16(p.rope)),
                "conv_gemm: fused RoPE needs the float4 epilogue (N, strides, pointers multiples of 4 / 16 B)");
     int cfg;
@@ -576,7 +513,6 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
             }
         }
     }
-    if (p.st_in && cfg == PROF_CFG_128x32) cfg = PROF_CFG_128x64;  // the LayerNorm-fused instances exist for the four MFMA tile shapes
     switch (cfg) {
         case PROF_CFG_128x32: return launch_cfg<128, 32, 4, 1>(q, stream);
         case PROF_CFG_128x64: return launch_cfg<128, 64, 2, 2>(q, stream);

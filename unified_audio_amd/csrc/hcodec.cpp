@@ -341,19 +341,10 @@ void build_mimi(Builder& b, MimiW* mw, const std::string& p, int d, int n_layers
 
 // ---------------------------------------------------------------- graph helpers
 
-// LayerNorm fused across two GEMMs (ConvParams::st_out / st_in): the producer's epilogue leaves the row statistics of what it stores,
-// the consumer normalises its A operand while staging it - the normalised activation never exists in HBM
-struct LnFuse {
-    float* st_out = nullptr;                 // producer: [rows, N / 32, 2]
-    const float* st_in = nullptr;            // consumer: [rows, K / 32, 2] ...
-    const float *g = nullptr, *b = nullptr;  // ... with the LayerNorm weight / bias
-    float eps = 0.f;
-};
-
 int conv_op(Ctx& c, const float* x, int64_t ldx, int B, int T_in, const ConvW& w, float* y, int64_t ldy, int T_out,
             int stride, int pad_left, int pad_right, int pad_mode, int prologue, int act, const float* gamma,
             const float* res, int64_t ldr, const float* gate, int post_act, int in_rep = 1, const float* rope = nullptr,
-            int rope_n = 0, int rope_hd = 0, int rope_T = 0, int rope_pos0 = 0, const LnFuse* ln = nullptr) {
+            int rope_n = 0, int rope_hd = 0, int rope_T = 0, int rope_pos0 = 0) {
     if (c.dry) return QA_OK;
     qa_conv_args a{};
     a.x = x; a.w = w.w; a.bias = w.b; a.gamma = gamma; a.residual = res; a.gate = gate; a.y = y;
@@ -367,10 +358,6 @@ int conv_op(Ctx& c, const float* x, int64_t ldx, int B, int T_in, const ConvW& w
     p.algo_n = w.algo_n;
     p.algo_k = w.algo_cin ? w.algo_cin * w.ksize : 0;
     p.rope = rope; p.rope_n = rope_n; p.rope_hd = rope_hd; p.rope_T = rope_T; p.rope_pos0 = rope_pos0;
-    if (ln) {
-        p.st_out = ln->st_out;
-        p.st_in = ln->st_in; p.ln_g = ln->g; p.ln_b = ln->b; p.ln_eps = ln->eps;
-    }
     return launch_conv_gemm(p, c.stream);
 }
 
@@ -401,9 +388,9 @@ int linear_pair_op(Ctx& c, const float* xa, const float* xb, int64_t rows, const
 
 // plain linear over `rows` rows
 int linear_op(Ctx& c, const float* x, int64_t rows, const ConvW& w, float* y, int act = ACT_NONE,
-              const float* res = nullptr, const float* gate = nullptr, const float* gamma = nullptr, const LnFuse* ln = nullptr) {
+              const float* res = nullptr, const float* gate = nullptr, const float* gamma = nullptr) {
     return conv_op(c, x, w.C_in, 1, (int)rows, w, y, w.N, (int)rows, 1, 0, 0, PAD_ZERO, ACT_NONE, act, gamma, res, w.N,
-                   gate, ACT_NONE, 1, nullptr, 0, 0, 0, 0, ln);
+                   gate, ACT_NONE);
 }
 
 // "same" zero-padded stride-1 conv (vq/conv.py:33-56, semantic_module.py:28-31)
@@ -483,24 +470,18 @@ int transformer_op(Ctx& c, const TransformerW& tw, float* x, int B, int N, const
 // StreamingTransformer.forward, non-causal / non-streaming (mimi/transformer.py:377-425,553-594,674-698), in place on x
 struct MimiTemps {
     float *hn, *qkv, *att, *u;
-    float* stats;  // [rows, d / 32, 2] row statistics of x in 32-column groups (QA_LN_FUSED), or null
 };
-bool mimi_ln_fused(const MimiW& mw) { return knob(K_LN_FUSED) != 0 && knob(K_GEMM_LINEAR) != 0 && mw.d % 32 == 0 && mw.d > 32; }
 MimiTemps mimi_temps(Ctx& c, const MimiW& mw, int64_t rows) {
     MimiTemps t;
     t.hn = c.arena.alloc<float>(rows * mw.d);
     t.qkv = c.arena.alloc<float>(rows * 3 * mw.d);
     t.att = c.arena.alloc<float>(rows * mw.d);
     t.u = c.arena.alloc<float>(rows * mw.ff);
-    t.stats = mimi_ln_fused(mw) ? c.arena.alloc<float>(rows * (mw.d / 32) * 2) : nullptr;
     return t;
 }
 // st != nullptr: streaming step of N frames at st->offset (layer index li selects the ring caches); the caller advances the offset
-// stats_in: t.stats holds the statistics of x (left by the previous layer's lin2) - LN1 rides in the QKV projection; make_stats: lin2
-// leaves them for the next layer.  Offline stacks only (QA_LN_FUSED): per layer the two rownorm launches and their 2 x read + write of
-// the activation disappear, except LN1 of the first layer of a stack (nobody produced x's statistics).
 int mimi_layer(Ctx& c, const MimiW& mw, const MimiLayerW& L, float* x, const MimiTemps& t, int B, int N, MimiStream* st = nullptr,
-               size_t li = 0, bool stats_in = false, bool make_stats = false) {
+               size_t li = 0) {
     const int d = mw.d, H = mw.heads, hd = d / H;
     const int64_t rows = (int64_t)B * N;
     const int pos0 = st ? st->offset : 0;
@@ -508,16 +489,10 @@ int mimi_layer(Ctx& c, const MimiW& mw, const MimiLayerW& L, float* x, const Mim
     const float* rope = win ? st->rope_win : mw.rope;
     const int rope_pos0 = win ? pos0 - st->rope_base : pos0;
     const float scale = 1.0f / std::sqrt((float)hd);
-    const bool fuse = t.stats != nullptr && st == nullptr;
-    LnFuse ln1, ln2, mk;
-    ln1.st_in = t.stats; ln1.g = L.n1w; ln1.b = L.n1b; ln1.eps = 1e-5f;
-    ln2.st_in = t.stats; ln2.g = L.n2w; ln2.b = L.n2b; ln2.eps = 1e-5f;
-    mk.st_out = t.stats;
-    const bool fuse1 = fuse && stats_in;
-    if (!fuse1) QA_TRY(launch_layernorm(x, L.n1w, L.n1b, t.hn, rows, d, 1e-5f, c.stream));
+    QA_TRY(launch_layernorm(x, L.n1w, L.n1b, t.hn, rows, d, 1e-5f, c.stream));
     // fused QKV projection with the interleaved-pair RoPE of q and k applied in the GEMM epilogue (one launch less per layer)
-    QA_TRY(conv_op(c, fuse1 ? x : t.hn, d, 1, (int)rows, L.in_proj, t.qkv, 3 * d, (int)rows, 1, 0, 0, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, nullptr,
-                   3 * d, nullptr, ACT_NONE, 1, rope, 2 * d, hd, N, rope_pos0, fuse1 ? &ln1 : nullptr));
+    QA_TRY(conv_op(c, t.hn, d, 1, (int)rows, L.in_proj, t.qkv, 3 * d, (int)rows, 1, 0, 0, PAD_ZERO, ACT_NONE, ACT_NONE, nullptr, nullptr,
+                   3 * d, nullptr, ACT_NONE, 1, rope, 2 * d, hd, N, rope_pos0));
     if (st) {
         // RingKVCache.complete(): the chunk's keys / values are written first, then every query attends over the ring
         QA_TRY(launch_ring_append(t.qkv + d, t.qkv + 2 * d, 3 * d, st->kc[li], st->vc[li], B, N, d, st->cap, pos0, c.stream));
@@ -527,18 +502,17 @@ int mimi_layer(Ctx& c, const MimiW& mw, const MimiLayerW& L, float* x, const Mim
         QA_TRY(launch_attention(t.qkv, 3 * d, t.qkv + d, t.qkv + 2 * d, 3 * d, t.att, d, B, N, N, (long long)N * 3 * d, H, hd, scale,
                                 mw.causal, c.stream, nullptr, nullptr, 0, mw.causal ? mw.context : 0));
     }
-    QA_TRY(linear_op(c, t.att, rows, L.out_proj, x, ACT_NONE, x, nullptr, L.ls1, fuse ? &mk : nullptr));
-    if (!fuse) QA_TRY(launch_layernorm(x, L.n2w, L.n2b, t.hn, rows, d, 1e-5f, c.stream));
-    QA_TRY(linear_op(c, fuse ? x : t.hn, rows, L.lin1, t.u, ACT_GELU, nullptr, nullptr, nullptr, fuse ? &ln2 : nullptr));
-    return linear_op(c, t.u, rows, L.lin2, x, ACT_NONE, x, nullptr, L.ls2, fuse && make_stats ? &mk : nullptr);
+    QA_TRY(linear_op(c, t.att, rows, L.out_proj, x, ACT_NONE, x, nullptr, L.ls1));
+    QA_TRY(launch_layernorm(x, L.n2w, L.n2b, t.hn, rows, d, 1e-5f, c.stream));
+    QA_TRY(linear_op(c, t.hn, rows, L.lin1, t.u, ACT_GELU));
+    return linear_op(c, t.u, rows, L.lin2, x, ACT_NONE, x, nullptr, L.ls2);
 }
 int mimi_op(Ctx& c, const MimiW& mw, float* x, int B, int N) {
     QA_REQUIRE(N <= MAX_POS, "mimi transformer: sequence of %d tokens exceeds %d", N, MAX_POS);
     const size_t mark = c.arena.mark();
     const MimiTemps t = mimi_temps(c, mw, (int64_t)B * N);
     if (!c.dry)
-        for (size_t i = 0; i < mw.layers.size(); ++i)
-            QA_TRY(mimi_layer(c, mw, mw.layers[i], x, t, B, N, nullptr, 0, i > 0, i + 1 < mw.layers.size()));
+        for (const MimiLayerW& L : mw.layers) QA_TRY(mimi_layer(c, mw, L, x, t, B, N));
     c.arena.release(mark);
     return QA_OK;
 }
@@ -589,10 +563,9 @@ int mimi_pair_op(Ctx& c, hipStream_t side, const MimiW& wa, float* xa, const Mim
         hipStream_t main = c.stream;
         for (size_t l = 0; l < wa.layers.size(); ++l) {
             c.stream = main;
-            const bool more = l + 1 < wa.layers.size();
-            int st = mimi_layer(c, wa, wa.layers[l], xa, ta, B, N, nullptr, 0, l > 0, more);
+            int st = mimi_layer(c, wa, wa.layers[l], xa, ta, B, N);
             c.stream = side;
-            if (st == QA_OK) st = mimi_layer(c, wb, wb.layers[l], xb, tb, B, N, nullptr, 0, l > 0, more);
+            if (st == QA_OK) st = mimi_layer(c, wb, wb.layers[l], xb, tb, B, N);
             c.stream = main;
             QA_TRY(st);
         }
@@ -1530,7 +1503,7 @@ static int mimi_run(qa_mimi* m, const float* x, int B, int T, float* y, hipStrea
         }
         if (y != x) QA_HIP(hipMemcpyAsync(y, x, sizeof(float) * rows * m->w.d, hipMemcpyDeviceToDevice, stream));
         for (size_t l = 0; l < m->w.layers.size(); ++l)
-            QA_TRY(mimi_layer(c, m->w, m->w.layers[l], y, t, B, T, streaming ? &m->st : nullptr, l, l > 0, l + 1 < m->w.layers.size()));
+            QA_TRY(mimi_layer(c, m->w, m->w.layers[l], y, t, B, T, streaming ? &m->st : nullptr, l));
     }
     return QA_OK;
 }

@@ -17,7 +17,6 @@ namespace qa {
     X(GEMM_LINEAR, "QA_GEMM_LINEAR", 1, "table-free K loop for ksize-1 layers")                                                  \
     X(GEMM_XCD, "QA_GEMM_XCD", 1, "XCD-aware tile order")                                                                        \
     X(GEMM_PANEL, "QA_GEMM_PANEL", 8, "conv_gemm tile order: column panels of this many tiles, row tiles fastest inside a panel (0: column tiles fastest over the whole row; 8: +4 % on N >= 4096 shapes, +1.2 % on H-Codec 2.0)") \
-    X(LN_FUSED, "QA_LN_FUSED", 0, "mimi stacks (H-Codec 1.5 aggregators + bottleneck): 1 = LayerNorm fused across the GEMMs around it - out_proj / lin2 leave the row statistics of what they store in their epilogue (32-column groups, two-pass inside a group), the QKV projection / lin1 normalise their A operand while staging it; the rownorm launch and its read + write of the activation disappear (all but LN1 of a stack's first layer)") \
     X(GEMM_GROUPED, "QA_GEMM_GROUPED", 0, "H-Codec 1.5: 1 = the two aggregator stacks as ONE grouped launch per layer op on one stream (measured: 147.1 ms against 143.5 for the default, the two stacks on two streams)") \
     X(ATT_DEBUG, "QA_ATT_DEBUG", 0, "attention_kernel debug bits: 1 always rescale, 2 extra barrier per tile, 4 wait for the prefetch at once") \
     X(SEANET_FUSED, "QA_SEANET_FUSED", 1, "fused conv0 + first SEANet residual block")                                           \
