@@ -144,6 +144,44 @@ def _gen(lm, spec, device, B, Nm, S, G, **kw):
     return g.cpu(), s.cpu()
 
 
+@pytest.mark.parametrize("B", [6, 40])
+def test_generate_under_a_callers_stream_capture(qa_lib, gpu_device, knob, B):
+    """batches above 32 sequences default to concurrent chains on INTERNAL streams that replay step graphs captured by the
+    library - inside a caller's own stream capture that would fail where the plain launches work.  qa_lm_generate now asks
+    hipStreamIsCapturing and, when the caller is capturing, issues everything as plain launches on the caller's stream (one chain, no
+    capture of its own): the call can be recorded into a caller's hipGraph (torch.cuda.graph) and the replayed graph produces the eager
+    call's tokens."""
+    spec = L.SPEC_UNISE
+    _, lm = _model(spec, 35, gpu_device)
+    mix = L.synth_feats(43, B, 12, spec.feats_dim).to(gpu_device)
+    mel = torch.zeros(B, 10, 80)
+    eager = lm.generate("se", None, None, mel, mix, global_length=6, do_sample=False)
+    torch.cuda.synchronize()
+    eager = (eager[0].clone(), eager[1].clone())
+    knob("QA_LM_CHAINS", 1)  # the layout a capturing caller gets: one eager call sizes the workspace for it (no allocation under capture)
+    one = lm.generate("se", None, None, mel, mix, global_length=6, do_sample=False)
+    torch.cuda.synchronize()
+    assert torch.equal(one[0], eager[0]) and torch.equal(one[1], eager[1])  # chains are a schedule, not a result
+    knob("QA_LM_CHAINS", 0)
+    side = torch.cuda.Stream(gpu_device)
+    side.wait_stream(torch.cuda.current_stream(gpu_device))
+    with torch.cuda.stream(side):  # one plain call on the capture stream first, as torch's graph recipe prescribes
+        lm.generate("se", None, None, mel, mix, global_length=6, do_sample=False)
+    torch.cuda.current_stream(gpu_device).wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = lm.generate("se", None, None, mel, mix, global_length=6, do_sample=False)
+    out[0].zero_()
+    out[1].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], eager[0]) and torch.equal(out[1], eager[1])
+    again = lm.generate("se", None, None, mel, mix, global_length=6, do_sample=False)  # and the handle is usable eagerly afterwards
+    torch.cuda.synchronize()
+    assert torch.equal(again[0], eager[0]) and torch.equal(again[1], eager[1])
+
+
 def test_graph_replay_equals_eager_launches_and_is_deterministic(qa_lib, gpu_device, knob):
     """One captured step replayed per token (QA_LM_GRAPH, the default) against the same kernels launched eagerly: identical
     integers; repeated calls re-use the captured graphs and the workspace and stay identical; a second shape re-captures."""

@@ -685,6 +685,15 @@ static int lm_generate_impl(qa_lm* lm, int32_t task, const float* enroll_feats, 
     c.arena.begin(nullptr, 0);
     QA_TRY(generate_graph(lm, c, task, enroll_feats, (int)n_enroll, mix_feats, (int)n_mix, (int)B, global_length, semantic_length,
                           (long long*)global_ids, (long long*)semantic_ids, sc));
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(c.stream, &cs) != hipSuccess) (void)hipGetLastError();
+        // growing the workspace synchronises the device and allocates: neither is possible inside a caller's stream capture
+        QA_REQUIRE(cs != hipStreamCaptureStatusActive || c.arena.peak() <= lm->ws_cap,
+                   "qa_lm_generate under a stream capture needs %zu bytes of workspace, the handle holds %zu: make one call of the same shape outside "
+                   "the capture first (with QA_LM_CHAINS=1 for batches above 32: a capturing caller gets the single-chain launches)",
+                   c.arena.peak(), lm->ws_cap);
+    }
     QA_TRY(ensure_ws(lm, c.arena.peak()));
     c.dry = false;
     c.arena.begin(lm->ws, lm->ws_cap);
