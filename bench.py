@@ -665,9 +665,19 @@ def main():
     for k in range(n_hbm):
         by, ms, n = hbm[3 * k], hbm[3 * k + 1], hbm[3 * k + 2]
         if n:
-            hbm_rows.append({"kernel": lib.qa_profile_hbm_name(k).decode(), "launches_per_step": n / 2, "avg_us": 1e3 * ms / n,
-                             "algorithmic_bytes_per_launch": by / n, "achieved_GBps": by / (ms * 1e-3) / 1e9, "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                             "ms_per_step": ms / 2})
+            row = {"kernel": lib.qa_profile_hbm_name(k).decode(), "launches_per_step": n / 2, "avg_us": 1e3 * ms / n,
+                   "algorithmic_bytes_per_launch": by / n, "achieved_GBps": by / (ms * 1e-3) / 1e9, "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                   "ms_per_step": ms / 2}
+            if row["kernel"].startswith("seanet_block") and args.model != "2.0":
+                # the one kernel north_star calls HBM-bound is not, in fp32: conv0 (k7, 1 -> 32) + k3 32 -> 16 + 1x1 16 -> 32 + the 32 -> 32 shortcut
+                # are 3 296 MACs per sample for 132 bytes moved: 50 FLOP/B against a ridge of 157.3 / 8 = 19.7 FLOP/B, so its floor is the
+                # matrix pipe (0.21 ms per launch), not HBM (0.085 ms) - price it against BOTH
+                flop = 2.0 * 3296.0 * B * T
+                row.update({"flop_per_launch": flop, "tflops": flop / (1e-3 * ms / n) / 1e12, "frac_of_f32_mfma_peak": flop / (1e-3 * ms / n) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                            "arithmetic_intensity_flop_per_byte": flop / (by / n), "ridge_flop_per_byte": MFMA_F32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBPS,
+                            "bound": "mfma (arithmetic intensity above the fp32 ridge: even at the matrix peak this launch would move its bytes at "
+                                     "0.40 of the HBM peak)"})
+            hbm_rows.append(row)
 
     # secondary: the same step with host (pageable) tensors in and out, as HCodecTokenizer's __main__ moves them
     # (audio_tokenizer.py:79,84: wav.to(device) ... wav_rec.cpu()); never `value`
