@@ -125,6 +125,41 @@ def test_gather_pads_data_dependent_trailing_dims_gloo():
     assert not q.empty() and q.get() == "ok"
 
 
+def _worker_subgroup(rank, world, port, q):
+    """The drivers inside a SUB-group (e.g. one group per node): global ranks 1 and 2 of a world of 3 form the group, its rank 0 (global 1)
+    is the root.  `src` / `dst` are group ranks; torch.distributed's point-to-point calls and object broadcasts want global ranks."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        grp = dist.new_group(ranks=[1, 2])  # every rank of the world calls new_group
+        if rank == 0:
+            q.put("idle")
+            return
+        dev = torch.device("cpu")
+        root = dist.get_rank(grp) == 0
+        clips = torch.arange(5 * 6, dtype=torch.float32).view(5, 6) if root else None
+
+        def hot(wav):
+            return (wav[:, :2] * 3).to(torch.int64), wav + 1.0
+
+        out = qd.run_sharded(hot, [clips], dev, group=grp)
+        utts = [torch.full((n,), float(i)) for i, n in enumerate((9, 2, 4, 7))] if root else None
+        rag = qd.run_sharded_ragged(lambda us: [u * 2 for u in us], utts, dev, group=grp)
+        if root:
+            ok = all(torch.equal(a, b) for a, b in zip(out, hot(clips))) and all(torch.equal(a, b * 2) for a, b in zip(rag, utts))
+            q.put("ok" if ok else "mismatch")
+        else:
+            assert out is None and rag is None
+            q.put("peer")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_drivers_work_inside_a_subgroup_gloo():
+    q = _run_ranks(_worker_subgroup, 3, ())
+    assert sorted(_drain(q, 3)) == ["idle", "ok", "peer"]
+
+
 # --------------------------------------------------------------------------------------- ragged lists, failure propagation
 
 def test_balanced_partition_properties():

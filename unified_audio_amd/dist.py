@@ -5,6 +5,8 @@ codes / waveforms back.  The reference does rank-strided sharding
 
 One process per GPU (`torchrun`), `torch.distributed` backend "nccl" (= RCCL over xGMI on ROCm) on GPUs, "gloo" in the
 CPU tests.  Transfers are direct rank0 <-> rank_i (scatter / gather), never an all-reduce: nothing is reduced.
+`src` / `dst` and every rank in here are ranks OF THE GROUP passed in (group=None: the world); they are translated to global ranks
+where torch.distributed wants those (`_peer`), so the drivers work unchanged inside a sub-group (e.g. one group per node).
 """
 from __future__ import annotations
 
@@ -29,8 +31,13 @@ def _meta_from_root(t: Optional[torch.Tensor], src: int, group=None):
     meta = [None]
     if dist.get_rank(group) == src:
         meta = [(tuple(t.shape), t.dtype)]
-    dist.broadcast_object_list(meta, src=src, group=group)
+    dist.broadcast_object_list(meta, src=_peer(group, src), group=group)
     return meta[0]
+
+
+def _peer(group, group_rank: int) -> int:
+    """P2POp / send / recv address a peer by its GLOBAL rank; the partitions here are computed in group-local ranks."""
+    return group_rank if group is None else dist.get_global_rank(group, group_rank)
 
 
 def _exchange(ops) -> None:
@@ -57,12 +64,12 @@ def scatter_clips(clips: Optional[torch.Tensor], device: torch.device, src: int 
         for r in range(world):
             ra, rb = shard_range(shape[0], r, world)
             if r != src and rb > ra:
-                ops.append(dist.P2POp(dist.isend, clips[ra:rb].to(device), r, group))
+                ops.append(dist.P2POp(dist.isend, clips[ra:rb].to(device), _peer(group, r), group))
         _exchange(ops)
         return clips[a:b].to(device)
     out = torch.empty((b - a,) + tuple(shape[1:]), dtype=dtype, device=device)
     if b > a:
-        _exchange([dist.P2POp(dist.irecv, out, src, group)])
+        _exchange([dist.P2POp(dist.irecv, out, _peer(group, src), group)])
     return out
 
 
@@ -81,7 +88,7 @@ def gather_ragged(local: torch.Tensor, dst: int = 0, group=None, pad_value=0) ->
     shapes = [[int(v) for v in t.tolist()] for t in shapes]
     if rank != dst:
         if local.numel() > 0:
-            _exchange([dist.P2POp(dist.isend, local.contiguous(), dst, group)])
+            _exchange([dist.P2POp(dist.isend, local.contiguous(), _peer(group, dst), group)])
         return None
     # a rank with an empty shard has no trailing extents of its own (run_sharded builds them from another rank's signature)
     trail = tuple(max(t[i] for t in shapes) for i in range(1, local.dim()))
@@ -98,10 +105,10 @@ def gather_ragged(local: torch.Tensor, dst: int = 0, group=None, pad_value=0) ->
         if r == dst:
             rows[tuple(slice(None) if i == 0 else slice(0, e) for i, e in enumerate(local.shape))] = local
         elif tuple(t[1:]) == trail:
-            ops.append(dist.P2POp(dist.irecv, rows, r, group))
+            ops.append(dist.P2POp(dist.irecv, rows, _peer(group, r), group))
         else:
             buf = torch.empty(t, dtype=local.dtype, device=local.device)
-            ops.append(dist.P2POp(dist.irecv, buf, r, group))
+            ops.append(dist.P2POp(dist.irecv, buf, _peer(group, r), group))
             staged.append((rows, buf))
     _exchange(ops)
     for rows, buf in staged:
@@ -198,18 +205,18 @@ def run_sharded_ragged(fn: Callable[[List[torch.Tensor]], Sequence[torch.Tensor]
     if rank == src:
         lengths = [int(u.numel()) for u in utterances]
         plan = [(balanced_partition(lengths, world), lengths, utterances[0].dtype if utterances else torch.float32)]
-    dist.broadcast_object_list(plan, src=src, group=group)
+    dist.broadcast_object_list(plan, src=_peer(group, src), group=group)
     parts, lengths, dtype = plan[0]
     mine = parts[rank]
     # ---- scatter: one packed tensor per destination rank
     if rank == src:
-        _exchange([dist.P2POp(dist.isend, _pack([utterances[i] for i in parts[r]], device, dtype), r, group)
+        _exchange([dist.P2POp(dist.isend, _pack([utterances[i] for i in parts[r]], device, dtype), _peer(group, r), group)
                    for r in range(world) if r != src and parts[r]])
         local = [utterances[i].reshape(-1).to(device) for i in mine]
     else:
         packed = torch.empty(sum(lengths[i] for i in mine), dtype=dtype, device=device)
         if mine:
-            dist.recv(packed, src=src, group=group)
+            dist.recv(packed, src=_peer(group, src), group=group)
         local, at = [], 0
         for i in mine:
             local.append(packed[at:at + lengths[i]])
@@ -229,11 +236,11 @@ def run_sharded_ragged(fn: Callable[[List[torch.Tensor]], Sequence[torch.Tensor]
     dist.all_gather_object(meta, ([int(o.numel()) for o in outs], outs[0].dtype if outs else None), group=group)
     if rank != src:
         if outs:
-            dist.send(_pack(outs, device, outs[0].dtype), dst=src, group=group)
+            dist.send(_pack(outs, device, outs[0].dtype), dst=_peer(group, src), group=group)
         return None
     result: List[Optional[torch.Tensor]] = [None] * len(lengths)
     bufs = {r: torch.empty(sum(meta[r][0]), dtype=meta[r][1], device=device) for r in range(world) if r != src and meta[r][0]}
-    _exchange([dist.P2POp(dist.irecv, buf, r, group) for r, buf in bufs.items()])  # every peer's packed results as one group
+    _exchange([dist.P2POp(dist.irecv, buf, _peer(group, r), group) for r, buf in bufs.items()])  # every peer's packed results as one group
     for r in range(world):
         lens, _ = meta[r]
         if not lens:
