@@ -6,8 +6,6 @@
 
 namespace qa {
 
-typedef float f32x4v __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs
-
 // ------------------------------------------------------------------------------------------------
 // conv_in: SConv1d with C_in = 1 (reference: encoder.model.0, encoder_modules/conv.py:195-211; seanet.py:121-124)
 // y[b, t, co] = bias[co] + sum_j w[co, j] * x[b, reflect(t - pad_left + j)]
@@ -194,86 +192,6 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
     }
 }
 
-// Round 4: the same operation as a SLIDING WINDOW.  dwconv_kernel gives every output frame a wave that re-reads the ksize input frames
-// around it (7 x the L1 / TA traffic of the algorithm: 2.6 - 3.0 TB/s of algorithmic bytes, a third of the HBM roofline).  Here a
-// workgroup of ceil(C / 256) waves walks a run of `run` consecutive frames of one clip: every lane owns ONE float4 of channels, the last
-// ksize frames of it live in REGISTERS and shift by one per output frame, the filter taps, bias and LayerNorm weights stay in registers
-// for the whole run, and the loads of the next PF = 3 frames are in flight while a frame is computed (a wave keeps 3 KB outstanding;
-// ~18 waves per CU: the ~50 KB per CU an HBM-rate stream needs): every input frame is read ONCE per run (+ ksize - 1 frames of warm-up),
-// every output written once.  LayerNorm over the C channels needs all waves of the workgroup: per-wave partial sums meet in LDS
-// (two-pass like rownorm_kernel: mean, then sum of squared deviations), double-buffered by frame parity so that two barriers per frame
-// suffice.
-template <bool LN>
-__global__ __launch_bounds__(512) void dwconv_run_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, const float* __restrict__ lnw,
-                                                         const float* __restrict__ lnb, float* __restrict__ y, int T, int C, int ksize,
-                                                         float eps, int pad, int run, int runs_per_clip) {
-    constexpr int KMAX = 7, PF = 3;
-    __shared__ float s_sum[2][8], s_sq[2][8];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int b = blockIdx.x / runs_per_clip, t0 = (blockIdx.x % runs_per_clip) * run;
-    const int t1 = min(t0 + run, T);
-    const int ch = (wave * 64 + lane) * 4;
-    const bool live = ch < C;
-    const int c = live ? ch : 0;
-    const float* xc = x + (long long)b * T * C + c;
-    float* yc = y + (long long)b * T * C + c;
-    const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4v wt[KMAX], win[KMAX], nxt[PF];
-    const f32x4v bs = *reinterpret_cast<const f32x4v*>(bias + c);
-    const f32x4v gw = LN ? *reinterpret_cast<const f32x4v*>(lnw + c) : zero;
-    const f32x4v gb = LN ? *reinterpret_cast<const f32x4v*>(lnb + c) : zero;
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j) wt[j] = j < ksize ? *reinterpret_cast<const f32x4v*>(w + (long long)j * C + c) : zero;
-    auto frame = [&](int src) -> f32x4v {  // frame `src` of this lane's channel quad; zero padding outside the clip
-        return (live && src >= 0 && src < T) ? *reinterpret_cast<const f32x4v*>(xc + (long long)src * C) : zero;
-    };
-    // warm-up: win[1 .. ksize - 1] = frames t0 - pad .. t0 - pad + ksize - 2; the frames after them arrive through the prefetch ring
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j) win[j] = (j >= 1 && j < ksize) ? frame(t0 - pad + j - 1) : zero;
-#pragma unroll
-    for (int k = 0; k < PF; ++k) nxt[k] = frame(t0 - pad + ksize - 1 + k);
-    for (int t = t0; t < t1; ++t) {
-#pragma unroll
-        for (int j = 0; j + 1 < KMAX; ++j) win[j] = win[j + 1];  // shift: win[j] = frame t - pad + j
-#pragma unroll
-        for (int j = 0; j < KMAX; ++j)
-            if (j == ksize - 1) win[j] = nxt[0];
-#pragma unroll
-        for (int k = 0; k + 1 < PF; ++k) nxt[k] = nxt[k + 1];
-        nxt[PF - 1] = frame(t + PF - pad + ksize - 1);  // PF frames ahead: in flight under the arithmetic of this and the next frames
-        f32x4v a = bs;
-#pragma unroll
-        for (int j = 0; j < KMAX; ++j)
-            if (j < ksize) {  // taps in ascending order, one fma each: the accumulation order of dwconv_kernel
-                a.x = fmaf(win[j].x, wt[j].x, a.x);
-                a.y = fmaf(win[j].y, wt[j].y, a.y);
-                a.z = fmaf(win[j].z, wt[j].z, a.z);
-                a.w = fmaf(win[j].w, wt[j].w, a.w);
-            }
-        if (LN) {
-            const int par = t & 1;
-            float s = live ? (a.x + a.y) + (a.z + a.w) : 0.f;
-            s = wave_sum(s);
-            if (lane == 0) s_sum[par][wave] = s;
-            __syncthreads();
-            float tot = 0.f;
-            for (int k = 0; k < nw; ++k) tot += s_sum[par][k];
-            const float mean = tot / C;
-            const float d0 = a.x - mean, d1 = a.y - mean, d2 = a.z - mean, d3 = a.w - mean;
-            float q = live ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
-            q = wave_sum(q);
-            if (lane == 0) s_sq[par][wave] = q;
-            __syncthreads();
-            float qt = 0.f;
-            for (int k = 0; k < nw; ++k) qt += s_sq[par][k];
-            const float rstd = rsqrtf(qt / C + eps);
-            a = (a - mean) * rstd * gw + gb;
-        }
-        if (live) *reinterpret_cast<f32x4v*>(yc + (long long)t * C) = a;
-    }
-}
-
 int launch_dwconv(const float* x, const float* w_kc, const float* bias, const float* lnw, const float* lnb, float* y,
                   int B, int T, int C, int ksize, float eps, hipStream_t s, int pad_left) {
     QA_REQUIRE(C % 4 == 0 && C <= 256 * MAX_V4 && (ksize & 1) && pad_left < ksize, "dwconv: C=%d ksize=%d pad_left=%d unsupported", C,
@@ -281,16 +199,6 @@ int launch_dwconv(const float* x, const float* w_kc, const float* bias, const fl
     const unsigned grid = (unsigned)ceil_div((long long)B * T, 4);
     const int pad = pad_left >= 0 ? pad_left : ksize / 2;
     HbmProf prof_(HK_DWCONV_LN, 8.0 * (double)B * T * C, s);
-    if (knob(K_DWCONV_RUN) != 0 && C <= 2048 && ksize <= 7 && (lnw == nullptr) == (lnb == nullptr)) {
-        // runs of 32 frames when that still yields >= 1024 workgroups, else 16 (every run re-reads ksize - 1 frames of warm-up)
-        const int run = ((long long)B * ceil_div(T, 32) >= 1024) ? 32 : 16;
-        const int rpc = (int)ceil_div(T, run);
-        const dim3 g((unsigned)((long long)B * rpc)), blk((unsigned)(64 * ceil_div(C, 256)));
-        if (lnw) hipLaunchKernelGGL(dwconv_run_kernel<true>, g, blk, 0, s, x, w_kc, bias, lnw, lnb, y, T, C, ksize, eps, pad, run, rpc);
-        else hipLaunchKernelGGL(dwconv_run_kernel<false>, g, blk, 0, s, x, w_kc, bias, lnw, lnb, y, T, C, ksize, eps, pad, run, rpc);
-        QA_LAUNCH_CHECK();
-        return QA_OK;
-    }
     if (lnw)
         hipLaunchKernelGGL(dwconv_kernel<true>, dim3(grid), dim3(256), 0, s, x, w_kc, bias, lnw, lnb, y, B, T, C, ksize,
                            eps, pad);
