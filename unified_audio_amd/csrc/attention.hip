@@ -21,6 +21,26 @@
 // which is exactly the k-slot order used for the second product, so P never leaves the registers.
 #include "kernels.h"
 
+#ifdef QA_ATT_TIMING  // tuning builds only (tools/variants.py -DQA_ATT_TIMING=1, read by tools/att_timing.py): shader cycles per phase of the key-tile loop
+__device__ unsigned long long g_qa_att_timing[8];  // [0] barriers + LDS stores (incl. the wait for the prefetched tile), [1] S = K Q^T, [2] softmax, [3] O += V P, [4] whole kernel, [5] waves, [6] tiles
+#define QA_ATT_TICK(i)                                      \
+    {                                                       \
+        const long long now_ = __builtin_readcyclecounter(); \
+        tacc[i] += now_ - tlast;                            \
+        tlast = now_;                                       \
+    }
+extern "C" int qa_debug_att_timing(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qa_att_timing), sizeof(g_qa_att_timing)) != hipSuccess) return -1;  // out[8]
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_qa_att_timing), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define QA_ATT_TICK(i)
+#endif
+
 namespace qa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -126,8 +146,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
             vreg[j] = *reinterpret_cast<const f32x4*>(vb + (long long)key * ldkv + c4);
         }
     };
+#ifdef QA_ATT_TIMING
+    long long tacc[4] = {0, 0, 0, 0};
+    long long tlast = __builtin_readcyclecounter();
+    const long long tbegin = tlast;
+    long long n_done = 0;
+#endif
     fetch(kt0);
     for (int kt = kt0; kt < n_tiles; ++kt) {
+        QA_ATT_TICK(3)  // (the tail of the previous tile's PV phase; the first time: the Q prologue, negligible)
         __syncthreads();  // the previous tile is no longer read
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
@@ -139,6 +166,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
         __syncthreads();
         if (kt + 1 < n_tiles) fetch(kt + 1);
         if (dbg & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        QA_ATT_TICK(0)
         // wave-uniform skips: the whole tile is masked for this wave, or the wave owns no query at all (the last query block of a
         // sequence that is not a multiple of 128: at N = 283 three of the four waves of block 3 would multiply clamped rows)
         if (!(dbg & 8) && (kt * 32 > wave_last_key || kt * 32 + 31 < wave_first_key || q_blk0 + wave * 32 >= n_q)) continue;
@@ -156,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * g + 2], s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * g + 3], s, 0, 0, 0);
         }
+        QA_ATT_TICK(1)
         // online softmax in base 2 (per lane = per query; the two halves of the wave hold interleaved key groups).  Masks are
         // evaluated only on tiles that can contain a hidden key for some query of this wave (wave-uniform test).
         const int q_first = q_blk0 + wave * 32, q_last = q_first + 31;
@@ -201,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
         }
+        QA_ATT_TICK(2)
         // O^T += V^T P^T ; k-slot (step st, half h) <-> key (st&3) + 8*(st>>2) + 4*h
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
@@ -210,7 +240,19 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
             for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * t], s[st], o[t], 0, 0, 0);
         }
         if (dbg & 2) __syncthreads();
+#ifdef QA_ATT_TIMING
+        ++n_done;
+#endif
     }
+#ifdef QA_ATT_TIMING
+    QA_ATT_TICK(3)
+    if (lane == 0) {
+        for (int i = 0; i < 4; ++i) atomicAdd(&g_qa_att_timing[i], (unsigned long long)tacc[i]);
+        atomicAdd(&g_qa_att_timing[4], (unsigned long long)(tlast - tbegin));
+        atomicAdd(&g_qa_att_timing[5], 1ULL);
+        atomicAdd(&g_qa_att_timing[6], (unsigned long long)n_done);
+    }
+#endif
 
     if (qi < n_q) {
         // a query with no visible key (possible in the ring mode: a chunk as long as the ring overwrites everything its first query
