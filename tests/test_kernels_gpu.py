@@ -270,19 +270,3 @@ def test_attention_kernel_long_ragged_sequences_are_exact_and_deterministic(qa_l
     ref = (torch.softmax(q @ k.transpose(2, 3) * hd ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(B, N, d)
     err = rel_err(outs[0], ref)
     assert err < 2e-6, err
-
-
-@pytest.mark.parametrize("B,N,H,hd", [(4, 1500, 24, 64), (3, 283, 8, 64), (2, 250, 12, 64), (2, 500, 8, 128), (2, 333, 4, 96), (2, 97, 4, 32), (1, 5, 2, 64)])
-def test_attention_pipelined_loop_is_bit_identical_to_the_plain_one(qa_lib, gpu_device, knob, B, N, H, hd):
-    """QA_ATT_PIPE2: the scores of tile t + 1 are computed while the softmax of tile t runs (second S accumulator, K one tile ahead of V in
-    LDS).  Same arithmetic in the same order per tile, so every output bit must equal the plain loop's - incl. sequences shorter than one
-    tile, lengths that end inside a tile, and three runs in a row (this kernel's prefetch has been miscompiled once)."""
-    d = H * hd
-    qkv = torch.randn(B, N, 3 * d, generator=torch.Generator().manual_seed(N + hd)).to(gpu_device)
-    knob("QA_ATT_PIPE2", 0)
-    plain = _attention_alone(qa_lib, qkv, H, hd).clone()
-    knob("QA_ATT_PIPE2", 1)
-    outs = [_attention_alone(qa_lib, qkv, H, hd).clone() for _ in range(3)]
-    torch.cuda.synchronize()
-    for o in outs:
-        assert torch.equal(o, plain)

@@ -48,14 +48,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // BIAS: WavLM's gated relative position bias (transformers WavLMAttention.forward): score(i, j) += gate[b, head, i] *
 // relbias[head][clamp(j - i, -R, R) + R]; the bucket function saturates below R, so the clamp is exact.
-// PIPE (QA_ATT_PIPE2, round 4): software-pipelined key-tile loop.  profiles/r04_attention_phase_cycles.txt: the softmax of a tile (~65 vector
-// instructions) takes as long as its 64 MFMAs, because a vector instruction issued beside the co-resident waves' back-to-back MFMAs gets
-// about one issue slot per MFMA.  Here the raw scores of tile t + 1 (S = K Q^T, into a second accumulator; K one tile ahead of V in a
-// double-buffered LDS tile) are computed WHILE the softmax of tile t runs: the MFMA groups and the softmax slices alternate in program
-// order, so the vector instructions sit in the shadow of the SAME wave's MFMAs.  Same arithmetic in the same order per tile: results are
-// bit-identical to the plain loop.
-template <int HD, bool BIAS, bool PIPE = false>
-__global__ __launch_bounds__(256, (PIPE && HD <= 64 ? 3 : 2)) void attention_kernel(const float* __restrict__ q, long long ldq,
+template <int HD, bool BIAS>
+__global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ q, long long ldq,
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         long long ldkv, long long kv_bstride, float* __restrict__ out,
                                                         long long ldo, int n_q, int n_keys, float scale, int causal,
@@ -70,7 +64,7 @@ __global__ __launch_bounds__(256, (PIPE && HD <= 64 ? 3 : 2)) void attention_ker
     constexpr int LD = HD + 4;
     constexpr int DT = HD / 32;
     constexpr int NG = HD / 8;
-    __shared__ __attribute__((aligned(16))) float sK[(PIPE ? 2 : 1) * 32 * LD];
+    __shared__ __attribute__((aligned(16))) float sK[32 * LD];
     __shared__ __attribute__((aligned(16))) float sV[32 * LD];
 
     // `wave` through readfirstlane: every wave-level test below (tile skips, mask tests) is then a SCALAR branch.  As a VGPR value
@@ -137,160 +131,6 @@ __global__ __launch_bounds__(256, (PIPE && HD <= 64 ? 3 : 2)) void attention_ker
     // exec-masked region; with it hipcc (ROCm 7.2) re-used the staging registers while the loads were still in flight for
     // HD = 64 at n_keys = 1500: half of all outputs differed from run to run (tools/diag_attention.py on a build of that form,
     // profiles/r03_attention_determinism.txt).  Caught by the at-size parity test of H-Codec 2.0 (tests/test_at_size_gpu.py).
-    if constexpr (PIPE) {
-        constexpr int NLD = HD / 32;
-        f32x4 kreg[NLD], vreg[NLD];
-        auto fetch_k = [&](int kt) {  // unconditional, rows clamped (see the plain loop's note on exec-masked prefetches)
-#pragma unroll
-            for (int j = 0; j < NLD; ++j) {
-                const int i = tid + 256 * j;
-                const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
-                kreg[j] = *reinterpret_cast<const f32x4*>(kb + (long long)min(kt * 32 + row, n_keys - 1) * ldkv + c4);
-            }
-        };
-        auto fetch_v = [&](int kt) {
-#pragma unroll
-            for (int j = 0; j < NLD; ++j) {
-                const int i = tid + 256 * j;
-                const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
-                vreg[j] = *reinterpret_cast<const f32x4*>(vb + (long long)min(kt * 32 + row, n_keys - 1) * ldkv + c4);
-            }
-        };
-        auto store_k = [&](int buf) {
-#pragma unroll
-            for (int j = 0; j < NLD; ++j) {
-                const int i = tid + 256 * j;
-                const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
-                *reinterpret_cast<f32x4*>(sK + buf * 32 * LD + row * LD + c4) = kreg[j];
-            }
-        };
-        auto store_v = [&]() {
-#pragma unroll
-            for (int j = 0; j < NLD; ++j) {
-                const int i = tid + 256 * j;
-                const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
-                *reinterpret_cast<f32x4*>(sV + row * LD + c4) = vreg[j];
-            }
-        };
-        auto tile_live = [&](int kt) {  // wave-uniform (scalar): the tile is not wholly masked for this wave and the wave owns a query
-            return !(kt * 32 > wave_last_key || kt * 32 + 31 < wave_first_key || q_blk0 + wave * 32 >= n_q);
-        };
-        auto s_group = [&](f32x16& acc, const float* kp, int g) {  // the 4 MFMAs of K fragment g
-            const float4 a = *reinterpret_cast<const float4*>(kp + 8 * g);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * g + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * g + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * g + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * g + 3], acc, 0, 0, 0);
-        };
-        // prologue: K(kt0) -> LDS, S(kt0); then K(kt0 + 1) and V(kt0) -> LDS: the state every iteration starts from
-        fetch_k(kt0);
-        fetch_v(kt0);
-        store_k(kt0 & 1);
-        __syncthreads();
-        fetch_k(kt0 + 1);
-        f32x16 s_cur;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s_cur[r] = 0.f;
-        bool cur_live = tile_live(kt0);
-        {
-            const float* kp = sK + (kt0 & 1) * 32 * LD + ql * LD + 4 * hh;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) s_group(s_cur, kp, g);
-        }
-        store_k((kt0 + 1) & 1);
-        store_v();
-        __syncthreads();
-        fetch_k(kt0 + 2);
-        fetch_v(kt0 + 1);
-        constexpr int EG = NG > 4 ? NG - 4 : 1;         // MFMA groups that carry exponentials
-        constexpr int EPG = (16 + EG - 1) / EG;          // scores per such group
-        for (int kt = kt0; kt < n_tiles; ++kt) {
-            f32x16 s_next;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s_next[r] = 0.f;
-            const float* kp = sK + ((kt + 1) & 1) * 32 * LD + ql * LD + 4 * hh;  // K(kt + 1) (clamped rows past the end: finite, unused)
-            if (cur_live) {
-                // mask / bias of tile kt first (rare outside WavLM), then S(kt + 1) groups alternating with softmax(kt) slices
-                const int q_first = q_blk0 + wave * 32, q_last = q_first + 31;
-                const bool need_mask = (dbg & 16) || ring || kt * 32 + 31 >= n_keys ||
-                                       (lin_causal && (kt * 32 + 31 > q_first + off || (context > 0 && kt * 32 < q_last + off - context + 1)));
-                if (BIAS || need_mask) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        bool ok = key < n_keys;
-                        if (ring) {
-                            const int delta = key - ring_idx;
-                            const int pos = key >= ring_end ? -1 : (delta <= 0 ? ring_end + delta : ring_end + delta - n_keys);
-                            const int dq = q_pos0 + qi - pos;
-                            ok = ok && pos >= 0 && dq >= 0 && dq < context;
-                        } else if (causal) {
-                            ok = ok && key <= qi + off && (context <= 0 || qi + off - key < context);
-                        }
-                        float sc = s_cur[r];
-                        if (BIAS) sc += gate_q * rb[max(-R, min(R, key - qi))];
-                        s_cur[r] = ok ? sc : -INFINITY;
-                    }
-                }
-                float tmax = -INFINITY, m_new = 0.f, m_use = 0.f, alpha = 1.f, psum = 0.f;
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    s_group(s_next, kp, g);
-                    if (g == 0) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s_cur[r]);
-                    }
-                    if (g == 1 || NG == 1) {
-                        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-                        m_new = fmaxf(m_run, tmax);
-                        m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                        alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
-                    }
-                    if (g >= 2 && g < 2 + EG) {
-#pragma unroll
-                        for (int r = (g - 2) * EPG; r < (g - 1) * EPG; ++r)
-                            if (r < 16) {
-                                s_cur[r] = __builtin_amdgcn_exp2f(s_cur[r] - m_use);
-                                psum += s_cur[r];
-                            }
-                    }
-                    if (g == NG - 2) {
-                        psum += __shfl_xor(psum, 32, 64);
-                        l_run = l_run * alpha + psum;
-                        m_run = m_new;
-                    }
-                    if (g == NG - 1) {
-                        if ((dbg & 1) || __any(alpha != 1.f)) {
-#pragma unroll
-                            for (int t = 0; t < DT; ++t)
-#pragma unroll
-                                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // O^T += V^T P^T over tile kt
-#pragma unroll
-                for (int st = 0; st < 16; ++st) {
-                    const int key = (st & 3) + 8 * (st >> 2) + 4 * hh;
-                    const float* vp = sV + key * LD + ql;
-#pragma unroll
-                    for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * t], s_cur[st], o[t], 0, 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int g = 0; g < NG; ++g) s_group(s_next, kp, g);
-            }
-            __syncthreads();      // everybody is done with V(kt) and with K(kt) (read one iteration ago): both buffers are free
-            store_k(kt & 1);      // K(kt + 2)
-            store_v();            // V(kt + 1)
-            __syncthreads();
-            fetch_k(kt + 3);
-            fetch_v(kt + 2);
-            s_cur = s_next;
-            cur_live = kt + 1 < n_tiles && tile_live(kt + 1);
-        }
-    } else {
     constexpr int NLD = HD / 32;  // float4 per thread per operand: 32 keys x HD floats over 256 threads
     // native vector type, NOT float4: with float4 staging arrays hipcc funnels the unconditional loads through ONE temporary register
     // quad into AGPRs for HD >= 96 (global_load; s_waitcnt vmcnt(0); v_accvgpr_write - eight serialized round trips per tile: 110 -> 177 us
@@ -414,7 +254,6 @@ __global__ __launch_bounds__(256, (PIPE && HD <= 64 ? 3 : 2)) void attention_ker
     }
 #endif
 
-    }
     if (qi < n_q) {
         // a query with no visible key (possible in the ring mode: a chunk as long as the ring overwrites everything its first query
         // could see, and the slot at the write cursor is masked) yields 0, as torch >= 2.5's scaled_dot_product_attention does for
@@ -446,18 +285,13 @@ int launch_attention(const float* q, long long ldq, const float* k, const float*
                "attention: gate and relbias come together, for non-causal self-attention");
     dim3 grid((unsigned)ceil_div(n_q, 128), H, B);
     const int dbg = (int)knob(K_ATT_DEBUG);
-    const bool pipe = knob(K_ATT_PIPE2) != 0;
-#define QA_ATT_L(HD, BIAS_, PIPE_, G_, RB_, R_)                                                                                           \
-    hipLaunchKernelGGL((attention_kernel<HD, BIAS_, PIPE_>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, n_keys, \
-                       scale, causal, G_, RB_, R_, context, q_pos0, ring_end, dbg)
-#define QA_ATT(HD)                                                                   \
-    if (gate) {                                                                       \
-        if (pipe) QA_ATT_L(HD, true, true, gate, relbias, R);                         \
-        else QA_ATT_L(HD, true, false, gate, relbias, R);                             \
-    } else {                                                                          \
-        if (pipe) QA_ATT_L(HD, false, true, nullptr, nullptr, 0);                     \
-        else QA_ATT_L(HD, false, false, nullptr, nullptr, 0);                         \
-    }
+#define QA_ATT(HD)                                                                                                          \
+    if (gate)                                                                                                                \
+        hipLaunchKernelGGL((attention_kernel<HD, true>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, \
+                           n_keys, scale, causal, gate, relbias, R, context, q_pos0, ring_end, dbg);                             \
+    else                                                                                                                     \
+        hipLaunchKernelGGL((attention_kernel<HD, false>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, \
+                           n_keys, scale, causal, nullptr, nullptr, 0, context, q_pos0, ring_end, dbg)
     switch (hd) {
         case 32: QA_ATT(32); break;
         case 64: QA_ATT(64); break;
@@ -466,7 +300,6 @@ int launch_attention(const float* q, long long ldq, const float* k, const float*
         default: qa::set_error("attention: head_dim=%d unsupported (32/64/96/128)", hd); return QA_ERR_UNSUPPORTED;
     }
 #undef QA_ATT
-#undef QA_ATT_L
     QA_LAUNCH_CHECK();
     return QA_OK;
 }
