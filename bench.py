@@ -737,6 +737,15 @@ def main():
             # BASELINE configs[3] on ONE GPU is 64 segments: batches above 32 run as concurrent chains of 32 (csrc/lm.cpp)
             log("UniSE LM at 64 segments per GPU (2 concurrent chains): SE and TSE ...")
             extras["unise_lm_b64"] = lm_bench(dev, rank, world, None, 64, reps=1)
+            # configs[2] end to end at the driver's default micro-batch (UniSE(max_segments=64)): the LM's decode step
+            # costs about the same for 16 and for 64 sequences, so the three stages are timed at 64 segments x 5 s as well
+            fe64, bd64 = ssl_bench(dev, "unise", 64, 5.0, reps=2), bicodec_bench(dev, 64, reps=2)
+            st64 = {"wavlm_ms": fe64["ms_per_pass"], "lm_generate_ms": extras["unise_lm_b64"]["ms_per_generate"], "bicodec_detokenize_ms": bd64["ms_per_pass"]}
+            tot64 = sum(st64.values()) * 1e-3
+            extras["unise_end_to_end_b64"] = {"value": 64 * 5.0 / tot64, "unit": "audio-seconds/sec", "ms": 1e3 * tot64, "stages": st64,
+                                              "tokens_per_sec": 64 * 283 / tot64,
+                                              "note": "Model.test_step 'se' on 64 x 5 s segments (the micro-batch unified_audio_amd.UniSE feeds by default), stages timed "
+                                                      "back to back; outputs do not depend on the micro-batch (every stage is batch-invariant)"}
             extras["unise_lm_tse_b64"] = lm_bench(dev, rank, world, None, 64, reps=1, task="tse", n_enroll=250)
         except Exception as e:  # noqa: BLE001
             extras["unise_lm_b64"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
