@@ -270,18 +270,3 @@ def test_attention_kernel_long_ragged_sequences_are_exact_and_deterministic(qa_l
     ref = (torch.softmax(q @ k.transpose(2, 3) * hd ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(B, N, d)
     err = rel_err(outs[0], ref)
     assert err < 2e-6, err
-
-
-@pytest.mark.parametrize("B,N,H,hd", [(4, 1500, 24, 64), (3, 283, 8, 64), (2, 250, 12, 64), (2, 500, 8, 128), (2, 333, 4, 96), (2, 97, 4, 32), (1, 5, 2, 64)])
-def test_attention_with_v_transposed_in_lds_is_bit_identical(qa_lib, gpu_device, knob, B, N, H, hd):
-    """QA_ATT_VT: V sits transposed in LDS so that the PV fragment of four k-steps is one 16-byte read.  Same products in the same order:
-    every output bit must equal the plain layout's, three runs in a row."""
-    d = H * hd
-    qkv = torch.randn(B, N, 3 * d, generator=torch.Generator().manual_seed(N + hd)).to(gpu_device)
-    knob("QA_ATT_VT", 0)
-    plain = _attention_alone(qa_lib, qkv, H, hd).clone()
-    knob("QA_ATT_VT", 1)
-    outs = [_attention_alone(qa_lib, qkv, H, hd).clone() for _ in range(3)]
-    torch.cuda.synchronize()
-    for o in outs:
-        assert torch.equal(o, plain)

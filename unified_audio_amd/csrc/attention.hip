@@ -48,11 +48,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // BIAS: WavLM's gated relative position bias (transformers WavLMAttention.forward): score(i, j) += gate[b, head, i] *
 // relbias[head][clamp(j - i, -R, R) + R]; the bucket function saturates below R, so the clamp is exact.
-// VT (QA_ATT_VT, round 4 experiment): V TRANSPOSED in LDS (sVt[dim][key], row stride 36) so that the A fragment of O^T += V^T P^T for four
-// consecutive k-steps is ONE ds_read_b128 (8 reads per tile at head_dim 64 instead of 16 ds_read2_b32, each waited for in front of an MFMA
-// pair: profiles/r04_attention_phase_cycles.txt); the price is scalar, 8-way bank-conflicting LDS stores.  Same products in the same order:
-// bit-identical results.
-template <int HD, bool BIAS, bool VT = false>
+template <int HD, bool BIAS>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ q, long long ldq,
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         long long ldkv, long long kv_bstride, float* __restrict__ out,
@@ -69,8 +65,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
     constexpr int DT = HD / 32;
     constexpr int NG = HD / 8;
     __shared__ __attribute__((aligned(16))) float sK[32 * LD];
-    constexpr int LDT = 36;  // VT: keys per transposed row + pad (36 = 4 mod 32: conflict-free 16-byte fragment reads)
-    __shared__ __attribute__((aligned(16))) float sV[VT ? HD * LDT : 32 * LD];
+    __shared__ __attribute__((aligned(16))) float sV[32 * LD];
 
     // `wave` through readfirstlane: every wave-level test below (tile skips, mask tests) is then a SCALAR branch.  As a VGPR value
     // hipcc lowers them to exec-masked regions, and exec-masked VMEM next to register-staged prefetches is where ROCm 7.2 mis-tracks
@@ -166,14 +161,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
             const int i = tid + 256 * j;
             const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
             *reinterpret_cast<f32x4*>(sK + row * LD + c4) = kreg[j];
-            if (VT) {
-                sV[(c4 + 0) * LDT + row] = vreg[j].x;
-                sV[(c4 + 1) * LDT + row] = vreg[j].y;
-                sV[(c4 + 2) * LDT + row] = vreg[j].z;
-                sV[(c4 + 3) * LDT + row] = vreg[j].w;
-            } else {
-                *reinterpret_cast<f32x4*>(sV + row * LD + c4) = vreg[j];
-            }
+            *reinterpret_cast<f32x4*>(sV + row * LD + c4) = vreg[j];
         }
         __syncthreads();
         if (kt + 1 < n_tiles) fetch(kt + 1);
@@ -244,25 +232,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
         }
         QA_ATT_TICK(2)
         // O^T += V^T P^T ; k-slot (step st, half h) <-> key (st&3) + 8*(st>>2) + 4*h
-        if (VT) {
 #pragma unroll
-            for (int j4 = 0; j4 < 4; ++j4) {  // k-steps 4 j4 .. 4 j4 + 3 <-> keys 8 j4 + 4 hh + {0, 1, 2, 3}: contiguous in a transposed row
-                f32x4 vv[DT];
+        for (int st = 0; st < 16; ++st) {
+            const int key = (st & 3) + 8 * (st >> 2) + 4 * hh;
+            const float* vp = sV + key * LD + ql;
 #pragma unroll
-                for (int t = 0; t < DT; ++t) vv[t] = *reinterpret_cast<const f32x4*>(sV + (32 * t + ql) * LDT + 8 * j4 + 4 * hh);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[t][e], s[4 * j4 + e], o[t], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int st = 0; st < 16; ++st) {
-                const int key = (st & 3) + 8 * (st >> 2) + 4 * hh;
-                const float* vp = sV + key * LD + ql;
-#pragma unroll
-                for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * t], s[st], o[t], 0, 0, 0);
-            }
+            for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * t], s[st], o[t], 0, 0, 0);
         }
         if (dbg & 2) __syncthreads();
 #ifdef QA_ATT_TIMING
@@ -310,18 +285,13 @@ int launch_attention(const float* q, long long ldq, const float* k, const float*
                "attention: gate and relbias come together, for non-causal self-attention");
     dim3 grid((unsigned)ceil_div(n_q, 128), H, B);
     const int dbg = (int)knob(K_ATT_DEBUG);
-    const bool vt = knob(K_ATT_VT) != 0;
-#define QA_ATT_L(HD, BIAS_, VT_, G_, RB_, R_)                                                                                            \
-    hipLaunchKernelGGL((attention_kernel<HD, BIAS_, VT_>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, n_keys, \
-                       scale, causal, G_, RB_, R_, context, q_pos0, ring_end, dbg)
-#define QA_ATT(HD)                                                                   \
-    if (gate) {                                                                       \
-        if (vt) QA_ATT_L(HD, true, true, gate, relbias, R);                           \
-        else QA_ATT_L(HD, true, false, gate, relbias, R);                             \
-    } else {                                                                          \
-        if (vt) QA_ATT_L(HD, false, true, nullptr, nullptr, 0);                       \
-        else QA_ATT_L(HD, false, false, nullptr, nullptr, 0);                         \
-    }
+#define QA_ATT(HD)                                                                                                          \
+    if (gate)                                                                                                                \
+        hipLaunchKernelGGL((attention_kernel<HD, true>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, \
+                           n_keys, scale, causal, gate, relbias, R, context, q_pos0, ring_end, dbg);                             \
+    else                                                                                                                     \
+        hipLaunchKernelGGL((attention_kernel<HD, false>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, \
+                           n_keys, scale, causal, nullptr, nullptr, 0, context, q_pos0, ring_end, dbg)
     switch (hd) {
         case 32: QA_ATT(32); break;
         case 64: QA_ATT(64); break;
@@ -330,7 +300,6 @@ int launch_attention(const float* q, long long ldq, const float* k, const float*
         default: qa::set_error("attention: head_dim=%d unsupported (32/64/96/128)", hd); return QA_ERR_UNSUPPORTED;
     }
 #undef QA_ATT
-#undef QA_ATT_L
     QA_LAUNCH_CHECK();
     return QA_OK;
 }

@@ -19,7 +19,6 @@ namespace qa {
     X(GEMM_PANEL, "QA_GEMM_PANEL", 8, "conv_gemm tile order: column panels of this many tiles, row tiles fastest inside a panel (0: column tiles fastest over the whole row; 8: +4 % on N >= 4096 shapes, +1.2 % on H-Codec 2.0)") \
     X(GEMM_GROUPED, "QA_GEMM_GROUPED", 0, "H-Codec 1.5: 1 = the two aggregator stacks as ONE grouped launch per layer op on one stream (measured: 147.1 ms against 143.5 for the default, the two stacks on two streams)") \
     X(ATT_DEBUG, "QA_ATT_DEBUG", 0, "attention_kernel debug bits: 1 always rescale, 2 extra barrier per tile, 4 wait for the prefetch at once") \
-    X(ATT_VT, "QA_ATT_VT", 0, "attention_kernel: 1 = V transposed in LDS (16-byte fragment reads for the PV products, scalar stores; bit-identical results)") \
     X(SEANET_FUSED, "QA_SEANET_FUSED", 1, "fused conv0 + first SEANet residual block")                                           \
     X(MIMI_ROPE_WINDOW, "QA_MIMI_ROPE_WINDOW", 8192, "mimi streaming: positions covered by the RoPE table before the rolling window takes over (tests shrink it)") \
     X(RVQ_LEGACY, "QA_RVQ_LEGACY", 0, "1: the single-launch RVQ search kernel instead of distance GEMM + pick")                   \
