@@ -1,6 +1,8 @@
 """Shape fuzzing of the implicit-GEMM Conv1d and the RVQ search through the C-ABI (hypothesis-driven shapes
 on top of the hand-picked edge cases of tests/test_kernels_gpu.py).  Every draw is checked against torch's own convolution on the CPU
 (the reference's op) / the plain-C RVQ oracle; the seeds are derandomised so a failure reproduces."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -13,7 +15,11 @@ from oracle import rvq_c
 from tests.util import act_ref, conv1d_cl, rel_err
 
 pytestmark = pytest.mark.gpu
-FUZZ = settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+# QA_FUZZ_EXAMPLES / QA_FUZZ_RANDOM widen a run by hand (e.g. under QA_GEMM_CFG=3 / 4 to drive every example through the 64-row tiles); the suite's
+# default is the fixed, derandomised set
+_N = int(os.environ.get("QA_FUZZ_EXAMPLES", "0"))
+_DERAND = not os.environ.get("QA_FUZZ_RANDOM")
+FUZZ = settings(max_examples=_N or 60, deadline=None, derandomize=_DERAND, suppress_health_check=list(HealthCheck))
 
 
 @st.composite
@@ -82,7 +88,7 @@ def test_conv1d_cl_fuzz(qa_lib, gpu_device, case):
     assert rel_err(y, ref) < 3e-6, case
 
 
-@settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=_N or 25, deadline=None, derandomize=_DERAND, suppress_health_check=list(HealthCheck))
 @given(n=st.integers(1, 1500), Q=st.integers(1, 6), K=st.sampled_from([1, 7, 32, 64, 100, 256, 1024]), D=st.sampled_from([8, 32, 64, 96, 128, 512]),
        seed=st.integers(0, 2 ** 16))
 def test_rvq_search_fuzz(qa_lib, gpu_device, n, Q, K, D, seed):
@@ -108,7 +114,7 @@ def test_rvq_search_fuzz(qa_lib, gpu_device, n, Q, K, D, seed):
     np.testing.assert_allclose(quant.cpu().numpy(), rvq_c.lookup_f32(got, cb), rtol=0, atol=1e-5)
 
 
-@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=_N or 30, deadline=None, derandomize=_DERAND, suppress_health_check=list(HealthCheck))
 @given(hd=st.sampled_from([32, 64, 96, 128]), heads=st.integers(1, 3), B=st.integers(1, 3), T=st.integers(1, 300), causal=st.booleans(),
        ctx=st.integers(0, 320), seed=st.integers(0, 2 ** 16))
 def test_mimi_attention_windows_fuzz(qa_lib, gpu_device, hd, heads, B, T, causal, ctx, seed):
@@ -129,7 +135,7 @@ def test_mimi_attention_windows_fuzz(qa_lib, gpu_device, hd, heads, B, T, causal
     assert rel_err(y, ref) < 5e-5, (hd, heads, B, T, causal, ctx)
 
 
-@settings(max_examples=20, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=_N or 20, deadline=None, derandomize=_DERAND, suppress_health_check=list(HealthCheck))
 @given(hd=st.sampled_from([32, 64]), ctx=st.integers(2, 24), chunks=st.lists(st.integers(1, 24), min_size=1, max_size=12), seed=st.integers(0, 2 ** 16))
 def test_mimi_streaming_fuzz(qa_lib, gpu_device, hd, ctx, chunks, seed):
     """Random chunk partitions against the oracle's RingKVCache restatement (pinned to the reference's module): ring wrap-around at any
