@@ -215,8 +215,9 @@ def run_sharded_ragged(fn: Callable[[List[torch.Tensor]], Sequence[torch.Tensor]
         local = [utterances[i].reshape(-1).to(device) for i in mine]
     else:
         packed = torch.empty(sum(lengths[i] for i in mine), dtype=dtype, device=device)
-        if mine:
-            dist.recv(packed, src=_peer(group, src), group=group)
+        if mine:  # batched on BOTH ends: an unbatched recv against the root's batched isend would, under a lazily
+            # initialised ProcessGroupNCCL, open a 2-rank communicator the root never joins
+            _exchange([dist.P2POp(dist.irecv, packed, _peer(group, src), group)])
         local, at = [], 0
         for i in mine:
             local.append(packed[at:at + lengths[i]])
@@ -236,7 +237,7 @@ def run_sharded_ragged(fn: Callable[[List[torch.Tensor]], Sequence[torch.Tensor]
     dist.all_gather_object(meta, ([int(o.numel()) for o in outs], outs[0].dtype if outs else None), group=group)
     if rank != src:
         if outs:
-            dist.send(_pack(outs, device, outs[0].dtype), dst=_peer(group, src), group=group)
+            _exchange([dist.P2POp(dist.isend, _pack(outs, device, outs[0].dtype), _peer(group, src), group)])
         return None
     result: List[Optional[torch.Tensor]] = [None] * len(lengths)
     bufs = {r: torch.empty(sum(meta[r][0]), dtype=meta[r][1], device=device) for r in range(world) if r != src and meta[r][0]}
