@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--lm-batch", type=int, default=16, help="UniSE segments per GPU (BASELINE configs[2]: batch=16)")
     ap.add_argument("--no-extras", action="store_true", help="skip the widened secondaries (H-Codec 2.0 share of configs[4], TSE share of "
                                                                "configs[3], second grouping point, LM CPU baseline)")
+    ap.add_argument("--no-multi-configs", action="store_true", help="N > 1: skip the configs[3] (TSE, 8 segments per GPU) and configs[4] (H-Codec 2.0, "
+                                                                     "16 x 30 s per GPU) legs (`configs3_tse` / `configs4_hcodec20` objects of the line)")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--bootstrap-selftest", action="store_true",
                     help="tests/test_bench_bootstrap_cpu.py: run ONLY the rank bootstrap (self-launch, rendezvous), the ranks_seen all-gather and the "
@@ -502,6 +504,46 @@ def exchange_leg(dist, rank, world, dev, hot_path, make_inputs, n_inputs, pad_va
     return exchange, res
 
 
+def sharded_config_leg(dist, rank, world, dev, hot_path, make_local, units_per_rank, unit, pad_values, fence, reps, workload, config_ref):
+    """One multi-GPU BASELINE configuration at N > 1: every rank runs `hot_path` on ITS OWN share of the
+    configuration (inputs resident, barrier + device fence on both sides, MAX over ranks) -> `value` = the units all ranks processed per
+    second; beside it - never inside it - the exchange step of that configuration (rank 0 holds every rank's share, run_sharded scatters
+    it, runs the same hot path, gathers the results; rank 0's block is checked against its own local run).  make_local(r) -> rank r's
+    input tensors [n_r, ...] (seeded by r, so rank 0 can rebuild everybody's share for the scatter)."""
+    local = [t.to(dev) for t in make_local(rank)]
+    hot_path(*local)  # warm-up (workspace growth, graphs)
+    best = float("inf")
+    for _ in range(reps):
+        fence()
+        t0 = time.perf_counter()
+        own = hot_path(*local)
+        fence()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        best = min(best, float(t.item()))
+    leg = {"value": world * units_per_rank / best, "unit": unit, "ms_per_step": 1e3 * best, "n_gpus": world, "scaling": "weak",
+           "timing": "barrier + device fence on both sides, max over ranks, best of %d" % reps,
+           "config": {"workload": workload, "baseline_config": config_ref, "parallelism": f"dp{world} (independent items, no collective)", "dtype": "f32"}}
+    try:
+        def make_inputs():
+            shares = [make_local(r) for r in range(world)]
+            return [torch.cat([sh[i] for sh in shares]).to(dev) for i in range(len(shares[0]))]
+
+        n_in = len(local)
+        sbytes = world * sum(t.numel() * t.element_size() for t in local)
+        exchange, res = exchange_leg(dist, rank, world, dev, hot_path, make_inputs, n_in, pad_values, fence, sbytes)
+        if rank == 0:
+            n0 = local[0].shape[0]
+            exchange["gathered_shapes"] = [list(r_.shape) for r_ in res]
+            exchange["rank0_block_matches_local_run"] = bool(all(
+                torch.equal(g[:n0][tuple(slice(None) if i == 0 else slice(0, e) for i, e in enumerate(o.shape))], o) for g, o in zip(res, own)))
+        leg["exchange"] = exchange
+    except Exception as e:  # noqa: BLE001
+        leg["exchange"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+    return leg
+
+
 def bootstrap_selftest(args):
     """--bootstrap-selftest: everything of an N > 1 bench run that is NOT the codec - launch, rendezvous, ranks_seen, the exchange leg,
     the max-over-ranks reduction, one JSON line from rank 0 - on gloo with a stub hot path (a fixed affine map of the clips, so the
@@ -536,6 +578,21 @@ def bootstrap_selftest(args):
             exchange["gathered_shapes"] = [list(r_.shape) for r_ in res]
             exchange["gathered_equals_unsharded_run"] = bool(all(torch.equal(a, b) for a, b in zip(res, want)))
         line["ranks_seen"], line["exchange"] = ranks_seen, exchange
+        # the two multi-GPU BASELINE configurations' legs (configs[3] TSE share, configs[4] H-Codec 2.0 share) through the SAME code path
+        # bench.py uses at N > 1, with stub hot paths of the real signatures: (mix, enrollment) -> (global ids, semantic ids) and
+        # (wav, features) -> (acoustic codes, semantic codes, waveform)
+        def tse_stub(mix, enr):
+            return (mix[:, :4, 0] * 8 + enr[:, :4, 0]).to(torch.int64), (mix[:, :, 1] * 4).to(torch.int64)
+
+        def codec_stub(w, f):
+            return (w[:, ::16] * 4).to(torch.int64)[:, None, :], (f[:, :, 0] * 4).to(torch.int64)[:, None, :], w * 0.5
+
+        line["configs3_tse"] = sharded_config_leg(
+            dist, rank, world, dev, tse_stub, lambda r: [clips_of(r).reshape(B, 16, 4), clips_of(r).reshape(B, 16, 4) + 0.5], B * 6, "tokens/sec",
+            None, fence, 1, "stub hot path (self-test)", "configs[3]")
+        line["configs4_hcodec20"] = sharded_config_leg(
+            dist, rank, world, dev, codec_stub, lambda r: [clips_of(r), clips_of(r).reshape(B, 16, 4)], B * T / 48000.0, "audio-seconds/sec",
+            None, fence, 1, "stub hot path (self-test)", "configs[4]")
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
@@ -701,6 +758,49 @@ def main():
         log("UniSE LM generate ...")
         lm_line = lm_bench(dev, rank, world, dist, args.lm_batch)
 
+    # N > 1: the two BASELINE configurations that ARE multi-GPU - configs[3] (UniSE TSE with enrollment, 64 mixed segments over 8 GPUs = 8
+    # per GPU; the enrollment travels with its segment, model.py:209-210) and configs[4] (H-Codec 2.0, 128 x 30 s over 8 GPUs = 16 per
+    # GPU) - every rank its own share, max over ranks, each with its own exchange block
+    multi = {}
+    if dist is not None and not args.lean and not args.no_extras and not args.no_multi_configs:
+        if not args.no_lm:
+            try:
+                log("configs[3]: TSE share, 8 segments per GPU ...")
+                lm3 = qa.LLM_SFT(device=dev).load_state_dict(synth.lm_state_dict(4321))
+                mel3 = torch.zeros(1, 250, 80)
+
+                def tse_path(mix, enr):
+                    n_ = mix.shape[0]
+                    return lm3.generate("tse", mel3.expand(n_, -1, -1), enr, mel3.expand(n_, -1, -1), mix, do_sample=False)
+
+                multi["configs3_tse"] = sharded_config_leg(
+                    dist, rank, world, dev, tse_path, lambda r: [synth.synth_feats(50 + r, 8, 250), synth.synth_feats(90 + r, 8, 250)], 8 * 283,
+                    "tokens/sec", None, fence, 2, "LLM_SFT.generate TSE task (greedy, prefill included), 8 segments x 5 s per GPU, prompt 503 "
+                    "(mixture 250 + enrollment 250 + 3), 33 global + 250 semantic steps; enrollment features scattered with their segment",
+                    "configs[3]: UniSE TSE, batch 64 over 8 GPUs")
+                del lm3
+            except Exception as e:  # noqa: BLE001
+                multi["configs3_tse"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        try:
+            log("configs[4]: H-Codec 2.0 share, 16 x 30 s per GPU ...")
+            spec20m = synth.Shapes20()
+            codec20m = qa.Codec(None, None, None, spec=qa.SPEC_20, device=dev).load_state_dict(synth.hcodec20_state_dict(1234, spec20m))
+            B20m, T20m = 16, 30 * 48000 // spec20m.frame_hop * spec20m.frame_hop
+
+            def h20_path(w, f):
+                a_, s_ = codec20m.encode(w, f)
+                return a_, s_, codec20m.decode(a_, s_)
+
+            multi["configs4_hcodec20"] = sharded_config_leg(
+                dist, rank, world, dev, h20_path,
+                lambda r: [synth.synth_wav_fullband(17 + r, B20m, T20m), synth.synth_feat(19 + r, B20m, T20m // spec20m.hop, 768)],
+                B20m * T20m / 48000.0, "audio-seconds/sec", None, fence, 2,
+                f"H-Codec 2.0 Codec.encode+Codec.decode (1.17 G parameters), 16 clips x {T20m / 48000:.0f} s @48 kHz per GPU, 16 + 16 codebooks, SSL features precomputed",
+                "configs[4]: H-Codec 2.0, 128 x 30 s over 8 GPUs")
+            del codec20m
+        except Exception as e:  # noqa: BLE001
+            multi["configs4_hcodec20"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+
     extras = {}
     if rank == 0 and world == 1 and not args.lean and not args.no_extras and args.model == "1.5":
         try:
@@ -737,6 +837,9 @@ def main():
             # BASELINE configs[3] on ONE GPU is 64 segments: batches above 32 run as concurrent chains of 32 (csrc/lm.cpp)
             log("UniSE LM at 64 segments per GPU (2 concurrent chains): SE and TSE ...")
             extras["unise_lm_b64"] = lm_bench(dev, rank, world, None, 64, reps=1)
+        except Exception as e:  # noqa: BLE001
+            extras["unise_lm_b64"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        try:  # its own try: a failure of the 64-segment front-end / detokenizer must not overwrite the LM result above
             # configs[2] end to end at the driver's default micro-batch (UniSE(max_segments=64)): the LM's decode step
             # costs about the same for 16 and for 64 sequences, so the three stages are timed at 64 segments x 5 s as well
             fe64, bd64 = ssl_bench(dev, "unise", 64, 5.0, reps=2), bicodec_bench(dev, 64, reps=2)
@@ -746,9 +849,12 @@ def main():
                                               "tokens_per_sec": 64 * 283 / tot64,
                                               "note": "Model.test_step 'se' on 64 x 5 s segments (the micro-batch unified_audio_amd.UniSE feeds by default), stages timed "
                                                       "back to back; outputs do not depend on the micro-batch (every stage is batch-invariant)"}
+        except Exception as e:  # noqa: BLE001
+            extras["unise_end_to_end_b64"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        try:
             extras["unise_lm_tse_b64"] = lm_bench(dev, rank, world, None, 64, reps=1, task="tse", n_enroll=250)
         except Exception as e:  # noqa: BLE001
-            extras["unise_lm_b64"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            extras["unise_lm_tse_b64"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
 
     if rank == 0 and world == 1 and not args.lean and not args.no_extras and args.model == "1.5":
         try:
@@ -854,6 +960,7 @@ def main():
                         traffic_src = pmc.get("_source", "profiles/") + " (2*FETCH_SIZE + WRITE_SIZE, per launch; rocprofv3 --pmc passes of this command)"
                         mfma_busy = v["mfma_busy_frac"]
         gemm_ms = sum(prof[4 * i + 1] for i in range(len(CFG_NAMES)))
+        gemm_flop = sum(prof[4 * i] for i in range(len(CFG_NAMES)))
         line = {
             "metric": "audio-seconds/sec H-Codec encode+decode @16kHz b=32",
             "value": audio_s / elapsed,
@@ -877,9 +984,14 @@ def main():
                          "traffic_algorithmic": dom["algorithmic_bytes_per_launch"], "flop_per_launch": dom["flop_per_launch"],
                          "mfma_busy_frac_pmc": mfma_busy,
                          "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
-                         "gemm_share_of_step_time": gemm_ms * 1e-3 / elapsed, "all_gemm_configs": cfgs,
+                         "gemm_launch_time_over_step_time_overlapping_streams": gemm_ms * 1e-3 / elapsed,
+                         "whole_step": {"tflops": gemm_flop / elapsed / 1e12, "frac": gemm_flop / elapsed / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                        "gemm_tflop_per_step": gemm_flop / args.steps / 1e12,
+                                        "note": "ALL conv_gemm FLOPs of the timed region / its wall time (recurrences, attention, norms, host gaps in the "
+                                                "denominator): the whole step against the nominal fp32 matrix peak"},
+                         "all_gemm_configs": cfgs,
                          "note": "live HIP events in the timed region; kernels on the library's concurrent internal streams share the "
-                                 "CUs, so their durations overlap (shares can sum past 1). `isolated` = the same kernel with "
+                                 "CUs, so their durations overlap (shares - and gemm_launch_time_over_step_time_overlapping_streams, the SUM of launch durations over wall time - can pass 1). `isolated` = the same kernel with "
                                  "qa_set_serial(1), alone on the device (what rocprofv3 under QA_SERIAL=1 reports)"},
         }
         if hbm_rows:
@@ -931,6 +1043,8 @@ def main():
             line["ranks_seen"] = ranks_seen
         if exchange is not None:
             line["exchange"] = exchange
+        for k_, v_ in multi.items():  # configs3_tse / configs4_hcodec20 (N > 1 only), beside `value`
+            line[k_] = v_
         if extras:
             line["extras"] = extras
         if ssl_line is not None:

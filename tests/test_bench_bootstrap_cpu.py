@@ -30,6 +30,17 @@ def _check_selftest_line(line, world):
     assert ex["gathered_shapes"] == [[3 * world, 8], [3 * world, 64]]
     assert ex["exchange_ms"] == pytest.approx(ex["scatter_ms"] + ex["gather_ms"])
     assert line["max_over_ranks"] == float(world)
+    # the two multi-GPU BASELINE configurations have their own objects in an N > 1 line (here through the stub hot paths
+    # of the real signatures): whole-job value over all ranks, weak scaling, and an exchange block whose rank-0 rows equal rank 0's own run
+    for key, unit, n_out in (("configs3_tse", "tokens/sec", 2), ("configs4_hcodec20", "audio-seconds/sec", 3)):
+        leg = line[key]
+        assert leg["unit"] == unit and leg["n_gpus"] == world and leg["scaling"] == "weak" and leg["value"] > 0 and leg["ms_per_step"] > 0
+        assert leg["config"]["baseline_config"].startswith("configs[")
+        lx = leg["exchange"]
+        assert "error" not in lx, lx
+        assert lx["rank0_block_matches_local_run"] is True
+        assert len(lx["gathered_shapes"]) == n_out and all(sh[0] == 3 * world for sh in lx["gathered_shapes"])
+        assert lx["exchange_ms"] == pytest.approx(lx["scatter_ms"] + lx["gather_ms"])
 
 
 def test_plain_command_self_launches_one_rank_per_gpu():
