@@ -315,7 +315,7 @@ def test_batches_above_32_run_as_concurrent_chains(qa_lib, gpu_device, knob):
         g1, s1 = lm.generate("tse", mel[i:i + 1], enr[i:i + 1].to(gpu_device), mel[i:i + 1], mix[i:i + 1].to(gpu_device), global_length=G,
                              do_sample=False)
         assert torch.equal(g1[0], g[i]) and torch.equal(s1[0], s[i]), i
-    for chains in (1, 4, 40):  # 1: one chain of 40 does not tile the fused step -> the per-op path; 40: one sequence per chain is capped at 16 chains
+    for chains in (1, 2, 4, 40):  # 1 (= the default since r05): ONE chain, two row groups per launch; 2: two chains of 20; 40: one sequence per chain is capped at 16 chains
         knob("QA_LM_CHAINS", chains)
         g2, s2 = lm.generate("tse", mel, enr.to(gpu_device), mel, mix.to(gpu_device), global_length=G, do_sample=False)
         assert torch.equal(g2, g) and torch.equal(s2, s), chains
@@ -324,17 +324,23 @@ def test_batches_above_32_run_as_concurrent_chains(qa_lib, gpu_device, knob):
     assert torch.equal(g3, g) and torch.equal(s3, s)
 
 
-def test_chains_full_width_b64_matches_b16_chunks(qa_lib, gpu_device):
-    """Full UniSE width, 64 segments (2 chains x 32): every 16-sequence chunk of the call equals the same chunk generated alone."""
+@pytest.mark.parametrize("B", [64, 80, 33])
+def test_chains_full_width_b64_matches_b16_chunks(qa_lib, gpu_device, B):
+    """Full UniSE width.  64 segments = ONE chain whose launches carry two row groups of 32 (r05; two chains of 32 before); 80 = two
+    chains of 40 (two row groups each, the second group 8 rows); 33 = one chain with a one-row second group: every 16-sequence chunk of
+    the call equals the same chunk generated alone."""
     spec = L.SPEC_UNISE
     _, lm = _model(spec, 33, gpu_device)
-    B, Nm, S = 64, 40, 24
+    Nm, S = 40, 24
     mix = L.synth_feats(9, B, Nm).to(gpu_device)
     mel = torch.zeros(B, S, 80)
     g, s = lm.generate("se", None, None, mel, mix, do_sample=False)
-    for b0 in (0, 16, 48):
+    for b0 in (0, 16, 48) if B >= 64 else (0, 17):
         g1, s1 = lm.generate("se", None, None, mel[b0:b0 + 16], mix[b0:b0 + 16], do_sample=False)
         assert torch.equal(g1, g[b0:b0 + 16]) and torch.equal(s1, s[b0:b0 + 16]), b0
+    if B > 64:  # the tail of the second chain's second row group
+        g1, s1 = lm.generate("se", None, None, mel[B - 5:], mix[B - 5:], do_sample=False)
+        assert torch.equal(g1, g[B - 5:]) and torch.equal(s1, s[B - 5:])
 
 
 def test_sampled_chains_key_the_rng_by_the_global_sequence_index(qa_lib, gpu_device, knob):
@@ -355,7 +361,7 @@ def test_sampled_chains_key_the_rng_by_the_global_sequence_index(qa_lib, gpu_dev
 
 
 def test_config4_on_one_gpu_64_tse_segments_match_the_reference_golden(qa_lib, gpu_device):
-    """BASELINE configs[3] placed on ONE GPU: 64 TSE segments (prompt 503, KV 786) = two concurrent chains of 32.  The batch is the
+    """BASELINE configs[3] placed on ONE GPU: 64 TSE segments (prompt 503, KV 786) = one chain, two row groups of 32 per launch (r05; two concurrent chains of 32 before).  The batch is the
     reference-golden case `lm_config4_tse_b8` eight times over, so every block of 8 sequences must reproduce the token stream the
     reference's own LLM_SFT.generate produced (smallest top-2 gap of the golden 3.2e-4: no near-tie, the streams must be identical)."""
     import os

@@ -410,7 +410,7 @@ uint64_t mix_key(uint64_t h, uint64_t v) {
 // device memory - one more dependent load per kernel - and cannot size the attention grid to the current key count: off by default.
 bool use_graphs() { return knob(K_LM_GRAPH) != 0; }
 
-// One chain = one batch of <= 32 sequences with its own buffers, KV cache and (for B > 32, or QA_LM_CHAINS) its own internal stream.
+// One chain = one batch of <= 64 sequences (LM_MAX_ROWS) with its own buffers, KV cache and (for B > 32, or QA_LM_CHAINS) its own internal stream.
 struct Chain {
     int b0 = 0, B = 0;  // sequences [b0, b0 + B) of the call
     LMBuffers b{};
@@ -438,7 +438,7 @@ int chain_alloc(qa_lm* lm, Ctx& c, Chain& ch, int L, int cap, int G, int S, int 
     b.tok = c.arena.alloc<long long>(B);
     b.q = c.arena.alloc<float>((size_t)B * d);
     b.att_part = c.arena.alloc<float>((size_t)B * H * b.S_att * (d / H + 4));
-    b.mlp_part = c.arena.alloc<float>(lm->mlp_fused ? (size_t)(I / lm->mlp_ac) * 32 * d : 0);
+    b.mlp_part = c.arena.alloc<float>(lm->mlp_fused ? (size_t)(I / lm->mlp_ac) * 32 * ceil_div(B, 32) * d : 0);  // [row group][I / ac][32][d]
     b.pmax = c.arena.alloc<float>((size_t)B * (wmax / 4 + 1));
     b.pidx = c.arena.alloc<int>((size_t)B * (wmax / 4 + 1));
     b.state = c.arena.alloc<int>(ST_WORDS);
@@ -449,7 +449,9 @@ int chain_alloc(qa_lm* lm, Ctx& c, Chain& ch, int L, int cap, int G, int S, int 
     return QA_OK;
 }
 
-// Batches of more than 32 sequences (the fused step's GEMVs hold at most two 16-row tiles) run as ceil(B / 32) independent CHAINS
+// r05: up to 64 sequences are ONE chain - every GEMV / fused-MLP launch of the step carries two row groups of 32 (gridDim.y, lm_decode.hip
+// row_group), so the step streams the 217 MB of weights once and issues 50 launches where two chains of 32 issued 100.
+// Batches of more than 64 sequences run as ceil(B / 64) independent CHAINS
 // on internal streams: a decode step is bound by the latency of its ~62 dependent launches and leaves the device almost idle
 // (DESIGN.md section 11), so chains overlap nearly for free - tokens/s scales with the number of chains until the CUs fill.  Every
 // chain replays ONE captured step per token (hipGraph), round-robin over the chains, so the host issues two graph launches per
@@ -472,12 +474,12 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
     }
     const bool capturing = cap_status == hipStreamCaptureStatusActive;
     int nc = (int)knob(K_LM_CHAINS);
-    if (nc <= 0) nc = tiles ? (int)ceil_div(B, 32) : 1;
+    if (nc <= 0) nc = tiles ? (int)ceil_div(B, LM_MAX_ROWS) : 1;  // r05: one chain serves up to 64 sequences (two row groups per launch)
     if (capturing) nc = 1;
     nc = std::max(1, std::min(std::min(nc, B), LM_MAX_CHAINS));
     const int cb = (int)ceil_div(B, nc);
     nc = (int)ceil_div(B, cb);
-    const bool fused = tiles && cb <= 32;
+    const bool fused = tiles && cb <= LM_MAX_ROWS;
     std::vector<Chain> chains(nc);
     for (int i = 0; i < nc; ++i) {
         chains[i].b0 = i * cb;

@@ -5,6 +5,7 @@
 namespace qa {
 
 enum { GM_QKV = 0, GM_GATEUP = 1, GM_RESID = 2, GM_HEAD = 3 };
+constexpr int LM_MAX_ROWS = 64;  // sequences one fused decode step serves: two row groups of 32 in every launch (lm_decode.hip, row_group)
 // device-side loop state (int words): position of the token being processed (= keys already cached), ids column, RNG step, seed
 // ST_SEQ0: index of the chain's first sequence inside the call (the sampler keys its Philox stream by the GLOBAL sequence index)
 enum { ST_POS = 0, ST_COL = 1, ST_STEP = 2, ST_SEQ0 = 3, ST_SEED_LO = 4, ST_SEED_HI = 5, ST_WORDS = 8 };

@@ -117,6 +117,30 @@ struct EpiPre {
     float c[4], s[4];  // GM_QKV: cos / sin of this thread's rotary pairs
 };
 
+// Row groups (r05: one chain for up to 64 sequences).  A launch with gridDim.y = RG > 1 serves batch rows [32 rg, 32 rg + 32) in the
+// workgroups of its y-plane rg: every pointer that is indexed by the batch row moves to the group's first row and M becomes the group's
+// row count, so the kernel bodies below never know about groups.  The weights of a column tile are then read by RG workgroups whose linear
+// ids differ by a multiple of gridDim.x - a multiple of 8 for every GEMV of the step, i.e. the SAME XCD (workgroup b runs on XCD b % 8):
+// the second reader hits the XCD's L2, HBM still streams every weight once per step, and the step issues 50 launches for 64 sequences
+// instead of 2 x 50.  A row's arithmetic does not depend on its group (rows never mix inside a GEMV), so tokens do not change.
+constexpr int LM_ROWS_PER_GROUP = 32;
+__device__ __forceinline__ void row_group(GemvArgs& a, int rg, int n_tiles) {
+    const long long r0 = (long long)rg * LM_ROWS_PER_GROUP;
+    a.M = min(LM_ROWS_PER_GROUP, a.M - (int)r0);
+    if (a.x) a.x += r0 * a.ldx;
+    if (a.tok) a.tok += r0;
+    if (a.att_part) a.att_part += r0 * a.H * a.S * (a.hd + 4);
+    if (a.q) a.q += r0 * a.d;
+    if (a.kc) a.kc += r0 * a.kv_bstride;
+    if (a.vc) a.vc += r0 * a.kv_bstride;
+    if (a.res) a.res += r0 * a.ldr;
+    if (a.res_tok) a.res_tok += r0;
+    if (a.y) a.y += r0 * a.ldy;
+    if (a.pmax) a.pmax += r0 * n_tiles;
+    if (a.pidx) a.pidx += r0 * n_tiles;
+    if (a.logits) a.logits += r0 * a.ldl;
+}
+
 template <int MT, int NT, int MODE>
 __device__ __forceinline__ void epi_prefetch(const GemvArgs& a, int tile, int tid, EpiPre& e) {
     if (MODE == GM_RESID) {
@@ -242,7 +266,9 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const float (*p
 // activation load of the batch is issued before the first MFMA, so a wave pays one memory round trip per batch instead of one per
 // chunk (hipcc does not software-pipeline the chunk loop by itself).
 template <int MT, int NT, int MODE, bool ATT, int NB>
-__global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a) {
+__global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a_in) {
+    GemvArgs a = a_in;
+    if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x);
     __shared__ float part[8][MT][16][17];
     __shared__ float s_sq[8][MT * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -341,7 +367,9 @@ __global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a) {
 // Every FMA is useful (the 16x16x4 form wastes 16 / NT of the matrix pipe on duplicated columns: 1.3 us per down_proj
 // workgroup); the four K phases are summed with two shuffles at the end.  NS = 16-wide K steps per wave loaded as one batch.
 template <int MT, int C, int MODE, bool ATT, int NS>
-__global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a) {
+__global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a_in) {
+    GemvArgs a = a_in;
+    if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x);
     constexpr int NT = 4 * C;
     __shared__ float part[8][MT][16][17];
     __shared__ float s_sq[8][MT * 16];
@@ -460,7 +488,7 @@ static int gemv_nb(int K) {
 
 template <int MODE, bool ATT, int NB>
 static int launch_gemv_nb(const GemvArgs& a, int nt, hipStream_t s) {
-    const dim3 grid((unsigned)(a.N / nt));
+    const dim3 grid((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, LM_ROWS_PER_GROUP));  // y: row groups of 32 (M <= 64: one or two)
     const bool m4 = narrow_on_4x4() && nt < 16;
 #define QA_GV(MT, NT) hipLaunchKernelGGL((lm_gemv_kernel<MT, NT, MODE, ATT, NB>), grid, dim3(512), 0, s, a)
 #define QA_G4(MT, C) hipLaunchKernelGGL((lm_gemv4_kernel<MT, C, MODE, ATT, 2 * NB>), grid, dim3(512), 0, s, a)
@@ -502,7 +530,7 @@ bool lm_gemv_supported(int hidden, int intermediate) {
 }
 
 int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s) {
-    QA_REQUIRE(a.M >= 1 && a.M <= 32, "lm_gemv: M=%d must be in [1, 32]", a.M);
+    QA_REQUIRE(a.M >= 1 && a.M <= LM_MAX_ROWS, "lm_gemv: M=%d must be in [1, %d]", a.M, LM_MAX_ROWS);
     QA_REQUIRE(a.K % 256 == 0 && (a.ldx % 4) == 0, "lm_gemv: K=%d must be a multiple of 256", a.K);
     QA_REQUIRE((nt == 16 || nt == 8 || nt == 4) && a.N % nt == 0, "lm_gemv: N=%d not a multiple of the tile width %d", a.N, nt);
     switch (mode) {
@@ -525,7 +553,9 @@ int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s) {
 // product on v_mfma_f32_16x16x4_f32 straight from an LDS copy of the activation tile, W_down slice prefetched at kernel entry.
 // AC = activation columns per workgroup: 16 (two gate/up tiles, I / 16 partials) or 8 (one tile, I / 8 partials, twice the workgroups)
 template <int MT, int NB, int AC>
-__global__ __launch_bounds__(512) void lm_mlp_kernel(const GemvArgs a, const float* __restrict__ wd, float* __restrict__ partial) {
+__global__ __launch_bounds__(512) void lm_mlp_kernel(const GemvArgs a_in, const float* __restrict__ wd, float* __restrict__ partial) {
+    GemvArgs a = a_in;
+    if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x);
     constexpr int NTL = AC / 8;  // gate/up decode tiles (8 gate + 8 up rows each) per workgroup
     __shared__ float part[8][NTL][MT][16][17];
     __shared__ float s_sq[8][MT * 16];
@@ -631,7 +661,7 @@ __global__ __launch_bounds__(512) void lm_mlp_kernel(const GemvArgs a, const flo
     __syncthreads();
     // phase 2: partial[j][row][n] = sum_{k < 16} act[row][k] * W_down[n][16 j + k].  Operands swapped (W is the MFMA's row operand):
     // D^T[n][row], so a lane ends up with 4 CONSECUTIVE output columns n = 4 kq .. 4 kq + 3 of batch row li - one 16-byte store per tile
-    float* pj = partial + (long long)j * (MT * 16) * d;
+    float* pj = partial + ((long long)blockIdx.y * gridDim.x + j) * (MT * 16) * d;  // [row group][j][MT * 16 rows][d]
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         float av[KL];
@@ -657,7 +687,8 @@ __global__ __launch_bounds__(64) void lm_mlp_reduce_kernel(const float* __restri
                                                            const float* __restrict__ res, long long ldr, float* __restrict__ y, long long ldy) {
     const int lane = threadIdx.x, g = lane >> 3, l8 = lane & 7;
     const int row = blockIdx.y, col = blockIdx.x * 32 + 4 * l8;
-    const float* p0 = partial + (long long)row * d + col;
+    const int rg = row / m_pad, rl = row - rg * m_pad;  // row group (m_pad rows each) and row inside it
+    const float* p0 = partial + ((long long)rg * n_part * m_pad + rl) * d + col;
     const long long pstride = (long long)m_pad * d;
     f32x4 res4 = {0.f, 0.f, 0.f, 0.f};
     if (g == 0) res4 = *reinterpret_cast<const f32x4*>(res + (long long)row * ldr + col);
@@ -691,10 +722,10 @@ int lm_mlp_ac() { return knob(K_LM_MLP_FUSED) == 2 ? 8 : 16; }  // read when the
 // partial: [I / 16][16 * MT][d] scratch; y = res + down(act)
 int launch_lm_mlp(const GemvArgs& a, int I, int ac, const float* wd, float* partial, const float* res, long long ldr, float* y, long long ldy,
                   hipStream_t s) {
-    QA_REQUIRE(a.M >= 1 && a.M <= 32 && a.K == a.d && lm_mlp_fused_supported(a.d, I, 16), "lm_mlp: unsupported shape M=%d d=%d I=%d", a.M, a.d, I);
+    QA_REQUIRE(a.M >= 1 && a.M <= LM_MAX_ROWS && a.K == a.d && lm_mlp_fused_supported(a.d, I, 16), "lm_mlp: unsupported shape M=%d d=%d I=%d", a.M, a.d, I);
     const int mt = a.M <= 16 ? 1 : 2;
     const int n_part = I / ac;
-    const dim3 grid((unsigned)n_part);
+    const dim3 grid((unsigned)n_part, (unsigned)ceil_div(a.M, LM_ROWS_PER_GROUP));  // partial: [row group][n_part][16 mt][d]
 #define QA_MLP(MT, NB) \
     if (ac == 16) hipLaunchKernelGGL((lm_mlp_kernel<MT, NB, 16>), grid, dim3(512), 0, s, a, wd, partial); \
     else hipLaunchKernelGGL((lm_mlp_kernel<MT, NB, 8>), grid, dim3(512), 0, s, a, wd, partial)
