@@ -165,8 +165,10 @@ int64_t qa_hcodec_tap(qa_hcodec* h, const char* name, float* dst, int64_t cap, v
  * quantized_out (nullable): [n_vec, D] = sum_q E_q[idx_q].  Ties resolve to the lowest index. */
 int qa_rvq_search(const float* x, int64_t n_vec, const float* codebooks, int32_t Q, int32_t K, int32_t D,
                   int64_t* indices, float* quantized_out, void* stream);
-/* indices: int64 [n_vec, Q] -> out [n_vec, D] = sum_q E_q[idx_q].  Out-of-range indices -> QA_ERR_INVALID is
- * NOT detected on device; the caller guarantees 0 <= idx < K (the reference would raise IndexError). */
+/* indices: int64 [n_vec, Q] -> out [n_vec, D] = sum_q E_q[idx_q].  idx == -1 is a DROPPED code and contributes a zero vector, as in the
+ * third-party ResidualVQ.get_output_from_indices the reference calls (vq/codec.py:183-184; upstream masks -1, the quantize-dropout
+ * convention).  Other out-of-range indices are NOT detected on device (clamped for memory safety); the caller guarantees
+ * -1 <= idx < K - qa_codes_check_async(codes, n, -1, K, ...) is the check (the reference would raise IndexError). */
 int qa_rvq_lookup(const int64_t* indices, int64_t n_vec, const float* codebooks, int32_t Q, int32_t K, int32_t D,
                   float* out, void* stream);
 
@@ -236,11 +238,16 @@ int qa_profile_end_hbm(double* out, int32_t n_out);
  * profiler sees every kernel alone on the device; results are bit-identical either way.  Process-wide. */
 int qa_set_serial(int32_t on);
 
+/* Diagnostics of the in-launch LSTM recurrences of `device` (tests): out[0] recurrences launched so far, out[1] model-graph calls with
+ * one possibly still in flight (not yet behind a host synchronisation), out[2] launches that took the per-step kernels because ANOTHER
+ * call's recurrence was in flight (the co-residency ticket: two handles driving one device never starve each other's grid barrier),
+ * out[3] 1 once a barrier time-out has degraded the device to the per-step kernels. */
+int qa_debug_lstm_stats(int32_t device, int64_t* out4);
+
 /* ---- tuning knobs -------------------------------------------------------------------------------------------
  * Every A/B switch of the library is one row of a table (csrc/knobs.h; INTEGRATION.md lists them): an integer whose initial
- * value is the environment variable of the same name (e.g. QA_LSTM_PERSISTENT, QA_LM_UNFUSED) and which qa_set_knob()
- * overrides at run time.  Knobs are read by the host-side launch code at launch (LM tile widths / QA_LM_UNFUSED: at
- * qa_lm_create) time.  No knob changes results beyond fp32 summation order; none selects a CPU path.  Process-wide. */
+ * value is the environment variable of the same name (e.g. QA_LSTM_PERSISTENT, QA_LM_MLP_FUSED) and which qa_set_knob()
+ * overrides at run time.  Knobs are read by the host-side launch code at launch (QA_LM_MLP_FUSED: at qa_lm_create) time.  No knob changes results beyond fp32 summation order; none selects a CPU path.  Process-wide. */
 int qa_knob_count(void);
 int qa_knob_info(int32_t index, const char** name, int64_t* value, int64_t* default_value, const char** doc);
 int qa_set_knob(const char* name, int64_t value);

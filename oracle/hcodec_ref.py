@@ -273,10 +273,14 @@ def rvq_search(x: Tensor, codebooks: Tensor) -> Tuple[Tensor, Tensor]:
 
 
 def rvq_lookup(indices: Tensor, codebooks: Tensor) -> Tensor:
-    """get_output_from_indices (codec.py:183-184; core_vq.py:406-412): sum_q E_q[idx_q]."""
+    """get_output_from_indices (codec.py:183-184; core_vq.py:406-412): sum_q E_q[idx_q].  idx == -1 = a dropped code: upstream
+    vector_quantize_pytorch masks it to a zero vector (get_codes_from_indices: `mask = indices == -1` ... `masked_fill(mask, 0.)`); the
+    in-tree core_vq.py has no such case (it would index from the end) - the third-party call site is what the product mirrors."""
     out = 0
     for q, e in enumerate(codebooks):
-        out = out + e[indices[..., q]]
+        idx = indices[..., q]
+        dropped = idx == -1
+        out = out + e[idx.masked_fill(dropped, 0)].masked_fill(dropped[..., None], 0.0)
     return out
 
 

@@ -55,9 +55,14 @@ class ResidualVQ(nn.Module):
         return quantized_out, torch.stack(all_indices, dim=-1), losses
 
     def get_output_from_indices(self, indices):  # [B, N, Q] -> [B, N, D]; core_vq.py:406-412
+        # upstream (residual_vq.py get_codes_from_indices): `mask = indices == -1`, the look-up runs on indices with the mask filled with 0,
+        # then `all_codes.masked_fill(mask, 0.)`: a dropped code (quantize dropout) contributes a zero vector
         out = 0
         for q, layer in enumerate(self.layers):
-            out = out + layer._codebook.embed[0][indices[..., q]]
+            idx = indices[..., q]
+            dropped = idx == -1
+            codes = layer._codebook.embed[0][idx.masked_fill(dropped, 0)]
+            out = out + codes.masked_fill(dropped[..., None], 0.0)
         return out
 
 

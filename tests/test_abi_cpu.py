@@ -31,7 +31,7 @@ def test_knob_table_is_enumerable_settable_and_documented(qa_lib):
     from unified_audio_amd import _lib
 
     rows = _lib.knobs()
-    assert {"QA_SERIAL", "QA_LSTM_PERSISTENT", "QA_LM_UNFUSED", "QA_GEMM_CFG", "QA_LM_CHAINS"} <= set(rows)
+    assert {"QA_SERIAL", "QA_LSTM_PERSISTENT", "QA_GEMM_CFG", "QA_LM_CHAINS"} <= set(rows)
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for name, (value, default, text) in rows.items():
         assert name.startswith("QA_") and text and f"`{name}`" in doc, f"{name} is not documented in INTEGRATION.md"

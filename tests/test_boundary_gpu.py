@@ -70,13 +70,36 @@ def test_decode_range_check_is_one_sync_and_optional(qa_lib, gpu_device):
     bad = ok.clone()
     bad[1, 2, 4] = 64
     neg = ok.clone()
-    neg[0, 0, 0] = -1
+    neg[0, 0, 0] = -2
     assert torch.isfinite(codec.decode(ok, ok)).all()
     for a, s in ((bad, ok), (ok, bad), (neg, ok)):
         with pytest.raises(IndexError):
             codec.decode(a, s)
     codec.check_codes = False  # unchecked: indices are clamped by the kernels, nothing faults
     assert torch.isfinite(codec.decode(bad, neg)).all()
+
+
+def test_decode_treats_minus_one_as_a_dropped_code(qa_lib, gpu_device):
+    """the third-party get_output_from_indices behind Codec.decode (vq/codec.py:183-184) masks -1 - a code dropped by
+    quantize dropout - to a zero vector; so does the HIP decode, against the oracle through the stand-in that restates upstream's
+    masking: trailing stages dropped on some frames of one stream, a whole frame dropped in the other."""
+    import unified_audio_amd as qa
+
+    ospec = R.HCodecSpec(**MINI)
+    sd = synth.hcodec10_state_dict(3, ospec)
+    codec = qa.Codec(None, None, None, spec=qa.HCodecSpec(**MINI), device=gpu_device).load_state_dict(sd)
+    gen = torch.Generator().manual_seed(11)
+    ac = torch.randint(0, 64, (2, 3, 7), dtype=torch.int64, generator=gen)
+    sc = torch.randint(0, 64, (2, 3, 7), dtype=torch.int64, generator=gen)
+    ac[0, 1:, 2] = -1
+    ac[1, 2, :] = -1
+    sc[1, :, 5] = -1
+    got = codec.decode(ac, sc).cpu()
+    with torch.no_grad():
+        want = R.decode(sd, ac, sc, ospec)
+    assert float((got - want).pow(2).mean().sqrt()) < 1e-5 * float(want.pow(2).mean().sqrt()) + 1e-7
+    full = codec.decode(ac.clamp(min=0), sc.clamp(min=0)).cpu()
+    assert not torch.equal(full, got)  # the dropped stages really are missing from the sum
 
 
 class _RefStyleExtractor(torch.nn.Module):

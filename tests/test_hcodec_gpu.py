@@ -337,57 +337,3 @@ def test_internal_streams_match_serial_hcodec15(qa_lib, gpu_device):
         _streams_vs_serial(codec, wav.unsqueeze(1), feat, True)
 
 
-def test_cu_masked_lstm_overlap_is_bit_identical(qa_lib, gpu_device, knob):
-    """QA_LSTM_CUS: the encoder's LSTM step launches on reserved CUs (hipExtStreamCreateWithCUMask) while the semantic encoder runs on
-    the others - same kernels, another schedule: codes and waveforms must not change by a bit, call after call (a missing fork / join
-    edge between the three streams would show as a changed or unstable result), for H-Codec 1.0 and 1.5."""
-    import unified_audio_amd as qa
-
-    knob("QA_LSTM_XCD", 0)  # the masked stream runs the per-step kernels: compare like with like
-    ospec = R.SPEC_10
-    sd = synth.hcodec10_state_dict(1234, ospec)
-    kw = {f: getattr(ospec, f) for f in ospec.__dataclass_fields__}
-    codec = qa.Codec(None, None, None, spec=qa.HCodecSpec(**kw), device=gpu_device).load_state_dict(sd)
-    B, T = 8, 640 * 125
-    wav = synth.synth_wav(7, B, T).to(gpu_device)
-    feat = synth.synth_feat(9, B, T // 320).to(gpu_device)
-    ac0, sc0 = codec.encode(wav.unsqueeze(1), feat)
-    rec0 = codec.decode(ac0, sc0)
-    for cus in (64, 32, 0, 96):
-        knob("QA_LSTM_CUS", cus)
-        for _ in range(2):
-            ac, sc = codec.encode(wav.unsqueeze(1), feat)
-            assert torch.equal(ac, ac0) and torch.equal(sc, sc0), cus
-        assert torch.equal(codec.decode(ac, sc), rec0)
-    knob("QA_LSTM_CUS", 64)
-    ospec15 = _spec15(agg_layers=2, bt_layers=2, threshold=0.7)
-    sd15 = synth.hcodec10_state_dict(81, ospec15)
-    kw15 = {f: getattr(ospec15, f) for f in ospec15.__dataclass_fields__}
-    c15 = qa.Codec(None, None, None, spec=qa.HCodecSpec(**kw15), device=gpu_device).load_state_dict(sd15)
-    w15 = synth.synth_wav(82, 4, 640 * 50).to(gpu_device)
-    f15 = synth.synth_feat(83, 4, 640 * 50 // 320, ospec15.sem_in).to(gpu_device)
-    on = c15.encode(w15.unsqueeze(1), f15)
-    knob("QA_LSTM_CUS", 0)
-    off = c15.encode(w15.unsqueeze(1), f15)
-    assert torch.equal(on["acoustic_codes"], off["acoustic_codes"]) and torch.equal(on["semantic_codes"], off["semantic_codes"])
-
-
-def test_grouped_aggregator_launches_are_bit_identical(qa_lib, gpu_device, knob):
-    """QA_GEMM_GROUPED=1: the two aggregator stacks advance as grouped conv_gemm launches (ConvParams::groups) + one attention launch
-    over 2 B sequences on ONE stream, instead of two streams - the same kernels on the same data: identical integers and floats."""
-    import unified_audio_amd as qa
-
-    ospec = _spec15(agg_layers=3, bt_layers=2, threshold=0.7)
-    sd = synth.hcodec10_state_dict(81, ospec)
-    kw = {f: getattr(ospec, f) for f in ospec.__dataclass_fields__}
-    codec = qa.Codec(None, None, None, spec=qa.HCodecSpec(**kw), device=gpu_device).load_state_dict(sd)
-    B, T = 5, 640 * 37
-    wav = synth.synth_wav(82, B, T).to(gpu_device)
-    feat = synth.synth_feat(83, B, T // 320, ospec.sem_in).to(gpu_device)
-    outs = []
-    for grouped in (0, 1, 1, 0):
-        knob("QA_GEMM_GROUPED", grouped)
-        enc = codec.encode(wav.unsqueeze(1), feat)
-        outs.append((enc["acoustic_codes"].clone(), enc["semantic_codes"].clone(), codec.decode(enc["acoustic_codes"], enc["semantic_codes"]).clone()))
-    for o in outs[1:]:
-        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])

@@ -193,6 +193,73 @@ def test_rvq_lookup_exact(qa_lib, gpu_device):
     assert np.array_equal(out.cpu().numpy(), rvq_c.lookup_f32(idx, cb))
 
 
+def test_rvq_lookup_dropped_codes_contribute_zero(qa_lib, gpu_device):
+    """VERDICT r04 item 9 / SURVEY 8c: upstream `get_output_from_indices` treats -1 as a DROPPED code (masked to a zero vector; the
+    quantize-dropout convention of vector_quantize_pytorch) - qa_rvq_lookup does the same, bit for bit equal to the stand-in that
+    restates upstream's masking, and a row that is dropped at every stage decodes to exactly 0."""
+    from oracle import hcodec_ref as R
+    from unified_audio_amd import _lib
+
+    _, cb = _rvq_problem(10, 4, 256, 128, seed=9)
+    rng = np.random.default_rng(2)
+    idx = rng.integers(0, 256, size=(500, 4)).astype(np.int64)
+    idx[rng.random((500, 4)) < 0.3] = -1
+    idx[7] = -1
+    idx[8, 1:] = -1  # the trailing stages dropped: what quantize dropout produces
+    out = torch.empty((500, 128), device=gpu_device)
+    idx_d, cb_d = torch.from_numpy(idx).to(gpu_device), torch.from_numpy(cb).to(gpu_device)
+    _lib.check(qa_lib.qa_rvq_lookup(idx_d.data_ptr(), 500, cb_d.data_ptr(), 4, 256, 128, out.data_ptr(), None))
+    got = out.cpu().numpy()
+    assert np.array_equal(got, R.rvq_lookup(torch.from_numpy(idx), torch.from_numpy(cb)).numpy())
+    assert not got[7].any() and np.array_equal(got[8], cb[0, idx[8, 0]])
+    # the range check that goes with it: -1 is legal, -2 and K are not
+    bad = torch.zeros(1, dtype=torch.int64, device=gpu_device)
+    probe = torch.tensor([-1, 0, 255, -2, 256, -1], dtype=torch.int64, device=gpu_device)
+    _lib.check(qa_lib.qa_codes_check_async(probe.data_ptr(), probe.numel(), -1, 256, bad.data_ptr(), None))
+    assert int(bad.item()) == 2
+
+
+@pytest.mark.parametrize("Q", [1, 4])
+def test_rvq_reencode_of_quantised_vectors(qa_lib, gpu_device, Q):
+    """VERDICT r04 item 9, the exact-hit case (decode -> re-encode): the input IS a sum of code vectors, so at some stage the residual
+    equals a code vector up to rounding and its squared distance rounds to +-1e-7 |x|^2 around 0.  Upstream computes -cdist with
+    clamp(min = 0).sqrt(), which turns every rounding-negative squared distance into an exact 0 (first index wins among THOSE); the
+    reference's in-tree statement (core_vq.py:223-231) and this library take the arg-min of the squared distance itself.  The two can
+    only differ when a SECOND code lies within rounding of the residual - a near-tie by the audit's definition.  Checked: the HIP search
+    equals the fp64 arg-min of its own residual at every stage (no excess), and with one stage the codes come back exactly."""
+    from unified_audio_amd import _lib
+
+    n, K, D = 3000, 1024, 512
+    _, cb = _rvq_problem(10, Q, K, D, seed=31)
+    rng = np.random.default_rng(5)
+    codes = rng.integers(0, K, size=(n, Q)).astype(np.int64)
+    cbd = torch.from_numpy(cb).to(gpu_device)
+    x = torch.empty((n, D), device=gpu_device)
+    cd = torch.from_numpy(codes).to(gpu_device)
+    _lib.check(qa_lib.qa_rvq_lookup(cd.data_ptr(), n, cbd.data_ptr(), Q, K, D, x.data_ptr(), None))
+    idx = torch.full((n, Q), -7, dtype=torch.int64, device=gpu_device)
+    quant = torch.empty((n, D), device=gpu_device)
+    _lib.check(qa_lib.qa_rvq_search(x.data_ptr(), n, cbd.data_ptr(), Q, K, D, idx.data_ptr(), quant.data_ptr(), None))
+    got, xh = idx.cpu().numpy(), x.cpu().numpy()
+    excess, best, gap = rvq_c.check_f64(xh, cb, got)
+    tol = 2e-5 * float((xh.astype(np.float64) ** 2).sum(1).mean())
+    assert excess.max() <= tol
+    assert (got[gap > tol] == best[gap > tol]).all()
+    if Q == 1:  # one stage: the residual IS code vector codes[:, 0]; seeded random codebooks hold no duplicate rows
+        assert np.array_equal(got, codes)
+        assert np.array_equal(quant.cpu().numpy(), xh)  # and the quantised output is that code vector, bit for bit
+    # the same decisions under upstream's formulation, evaluated in fp64: clamp + sqrt never changes the winner here (no second code
+    # within rounding of an exact hit) - if it ever did, the audit above would already have called that stage a near-tie
+    r = xh.astype(np.float64).copy()
+    cb64 = cb.astype(np.float64)
+    for q in range(Q):
+        d2 = (r * r).sum(1)[:, None] - 2.0 * r @ cb64[q].T + (cb64[q] ** 2).sum(1)[None, :]
+        up = np.sqrt(np.clip(d2, 0.0, None)).argmin(1)
+        sure = gap[:, q] > tol
+        assert (up[sure] == got[sure, q]).all()
+        r -= cb64[q][got[:, q]]
+
+
 _RVQ_GOLDEN = sorted(__import__("glob").glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rvq_corevq_*.npz")))
 
 

@@ -114,12 +114,14 @@ def test_generate_at_baseline_size_matches_reference_goldens(qa_lib, gpu_device,
     assert left == 0
 
 
-@pytest.mark.parametrize("name", ["lm_unise_se", "lm_config4_tse_b8"])
-def test_unfused_decode_step_matches_reference_goldens(qa_lib, gpu_device, knob, name):
-    """QA_LM_UNFUSED=1: the per-op decode step (skinny GEMM + attention_decode kernels of csrc/lm_kernels.hip), the path a
-    spec takes when the fused step does not tile it - through the same reference goldens, incl. the KV-786 case."""
-    knob("QA_LM_UNFUSED", 1)  # read at qa_lm_create
-    golden_stream_parity(name, gpu_device, audit=False)
+def test_spec_the_decode_step_cannot_tile_is_refused_with_the_reason(qa_lib, gpu_device):
+    """r05: the round-1 per-op decode step (QA_LM_UNFUSED) is gone; a spec whose widths the fused step does not tile (hidden not a
+    multiple of 256) is refused at load time with the reason instead of silently taking a slower path."""
+    import unified_audio_amd as qa
+
+    spec = L.LMSpec(hidden=128, n_layers=1, n_heads=2, global_size=64, semantic_size=96, feats_dim=64, num_tasks=3)
+    with pytest.raises(qa.QuarkAudioError, match="hidden % 256"):
+        _model(spec, 5, gpu_device)
 
 
 def test_generate_argument_errors(qa_lib, gpu_device):
@@ -215,8 +217,8 @@ def test_batch_17_to_32_uses_two_row_tiles(qa_lib, gpu_device):
 
 
 def test_narrow_tile_kernels_agree(qa_lib, gpu_device):
-    """The 4x4x1-MFMA narrow-tile GEMV (default) and the 16x16x4 one (QA_LM_MFMA16=1, read once per process: checked in a
-    child process) must produce the oracle's tokens; here: the default path on a spec whose every GEMV uses narrow tiles."""
+    """The 4x4x1-MFMA narrow-tile GEMV kernels (NT = 8 / 4) must produce the oracle's tokens: a spec whose every GEMV uses narrow
+    tiles.  (The 16x16x4 form of those tiles, QA_LM_MFMA16, measured equal in r02 and is gone since r05.)"""
     spec = L.LMSpec(hidden=256, n_layers=3, n_heads=4, global_size=64, semantic_size=96, feats_dim=64, num_tasks=3)
     sd, lm = _model(spec, 23, gpu_device)
     B, Nm, S, G = 4, 7, 10, 6

@@ -80,3 +80,31 @@ def test_golden_files_are_what_the_reference_produces_today():
         x, cb = G.case_inputs(int(g["seed"]), int(g["n"]), int(g["Q"]), int(g["K"]), int(g["D"]))
         idx_ref, quant_ref, _ = G.reference_rvq(mod, x, cb)
         assert np.array_equal(idx_ref, g["indices"].astype(np.int64)) and np.array_equal(quant_ref[::7, ::5], g["quant_sample"])
+
+
+def test_dropped_codes_are_masked_like_upstream_get_codes_from_indices():
+    """SURVEY 8c / VERDICT r04 item 9: upstream `get_output_from_indices` treats index -1 as a DROPPED code - `mask = indices == -1`,
+    look-up on the mask-filled indices, `masked_fill(mask, 0.)` - so the stage contributes a zero vector.  The oracle and the stand-in the
+    imported reference Codec runs on both restate that; everything that is not -1 is unchanged (bit for bit the plain sum of look-ups).
+    Unpinned against the pip package itself (absent, no network): this pins the two restatements to each other and to the definition."""
+    rng = np.random.default_rng(4)
+    Q, K, D = 4, 32, 16
+    cb = rng.standard_normal((Q, K, D)).astype(np.float32)
+    idx = torch.from_numpy(rng.integers(0, K, size=(3, 9, Q)).astype(np.int64))
+    plain = R.rvq_lookup(idx, torch.from_numpy(cb))
+    with torch.no_grad():
+        assert torch.equal(_stub_rvq(cb).get_output_from_indices(idx), plain)
+    drop = idx.clone()
+    drop[0, 0, :] = -1
+    drop[1, 2, 1:] = -1
+    drop[2, 5, 2] = -1
+    got = R.rvq_lookup(drop, torch.from_numpy(cb))
+    with torch.no_grad():
+        assert torch.equal(_stub_rvq(cb).get_output_from_indices(drop), got)
+    assert not got[0, 0].any()
+    assert torch.equal(got[1, 2], torch.from_numpy(cb[0, idx[1, 2, 0]]))
+    want = torch.from_numpy(cb[0, idx[2, 5, 0]]) + torch.from_numpy(cb[1, idx[2, 5, 1]]) + torch.from_numpy(cb[3, idx[2, 5, 3]])
+    assert torch.allclose(got[2, 5], want, atol=1e-6)
+    keep = torch.ones(3, 9, dtype=torch.bool)
+    keep[0, 0] = keep[1, 2] = keep[2, 5] = False
+    assert torch.equal(got[keep], plain[keep])

@@ -17,7 +17,7 @@ def _components(device):
                       compress_exponent=0.0)
     fx = qa.SSLFeatureExtractor(qa.SSLSpec(**{f: getattr(sspec, f) for f in sspec.__dataclass_fields__}), device=device)
     fx.load_state_dict(S.synth_state_dict(4, sspec, "wavlm"))
-    lspec = L.LMSpec(hidden=128, n_layers=2, n_heads=2, global_size=64, semantic_size=128, feats_dim=96)
+    lspec = L.LMSpec(hidden=256, n_layers=2, n_heads=4, global_size=64, semantic_size=128, feats_dim=96)
     lm = qa.LLM_SFT(feats_dim=96, llm_base_config=dict(global_size=64, semantic_size=128, hidden_size=128, num_layers=2,
                                                        num_attention_heads=2), device=device)
     lm.load_state_dict(L.lm_state_dict(8, lspec))

@@ -1,7 +1,7 @@
 """In-process A/B of run-time knobs (csrc/knobs.h) on the codec hot path: ONE process, one set of weights and inputs, the knob flipped
 with qa_set_knob between timed blocks, and every output of every setting compared BIT FOR BIT with the first setting's.
 
-    python tools/knob_ab.py --models 1.0,1.5 --knob QA_LSTM_GROUP_ROWS=0,16,8 [--steps 4] [--batch 32] [--seconds 10]
+    python tools/knob_ab.py --models 1.0,1.5 --knob QA_LSTM_XCD=1,2,0 [--steps 4] [--batch 32] [--seconds 10]
 
 Prints one line per (model, value): ms per encode+decode step (best and mean of --repeats blocks), `identical` = codes and
 waveform equal to the first value's, and a digest of the outputs.  Several --knob arguments are swept one after the other (not as a

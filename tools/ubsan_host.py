@@ -48,7 +48,7 @@ st = qa.StreamingTransformer(128, 4, 2, 256, causal=True, context=6, device=dev,
 x = torch.randn(2, 9, 128, device=dev)
 with st.streaming(2):
     for i in range(9): st(x[:, i:i + 1])
-# round 3 host paths: LM chains (B > 32) incl. a forced chain count, fused-MLP off, grouped aggregator launches, CU-masked streams, the
+# round 3 host paths: LM chains (B > 32) incl. a forced chain count, fused-MLP off, the
 # rolling RoPE window of an unbounded stream, the persistent LSTM and its time-out recovery
 from unified_audio_amd import _lib
 mix40 = synth.synth_feats(51, 40, 12).to(dev); mel40 = torch.zeros(40, 5, 80)
@@ -56,12 +56,12 @@ lm.generate("se", None, None, mel40, mix40, global_length=3, do_sample=False)
 _lib.set_knob("QA_LM_CHAINS", 3); lm.generate("se", None, None, mel40, mix40, global_length=3, do_sample=True); _lib.set_knob("QA_LM_CHAINS", 0)
 _lib.set_knob("QA_LM_MLP_FUSED", 0); lm2 = qa.LLM_SFT(device=dev).load_state_dict(synth.lm_state_dict(4321)); _lib.set_knob("QA_LM_MLP_FUSED", 1)
 lm2.generate("se", None, None, mel, mix, global_length=4, do_sample=False)
-for k, v in (("QA_GEMM_GROUPED", 1), ("QA_LSTM_CUS", 48), ("QA_LSTM_PERSISTENT", 1)):
+for k, v in (("QA_LSTM_PERSISTENT", 1),):
     _lib.set_knob(k, v)
     codes = tok.tokenize(wav.to(dev), feats=feat.transpose(1, 2).contiguous().to(dev)); assert torch.isfinite(tok.detokenize(**codes)).all()
 _lib.set_knob("QA_LSTM_FAULT", 1); _lib.set_knob("QA_LSTM_SPIN_LIMIT", 2048)
 codes = tok.tokenize(wav.to(dev), feats=feat.transpose(1, 2).contiguous().to(dev)); assert torch.isfinite(tok.detokenize(**codes)).all()
-for k, v in (("QA_LSTM_FAULT", 0), ("QA_LSTM_PERSISTENT", -1), ("QA_LSTM_CUS", 0), ("QA_GEMM_GROUPED", 0), ("QA_MIMI_ROPE_WINDOW", 8)):
+for k, v in (("QA_LSTM_FAULT", 0), ("QA_LSTM_PERSISTENT", -1), ("QA_MIMI_ROPE_WINDOW", 8)):
     _lib.set_knob(k, v)
 with st.streaming(2):
     for i in range(9): st(x[:, i:i + 1])

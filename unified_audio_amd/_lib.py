@@ -118,6 +118,7 @@ SYMBOLS = {
     "qa_profile_begin_ex": (C.c_int, [C.c_int32]),
     "qa_profile_hbm_kinds": (C.c_int, []),
     "qa_profile_hbm_name": (C.c_char_p, [C.c_int32]),
+    "qa_debug_lstm_stats": (C.c_int, [C.c_int32, C.POINTER(C.c_int64)]),
     "qa_profile_end_hbm": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
     "qa_set_serial": (C.c_int, [C.c_int32]),
     "qa_knob_count": (C.c_int, []),

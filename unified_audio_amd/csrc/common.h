@@ -123,14 +123,6 @@ struct ConvParams {
     float* y2;
     const float* alpha2;
     long long ldy2;
-    // Grouped launch (groups == 2, Linear layers only): two problems of IDENTICAL shape in one grid - group 1 reads / writes the same
-    // buffers displaced by g_x / g_y / g_res / g_gate floats and uses its own w2 / bias2 / gamma2 (H-Codec 1.5: the two aggregator
-    // stacks, layer by layer).  M, T_in, T_out describe ONE group; the grid holds groups x tiles.
-    int groups;
-    long long g_x, g_y, g_res, g_gate;
-    const float* w2;
-    const float* bias2;
-    const float* gamma2;
     // Arg-min epilogue (RVQ distance GEMM, rvq.hip): instead of storing y = x w^T, every group of 32 consecutive output columns of a row
     // is reduced to its nearest code - dist = (am_x2[m] - 2 y[m, n]) + am_e2[n] (core_vq.py:225-229 association), lowest n on ties - and
     // only (dist, n) goes to am_dist / am_idx [M, am_ld]: the [n_vec, K] product matrix never reaches memory.  y may be null.

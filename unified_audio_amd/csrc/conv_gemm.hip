@@ -120,19 +120,6 @@ __global__ __launch_bounds__(256, (BM == 64 && (BK == 16 || BN == 64) ? 4 : (BK 
         const int xcd = tile & 7, local = tile >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
-    if (LINEAR && p.groups > 1) {  // grouped launch: the second half of the (swizzled) tile ids is group 1 - workgroup-uniform
-        const int tpg = ((p.M + BM - 1) / BM) * tiles_n;
-        if (tile >= tpg) {
-            tile -= tpg;
-            p.x += p.g_x;
-            p.y += p.g_y;
-            if (p.res) p.res += p.g_res;
-            if (p.gate) p.gate += p.g_gate;
-            p.w = p.w2;
-            p.bias = p.bias2;
-            p.gamma = p.gamma2;
-        }
-    }
     int tm_i = tile / tiles_n, tn_i = tile % tiles_n;
     if (p.panel > 0 && tiles_n > p.panel) {
         // 2-D blocking of the tile order (QA_GEMM_PANEL = PW): column panels of PW tiles, row tiles fastest inside a panel, so that the
@@ -408,8 +395,7 @@ __global__ __launch_bounds__(256, (BM == 64 && (BK == 16 || BN == 64) ? 4 : (BK 
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const ConvParams& p, hipStream_t stream) {
     QA_REQUIRE(p.prologue == ACT_NONE || p.prologue == ACT_ELU, "conv_gemm: prologue %d unsupported", p.prologue);
-    const int ng = p.groups > 1 ? p.groups : 1;
-    const long long tiles = ng * ceil_div(p.M, BM) * ceil_div(p.N, BN);
+    const long long tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     const bool prof = profile_enabled();
     if (prof) {
         const int cfg = BM == 64 ? (BN == 64 ? PROF_CFG_64x64 : PROF_CFG_64x128) : (BN == 32 ? PROF_CFG_128x32 : (BN == 64 ? PROF_CFG_128x64 : PROF_CFG_128x128));
@@ -418,7 +404,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
         const double out_elems = p.am_dist ? 2.0 * (double)p.M * p.am_ld + p.M + n  // arg-min epilogue: (dist, idx) per 32 columns + |r|^2 + |e|^2
                                             : (double)p.M * n * (1.0 + (p.res ? 1.0 : 0.0) + (p.gate ? 1.0 : 0.0));
         const double elems = (double)p.B * p.T_in * p.C_in + n * k + out_elems;
-        profile_record_begin(cfg, ng * 2.0 * (double)p.M * n * k, ng * 4.0 * elems, stream, &p);
+        profile_record_begin(cfg, 2.0 * (double)p.M * n * k, 4.0 * elems, stream, &p);
     }
     // BK = 16 chunks need 45 KB / 35 KB of LDS, so 3-4 workgroups are co-resident per CU (BK = 32: 2) and cover each
     // other's barriers, prologues and epilogues: +10..25 % on the K = 512 layers of the aggregator stacks, +3..5 % on
@@ -432,7 +418,6 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
     const bool linear_on = knob(K_GEMM_LINEAR) != 0;
     const bool linear = linear_on && p.ksize == 1 && p.stride == 1 && p.pad_left == 0 && p.in_rep <= 1 && p.T_in == p.T_out &&
                         (p.dilation <= 1);
-    QA_REQUIRE(ng == 1 || (linear && ng == 2 && p.w2 && !p.y2), "conv_gemm: a grouped launch needs a Linear layer (ksize 1, QA_GEMM_LINEAR) and w2");
     const bool bk16 = BN >= 64 && p.prologue != ACT_ELU && ((p.K <= bk16_max_k && tiles >= bk16_min_tiles) || p.C_in % 32 != 0);
     if (bk16 && linear)
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, (BN >= 64 ? 16 : 32), true>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
@@ -478,7 +463,7 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
                                      (!p.y2 || (p.alpha2 && al16(p.alpha2) && al16(p.y2) && p.ldy2 % 4 == 0))),
                "conv_gemm: Snake activation / second output need the float4 epilogue and 16-byte aligned alpha vectors");
     QA_REQUIRE(p.dilation <= 1 || (p.pad_mode == PAD_ZERO && p.in_rep <= 1), "conv_gemm: dilation needs zero padding");
-    QA_REQUIRE(!p.am_dist || (q.vec_epi && p.am_idx && p.am_x2 && p.am_e2 && al16(p.am_e2) && p.am_ld >= (p.N + 31) / 32 && !p.y2 && p.groups <= 1),
+    QA_REQUIRE(!p.am_dist || (q.vec_epi && p.am_idx && p.am_x2 && p.am_e2 && al16(p.am_e2) && p.am_ld >= (p.N + 31) / 32 && !p.y2),
                "conv_gemm: the arg-min epilogue needs N %% 4 == 0, x2 / e2 / dist / idx and am_ld >= ceil(N / 32)");
     QA_REQUIRE(!p.rope || (q.vec_epi && p.rope_hd % 4 == 0 && p.rope_n % 4 == 0 && p.rope_T > 0 && al16(p.rope)),
                "conv_gemm: fused RoPE needs the float4 epilogue (N, strides, pointers multiples of 4 / 16 B)");
@@ -495,15 +480,13 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
         // (profiles/r04_gemm_tile_sweep.txt: 133.1 / 121.5 / 121.6 / 115.9 TFLOP/s); ties go to the larger tile (less L2 traffic).
         // Every configuration accumulates an output element over k in the same order, so this choice - which depends on M, i.e.
         // on the batch size - never changes a bit (tests/test_kernels_gpu.py::test_conv_gemm_tile_configurations_are_bit_identical).
-        const long long ngc = p.groups > 1 ? p.groups : 1;
         struct Cand { int cfg, bm, bn; double eff; };
         static const Cand cands[] = {{PROF_CFG_128x128, 128, 128, 1.0}, {PROF_CFG_64x128, 64, 128, 0.914}, {PROF_CFG_128x64, 128, 64, 0.913},
                                      {PROF_CFG_64x64, 64, 64, 0.871}};
         double best = 0.0;
         cfg = PROF_CFG_128x128;
         for (const Cand& c : cands) {
-            if (ngc > 1 && c.bm != 128) continue;  // grouped launches were tuned on the 128-row tiles only
-            const long long tiles = ngc * ceil_div(p.M, c.bm) * ceil_div(p.N, c.bn);
+            const long long tiles = ceil_div(p.M, c.bm) * ceil_div(p.N, c.bn);
             // a launch that gives a CU at most ONE workgroup has nobody to cover that workgroup's barriers, prologue and epilogue: the
             // 256-tile 4032 x 512 x 512 launch runs 8 % faster as 504 tiles of 64 x 64 although those need two rounds (same sweep)
             const double cost = (double)ceil_div(tiles, 256) * c.bm * c.bn / c.eff * (tiles <= 256 ? 1.25 : 1.0);

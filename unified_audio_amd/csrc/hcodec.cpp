@@ -109,10 +109,6 @@ struct qa_hcodec {
     int* host_sync = nullptr;  // pinned host scalar for the data-dependent group / frame counts
     hipStream_t side = nullptr;  // second stream: the two aggregator stacks are independent and run concurrently
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // QA_LSTM_CUS: the encoder's LSTM step launches on `lstm_cus` reserved CUs, the semantic encoder on the complementary CUs
-    hipStream_t lstm_stream = nullptr, sem_stream = nullptr;
-    hipEvent_t ev_l[2] = {nullptr, nullptr}, ev_sem[2] = {nullptr, nullptr};
-    int lstm_cus = 0;
     // workspace
     char* ws = nullptr;
     size_t ws_cap = 0;
@@ -361,31 +357,6 @@ int conv_op(Ctx& c, const float* x, int64_t ldx, int B, int T_in, const ConvW& w
     return launch_conv_gemm(p, c.stream);
 }
 
-// two Linear layers of identical shape in ONE launch (ConvParams::groups): group 1 = the same buffers displaced by the pointer
-// differences, with its own weights
-int linear_pair_op(Ctx& c, const float* xa, const float* xb, int64_t rows, const ConvW& wa, const ConvW& wb, float* ya, float* yb, int act,
-                   const float* resa, const float* resb, const float* gammaa, const float* gammab, const float* rope = nullptr, int rope_n = 0,
-                   int rope_hd = 0, int rope_T = 0) {
-    if (c.dry) return QA_OK;
-    QA_REQUIRE(wa.N == wb.N && wa.C_in == wb.C_in && wa.ksize == 1 && wb.ksize == 1 && (resa == nullptr) == (resb == nullptr) &&
-                   (gammaa == nullptr) == (gammab == nullptr) && (wa.b == nullptr) == (wb.b == nullptr),
-               "linear pair: the two layers differ in shape");
-    qa_conv_args a{};
-    a.x = xa; a.w = wa.w; a.bias = wa.b; a.gamma = gammaa; a.residual = resa; a.y = ya;
-    a.B = 1; a.T_in = rows; a.C_in = wa.C_in; a.T_out = rows; a.N = wa.N;
-    a.ldx = wa.C_in; a.ldy = wa.N; a.ldr = wa.N; a.ldg = wa.N;
-    a.ksize = 1; a.stride = 1; a.act = act;
-    ConvParams p;
-    QA_TRY(conv_params_from_args(a, &p));
-    p.rope = rope; p.rope_n = rope_n; p.rope_hd = rope_hd; p.rope_T = rope_T; p.rope_pos0 = 0;
-    p.groups = 2;
-    p.g_x = xb - xa;
-    p.g_y = yb - ya;
-    p.g_res = resa ? resb - resa : 0;
-    p.w2 = wb.w; p.bias2 = wb.b; p.gamma2 = gammab;
-    return launch_conv_gemm(p, c.stream);
-}
-
 // plain linear over `rows` rows
 int linear_op(Ctx& c, const float* x, int64_t rows, const ConvW& w, float* y, int act = ACT_NONE,
               const float* res = nullptr, const float* gate = nullptr, const float* gamma = nullptr) {
@@ -439,15 +410,7 @@ int transformer_op(Ctx& c, const TransformerW& tw, float* x, int B, int N, const
         const std::string lp = tap_prefix + ".layers." + std::to_string(l);
         RUN(launch_rmsnorm(x, L.ln1, hn, rows, d, 1e-6f, c.stream));
         RUN(linear_op(c, hn, rows, L.ih, big));
-        if (c.lstm_stream && !c.dry) {  // the recurrence on its reserved CUs; this stream resumes behind it
-            QA_HIP(hipEventRecord(c.lstm_ev[0], c.stream));
-            QA_HIP(hipStreamWaitEvent(c.lstm_stream, c.lstm_ev[0], 0));
-            QA_TRY(launch_lstm(big, L.w_hh, hl, cst, B, N, d, c.lstm_stream, knob(K_LSTM_GRAPH) != 2));  // QA_LSTM_GRAPH=2: replay the graph there
-            QA_HIP(hipEventRecord(c.lstm_ev[1], c.lstm_stream));
-            QA_HIP(hipStreamWaitEvent(c.stream, c.lstm_ev[1], 0));
-        } else {
-            RUN(launch_lstm(big, L.w_hh, hl, cst, B, N, d, c.stream));
-        }
+        RUN(launch_lstm(big, L.w_hh, hl, cst, B, N, d, c.stream));
         c.tap(lp + ".self_attn.rnn", hl, rows * d);
         RUN(linear_op(c, hl, rows, L.qkv, qkv));
         RUN(launch_rope(qkv, tw.rope, B, N, H, hd, 3 * d, 0, c.stream));
@@ -516,46 +479,9 @@ int mimi_op(Ctx& c, const MimiW& mw, float* x, int B, int N) {
     c.arena.release(mark);
     return QA_OK;
 }
-bool mimi_pair_is_grouped(const MimiW& wa, const MimiW& wb) {
-    return knob(K_GEMM_GROUPED) != 0 && knob(K_GEMM_LINEAR) != 0 && wa.d == wb.d && wa.ff == wb.ff && wa.heads == wb.heads &&
-           wa.causal == wb.causal && wa.context == wb.context && wa.layers.size() == wb.layers.size();
-}
-// two independent stacks of equal depth and shape as ONE chain of grouped launches (QA_GEMM_GROUPED): per layer 2 + 2 LayerNorm
-// launches, 4 grouped GEMMs (twice the tiles of one stack: the 568-tile N = 512 layers no longer leave a quarter of the CUs idle in
-// their last round) and one attention launch over 2 B sequences - 9 launches instead of 16, on one stream, deterministic order
-int mimi_pair_grouped(Ctx& c, const MimiW& wa, float* xa, const MimiW& wb, float* xb, int B, int N) {
-    const int d = wa.d, H = wa.heads, hd = d / H;
-    const int64_t rows = (int64_t)B * N;
-    const size_t mark = c.arena.mark();
-    float* hn = c.arena.alloc<float>(2 * rows * d);        // [stack][rows][d]: the two stacks' temporaries are contiguous, so the
-    float* qkv = c.arena.alloc<float>(2 * rows * 3 * d);   // attention sees one batch of 2 B sequences
-    float* att = c.arena.alloc<float>(2 * rows * d);
-    float* u = c.arena.alloc<float>(2 * rows * wa.ff);
-    if (!c.dry) {
-        const float scale = 1.0f / std::sqrt((float)hd);
-        for (size_t l = 0; l < wa.layers.size(); ++l) {
-            const MimiLayerW &La = wa.layers[l], &Lb = wb.layers[l];
-            QA_TRY(launch_layernorm(xa, La.n1w, La.n1b, hn, rows, d, 1e-5f, c.stream));
-            QA_TRY(launch_layernorm(xb, Lb.n1w, Lb.n1b, hn + rows * d, rows, d, 1e-5f, c.stream));
-            QA_TRY(linear_pair_op(c, hn, hn + rows * d, rows, La.in_proj, Lb.in_proj, qkv, qkv + rows * 3 * d, ACT_NONE, nullptr, nullptr, nullptr,
-                                  nullptr, wa.rope, 2 * d, hd, N));
-            QA_TRY(launch_attention(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, 2 * B, N, N, (long long)N * 3 * d, H, hd, scale, wa.causal,
-                                    c.stream, nullptr, nullptr, 0, wa.causal ? wa.context : 0));
-            QA_TRY(linear_pair_op(c, att, att + rows * d, rows, La.out_proj, Lb.out_proj, xa, xb, ACT_NONE, xa, xb, La.ls1, Lb.ls1));
-            QA_TRY(launch_layernorm(xa, La.n2w, La.n2b, hn, rows, d, 1e-5f, c.stream));
-            QA_TRY(launch_layernorm(xb, Lb.n2w, Lb.n2b, hn + rows * d, rows, d, 1e-5f, c.stream));
-            QA_TRY(linear_pair_op(c, hn, hn + rows * d, rows, La.lin1, Lb.lin1, u, u + rows * wa.ff, ACT_GELU, nullptr, nullptr, nullptr, nullptr));
-            QA_TRY(linear_pair_op(c, u, u + rows * wa.ff, rows, La.lin2, Lb.lin2, xa, xb, ACT_NONE, xa, xb, La.ls2, Lb.ls2));
-        }
-    }
-    c.arena.release(mark);
-    return QA_OK;
-}
-
 // two independent stacks of equal depth, layer-interleaved on two streams (xa on the caller's stream, xb on `side`)
 int mimi_pair_op(Ctx& c, hipStream_t side, const MimiW& wa, float* xa, const MimiW& wb, float* xb, int B, int N) {
     QA_REQUIRE(N <= MAX_POS && wa.layers.size() == wb.layers.size(), "mimi pair: mismatched stacks");
-    if (mimi_pair_is_grouped(wa, wb)) return mimi_pair_grouped(c, wa, xa, wb, xb, B, N);
     const size_t mark = c.arena.mark();
     const MimiTemps ta = mimi_temps(c, wa, (int64_t)B * N);
     const MimiTemps tb = mimi_temps(c, wb, (int64_t)B * N);
@@ -683,27 +609,6 @@ int encode_front(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const flo
         sem = c.arena.alloc<float>((size_t)B * Ls * sp.code_dim);
         return conv_same(c, s, B, Ls, h->sem_out, sem);
     };
-    // QA_LSTM_CUS > 0 (not with taps / qa_set_serial): the semantic encoder is enqueued FIRST, on a stream masked to the CUs the LSTM
-    // does not own, and the encoder transformer's LSTM step launches go to a stream that owns the reserved CUs - the recurrence
-    // (500 dependent 6 us launches per layer at 10 s clips) then runs under the semantic encoder's GEMMs instead of in front of them.
-    // Its buffers are carved before the acoustic branch's mark / release regions, so nothing the two streams touch aliases.
-    c.lstm_stream = nullptr;
-    const bool overlap = sp.version != 20 && h->lstm_stream && !c.capture && !serial_mode();
-    hipStream_t main_stream = c.stream;
-    if (overlap) {
-        if (!c.dry) {
-            QA_HIP(hipEventRecord(h->ev_sem[0], main_stream));
-            QA_HIP(hipStreamWaitEvent(h->sem_stream, h->ev_sem[0], 0));
-        }
-        c.stream = h->sem_stream;
-        const int st = semantic_branch();
-        c.stream = main_stream;
-        QA_TRY(st);
-        if (!c.dry) QA_HIP(hipEventRecord(h->ev_sem[1], h->sem_stream));
-        c.lstm_stream = h->lstm_stream;
-        c.lstm_ev[0] = h->ev_l[0];
-        c.lstm_ev[1] = h->ev_l[1];
-    }
     if (sp.version == 20) {
         QA_TRY(encoder20(h, c, wav, B, T, &emb, &N50, &N25));
     } else {
@@ -759,12 +664,7 @@ int encode_front(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, const flo
                    nullptr, nullptr, 0, nullptr, ACT_NONE));
     }
     c.tap("enc.emb", emb, (int64_t)B * N25 * sp.code_dim);
-    c.lstm_stream = nullptr;
-    if (overlap) {
-        if (!c.dry) QA_HIP(hipStreamWaitEvent(main_stream, h->ev_sem[1], 0));  // join: everything downstream needs both branches
-    } else {
-        QA_TRY(semantic_branch());
-    }
+    QA_TRY(semantic_branch());
     QA_REQUIRE(Ls == N25, "encode: semantic stream has %d frames, acoustic stream %d (feat must have T/%d frames)", Ls,
                N25, T / std::max(1, N50));
     c.tap("enc.sem", sem, (int64_t)B * Ls * sp.code_dim);
@@ -902,8 +802,7 @@ int encode_adaptive_graph(qa_hcodec* h, Ctx& c, const float* wav, int B, int T, 
     float* agg_s = c.arena.alloc<float>((size_t)B * G * D);
     // semantic_aggregator(sem), acoustic_aggregator(emb): both use the alignment of the semantic stream and are otherwise
     // independent, so the two 32-layer stacks run concurrently on two streams (fork / join with events; no host sync)
-    // (QA_GEMM_GROUPED, the default: the two stacks advance together as grouped launches on the caller's stream instead)
-    hipStream_t side = (serial_mode() || mimi_pair_is_grouped(h->agg_sem, h->agg_ac)) ? c.stream : h->side;  // qa_set_serial(1): one stream
+    hipStream_t side = serial_mode() ? c.stream : h->side;  // qa_set_serial(1): one stream
     if (!c.dry) {
         QA_TRY(launch_agg_build(sem, seg, start, len, nseg, h->qemb_sem, inter_s, B, N, G, D, c.stream));
         QA_TRY(launch_agg_build(emb, seg, start, len, nseg, h->qemb_ac, inter_a, B, N, G, D, c.stream));
@@ -1183,34 +1082,6 @@ int build(qa_hcodec* h, const HostTable& tab) {
 }  // namespace
 }  // namespace qa
 
-// QA_LSTM_CUS = n > 0: two CU-masked streams per handle - `lstm_stream` owns CUs [0, n), `sem_stream` the others (bit i of the mask =
-// CU i in the runtime's enumeration; the split only has to be disjoint).  Re-created when the knob changes; n = 0 removes them.
-static int ensure_masked_streams(qa_hcodec* h) {
-    const int want = (int)std::max<long long>(0, std::min<long long>(knob(K_LSTM_CUS), 248));
-    if (want == h->lstm_cus) return QA_OK;
-    if (h->lstm_stream) {
-        QA_HIP(hipDeviceSynchronize());
-        (void)hipStreamDestroy(h->lstm_stream);
-        (void)hipStreamDestroy(h->sem_stream);
-        h->lstm_stream = h->sem_stream = nullptr;
-    }
-    h->lstm_cus = want;
-    if (want == 0) return QA_OK;
-    int cus = 0;
-    QA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
-    QA_REQUIRE(want < cus, "QA_LSTM_CUS=%d: the device has %d CUs", want, cus);
-    const int words = (cus + 31) / 32;
-    std::vector<uint32_t> ml(words, 0u), ms(words, 0u);
-    for (int i = 0; i < cus; ++i) (i < want ? ml : ms)[i / 32] |= 1u << (i % 32);
-    QA_HIP(hipExtStreamCreateWithCUMask(&h->lstm_stream, (uint32_t)words, ml.data()));
-    QA_HIP(hipExtStreamCreateWithCUMask(&h->sem_stream, (uint32_t)words, ms.data()));
-    for (int i = 0; i < 2; ++i) {
-        if (!h->ev_l[i]) QA_HIP(hipEventCreateWithFlags(&h->ev_l[i], hipEventDisableTiming));
-        if (!h->ev_sem[i]) QA_HIP(hipEventCreateWithFlags(&h->ev_sem[i], hipEventDisableTiming));
-    }
-    return QA_OK;
-}
-
 // The non-dry pass of a model graph.  A call that launched the persistent LSTM recurrence (lstm.hip) waits for its stream before
 // returning and, should one of that kernel's grid barriers have timed out (it needs every workgroup resident at once: the device
 // was shared with another such kernel), runs the graph again on the per-step kernels - the call that hit the failure returns
@@ -1221,8 +1092,7 @@ static int run_graph_checked(qa_hcodec* h, Ctx& c, F&& graph) {
     QA_TRY(lstm_call_begin(h->device, &ticket));
     {
         const int st = graph();
-        if (st != QA_OK) {  // error path only: internal streams (aggregator side stream, CU-masked streams) may still run out of the workspace
-            c.lstm_stream = nullptr;
+        if (st != QA_OK) {  // error path only: the aggregator side stream may still run out of the workspace
             (void)hipDeviceSynchronize();
             bool ignored = false;
             (void)lstm_call_end(ticket, c.stream, &ignored);
@@ -1274,12 +1144,6 @@ void qa_hcodec_destroy(qa_hcodec* h) {
     if (h->ws) (void)hipFree(h->ws);
     if (h->host_sync) (void)hipHostFree(h->host_sync);
     if (h->side) (void)hipStreamDestroy(h->side);
-    if (h->lstm_stream) (void)hipStreamDestroy(h->lstm_stream);
-    if (h->sem_stream) (void)hipStreamDestroy(h->sem_stream);
-    for (int i = 0; i < 2; ++i) {
-        if (h->ev_l[i]) (void)hipEventDestroy(h->ev_l[i]);
-        if (h->ev_sem[i]) (void)hipEventDestroy(h->ev_sem[i]);
-    }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
@@ -1299,7 +1163,6 @@ int qa_hcodec_encode(qa_hcodec* h, const float* wav, int64_t B, int64_t T, const
     QA_REQUIRE(B * T < (1LL << 31), "qa_hcodec_encode: batch of %lld x %lld samples is too large", (long long)B, (long long)T);
     QA_REQUIRE(!h->spec.adaptive, "qa_hcodec_encode: this handle is an H-Codec 1.5 model, use qa_hcodec_encode_adaptive");
     QA_HIP(hipSetDevice(h->device));
-    QA_TRY(ensure_masked_streams(h));
     Ctx& c = h->ctx;
     c.stream = static_cast<hipStream_t>(stream);
     c.dry = true;
@@ -1348,7 +1211,6 @@ int qa_hcodec_encode_adaptive(qa_hcodec* h, const float* wav, int64_t B, int64_t
     QA_REQUIRE(threshold >= 0.f && threshold <= 1.f, "qa_hcodec_encode_adaptive: threshold %g outside [0, 1] (codec_adaptive.py:151)", threshold);
     const float thr = threshold <= 0.f ? h->spec.threshold : threshold;  // codec_adaptive.py:158
     QA_HIP(hipSetDevice(h->device));
-    QA_TRY(ensure_masked_streams(h));
     Ctx& c = h->ctx;
     c.stream = static_cast<hipStream_t>(stream);
     c.dry = true;

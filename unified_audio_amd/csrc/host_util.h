@@ -108,9 +108,6 @@ struct Ctx {
     hipStream_t stream = nullptr;
     bool dry = false;      // planning pass: allocate, do not launch
     bool capture = false;  // test hook: snapshot named intermediates (buffers are reused / updated in place later)
-    // CU-masked side stream for the LSTM recurrences of the current graph (QA_LSTM_CUS; nullptr: they stay on `stream`)
-    hipStream_t lstm_stream = nullptr;
-    hipEvent_t lstm_ev[2] = {nullptr, nullptr};
     std::unordered_map<std::string, Tap> taps;
     void tap(const std::string& name, const float* p, int64_t n) {
         if (!capture) return;

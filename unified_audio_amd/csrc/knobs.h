@@ -17,31 +17,18 @@ namespace qa {
     X(GEMM_LINEAR, "QA_GEMM_LINEAR", 1, "table-free K loop for ksize-1 layers")                                                  \
     X(GEMM_XCD, "QA_GEMM_XCD", 1, "XCD-aware tile order")                                                                        \
     X(GEMM_PANEL, "QA_GEMM_PANEL", 8, "conv_gemm tile order: column panels of this many tiles, row tiles fastest inside a panel (0: column tiles fastest over the whole row; 8: +4 % on N >= 4096 shapes, +1.2 % on H-Codec 2.0)") \
-    X(GEMM_GROUPED, "QA_GEMM_GROUPED", 0, "H-Codec 1.5: 1 = the two aggregator stacks as ONE grouped launch per layer op on one stream (measured: 147.1 ms against 143.5 for the default, the two stacks on two streams)") \
     X(ATT_DEBUG, "QA_ATT_DEBUG", 0, "attention_kernel debug bits: 1 always rescale, 2 extra barrier per tile, 4 wait for the prefetch at once") \
     X(SEANET_FUSED, "QA_SEANET_FUSED", 1, "fused conv0 + first SEANet residual block")                                           \
     X(MIMI_ROPE_WINDOW, "QA_MIMI_ROPE_WINDOW", 8192, "mimi streaming: positions covered by the RoPE table before the rolling window takes over (tests shrink it)") \
-    X(RVQ_LEGACY, "QA_RVQ_LEGACY", 0, "1: the single-launch RVQ search kernel instead of distance GEMM + pick")                   \
     X(LSTM_GRAPH, "QA_LSTM_GRAPH", 1, "replay the T step launches of an LSTM call from a cached hipGraph")                       \
-    X(LSTM_SPLIT, "QA_LSTM_SPLIT", 0, "1: two concurrent half-batch step chains (measured slower)")                              \
-    X(LSTM_GROUP_ROWS, "QA_LSTM_GROUP_ROWS", 0, "per-step LSTM kernel: batch rows per workgroup group (blockIdx.y); 0 = every workgroup serves all rows of the call. 16 halves the h_{t-1} slice a workgroup pulls at B = 32; results are bit-identical for every value") \
     X(LSTM_PERSISTENT, "QA_LSTM_PERSISTENT", -1, "persistent recurrence kernel: -1 auto (d >= 1536), 0 off, 1 on for every supported width") \
-    X(LSTM_PERSISTENT_U, "QA_LSTM_PERSISTENT_U", 0, "persistent recurrence: hidden units per workgroup (0: the fewest that fit the CU count; 8 halves the workgroups at d = 1024)") \
-    X(LSTM_XCD, "QA_LSTM_XCD", 1, "XCD-local LSTM recurrence for d = 512 / 768 (one launch, W_hh in the registers of every XCD's 32 CUs, sequences dealt to the XCDs, 32-member step barrier per XCD): 0 off (the per-step kernels; use it when several handles drive one device concurrently), 1 agent-scope hand-off forms, 2 XCD-local forms (h stores that stay in the XCD's L2; H-Codec 1.0: 42.7 against 43.3 ms)") \
-    X(LSTM_TEAM, "QA_LSTM_TEAM", 1, "team recurrence for d = 1024 (one launch: 4 teams of 64 workgroups, W_hh resident in registers, 8 sequences per team, agent-scope hand-offs; H-Codec 1.5 decoder: 134.1 -> 128.3 ms per step, profiles/r04_lstm_team_ab.txt): 0 = the per-step kernels (use it when several handles drive one device concurrently)") \
-    X(LSTM_CUS, "QA_LSTM_CUS", 0, "H-Codec 1.0 / 1.5 encode: CUs reserved (hipExtStreamCreateWithCUMask) for the encoder's LSTM step launches while the semantic encoder runs on the other CUs (0: off, everything on one stream)") \
+    X(LSTM_XCD, "QA_LSTM_XCD", 1, "XCD-local LSTM recurrence for d = 512 / 768 (one launch, W_hh in the registers of every XCD's 32 CUs, sequences dealt to the XCDs, 32-member step barrier per XCD): 0 off (the per-step kernels), 1 agent-scope hand-off forms, 2 XCD-local forms (h stores that stay in the XCD's L2; H-Codec 1.0: 42.7 against 43.3 ms)") \
+    X(LSTM_TEAM, "QA_LSTM_TEAM", 1, "team recurrence for d = 1024 (one launch: 4 teams of 64 workgroups, W_hh resident in registers, 8 sequences per team, agent-scope hand-offs; H-Codec 1.5 decoder: 134.1 -> 128.3 ms per step, profiles/r04_lstm_team_ab.txt): 0 = the per-step kernels") \
     X(LSTM_SPIN_LIMIT, "QA_LSTM_SPIN_LIMIT", 1 << 21, "persistent recurrence: polls of a barrier word before the barrier is declared broken") \
     X(LSTM_FAULT, "QA_LSTM_FAULT", 0, "1 (tests): the persistent kernel's barrier waits for a workgroup that does not exist, like a starved launch") \
     X(LM_GRAPH, "QA_LM_GRAPH", 0, "1: replay one captured decode step per token")                                                \
-    X(LM_UNFUSED, "QA_LM_UNFUSED", 0, "1: the per-op decode step (skinny GEMM + attention_decode kernels) instead of the fused one") \
-    X(LM_MFMA16, "QA_LM_MFMA16", 0, "1: narrow GEMV tiles on the 16x16x4 MFMA instead of the 4x4x1")                             \
-    X(LM_NT_QKV, "QA_LM_NT_QKV", 0, "column-tile width of the qkv GEMV (4 / 8 / 16; 0: lm_pick_nt)")                             \
-    X(LM_NT_O, "QA_LM_NT_O", 0, "column-tile width of the o_proj GEMV")                                                          \
-    X(LM_NT_GU, "QA_LM_NT_GU", 0, "column-tile width of the gate/up GEMV")                                                       \
-    X(LM_NT_DOWN, "QA_LM_NT_DOWN", 0, "column-tile width of the down GEMV")                                                      \
-    X(LM_MLP_FUSED, "QA_LM_MLP_FUSED", 1, "decode step: gate/up + SwiGLU + down of 16 activation columns per workgroup in one launch emitting K-slice partials, summed by a reduce launch (0: separate gate/up and down launches; 2: 8 columns per workgroup)") \
-    X(LM_ATT_SPLIT, "QA_LM_ATT_SPLIT", 0, "decode step: keys per workgroup of the single-query attention, at most 4 splits (0: 256)")  \
-    X(LM_CHAINS, "QA_LM_CHAINS", 0, "generate: number of concurrent chains of <= 32 sequences on internal streams (0: ceil(B / 32))")
+    X(LM_MLP_FUSED, "QA_LM_MLP_FUSED", 1, "decode step: gate/up + SwiGLU + down of 16 activation columns per workgroup in one launch emitting K-slice partials, summed by a reduce launch (0: separate gate/up and down launches)") \
+    X(LM_CHAINS, "QA_LM_CHAINS", 0, "generate: number of concurrent chains on internal streams (0: ceil(B / 64) - one chain serves up to 64 sequences, two row groups of 32 per launch; a count that would put more than 64 sequences into a chain is raised)")
 
 enum Knob {
 #define QA_KNOB_ENUM(id, name, def, doc) K_##id,

@@ -18,19 +18,11 @@
 namespace qa {
 int launch_assemble_prompt(float* x, const float* task_vec, const float* enroll_sos, const float* enroll_emb,
                            const float* mix_sos, const float* mix_emb, int B, int Ne, int Nm, int d, hipStream_t s);
-int launch_kv_store(const float* qkv, float* kc, float* vc, int B, int n, int pos0, int max_len, int d, hipStream_t s);
-int launch_embed(const long long* tok, const float* table, float* x, int B, int d, hipStream_t s);
-int launch_fill_i64(long long* p, long long v, int n, hipStream_t s);
-int launch_argmax(const float* logits, int B, int width, long long ld, int lo, long long* tok, long long* ids,
-                  long long ids_ld, int col, hipStream_t s);
 int launch_skinny_gemm(const float* x, long long ldx, const float* w, const float* bias, const float* gate,
                        long long ldg, const float* res, long long ldr, float* y, long long ldy, int M, int N, int K,
                        int act, hipStream_t s, float rms_eps, int dual);
 int launch_rope_kv(float* qkv, const float* cs, float* kc, float* vc, int B, int n, int H, int hd, int pos0, int max_len,
                    hipStream_t s);
-int launch_attention_decode(const float* q, long long ldq, const float* kc, const float* vc, long long kv_bstride,
-                            long long ldkv, float* out, long long ldo, int B, int H, int hd, int n_keys, float scale,
-                            hipStream_t s);
 
 }  // namespace qa
 
@@ -69,8 +61,8 @@ struct qa_lm {
     int device = 0;
     bool fused_ok = false;   // the shapes fit the fused decode step (otherwise the per-op decode path runs)
     bool mlp_fused = false;  // QA_LM_MLP_FUSED at create time: gate/up + SwiGLU + down as one launch + a reduce launch
-    int mlp_ac = 16;         // activation columns per workgroup of that launch (QA_LM_MLP_FUSED=2: 8)
-    int att_split = 256;     // keys per workgroup of the decode attention (QA_LM_ATT_SPLIT), at most 4 splits
+    int mlp_ac = 16;         // activation columns per workgroup of that launch (8 measured equal at B = 16, -4 % at B = 64: profiles/r03_lm_ab.txt)
+    int att_split = 256;     // keys per workgroup of the decode attention, at most 4 splits (flat between 256 and 384, worse below: same log)
     int nt_qkv = 0, nt_o = 0, nt_gu = 0, nt_down = 0;
     hipStream_t cap_stream = nullptr;
     std::vector<StepGraph> graphs;  // [2 * chain + phase]: phase 0 global, 1 semantic
@@ -113,6 +105,13 @@ int lm_linear(Ctx& c, const float* x, int64_t rows, const ConvW& w, float* y, co
     return launch_conv_gemm(p, c.stream);
 }
 
+// tile width of the head GEMV over a vocabulary slice of `width` entries (0: the slice does not tile)
+int head_nt(int width) {
+    int nt = lm_pick_nt(width);
+    while (nt >= 4 && width % nt) nt >>= 1;
+    return nt >= 4 ? nt : 0;
+}
+
 int build_lm(qa_lm* lm, const HostTable& tab) {
     const qa_lm_spec& sp = lm->spec;
     const int d = sp.hidden, V = vocab_of(sp), I = sp.intermediate;
@@ -121,19 +120,17 @@ int build_lm(qa_lm* lm, const HostTable& tab) {
     QA_REQUIRE(hd == 32 || hd == 64 || hd == 128, "lm spec: head_dim %d unsupported", hd);
     QA_REQUIRE(d % 32 == 0 && I % 32 == 0 && sp.feats_dim % 32 == 0, "lm spec: widths must be multiples of 32");
     // fused decode step: K of every GEMV a multiple of 256, every N a multiple of its tile width, rotary pairs inside a tile
-    auto tile_width = [](Knob k, int n) {  // QA_LM_NT_{QKV,O,GU,DOWN}: tuning override of the column-tile width
-        const int v = (int)knob(k);
-        return (v == 4 || v == 8 || v == 16) ? v : lm_pick_nt(n);
-    };
-    lm->nt_qkv = tile_width(K_LM_NT_QKV, 3 * d);
-    lm->nt_o = tile_width(K_LM_NT_O, d);
-    lm->nt_gu = tile_width(K_LM_NT_GU, 2 * I);
-    lm->nt_down = tile_width(K_LM_NT_DOWN, d);
+    lm->nt_qkv = lm_pick_nt(3 * d);
+    lm->nt_o = lm_pick_nt(d);
+    lm->nt_gu = lm_pick_nt(2 * I);
+    lm->nt_down = lm_pick_nt(d);
     lm->mlp_fused = knob(K_LM_MLP_FUSED) != 0 && lm_mlp_fused_supported(d, I, lm->nt_gu);
-    lm->mlp_ac = lm_mlp_ac();
-    lm->att_split = knob(K_LM_ATT_SPLIT) >= 32 ? (int)knob(K_LM_ATT_SPLIT) : 256;
     lm->fused_ok = lm_gemv_supported(d, I) && d % lm->nt_qkv == 0 && hd % lm->nt_qkv == 0 && d % lm->nt_o == 0 &&
-                   (2 * I) % lm->nt_gu == 0 && hd % 8 == 0 && knob(K_LM_UNFUSED) == 0;
+                   (2 * I) % lm->nt_gu == 0 && hd % 8 == 0 && head_nt(sp.global_size) && head_nt(sp.semantic_size);
+    // r05: the per-op decode step of round 1 (skinny GEMM + attention_decode kernels behind QA_LM_UNFUSED, the path a spec took when the
+    // fused step did not tile it) is gone - a spec the fused step cannot tile is refused here, with the reason
+    QA_REQUIRE(lm->fused_ok, "lm spec: the decode step needs hidden %% 256 == 0 (got %d), intermediate %% 256 == 0 (got %d), head_dim %% 8 == 0 and "
+               "global / semantic vocabulary sizes that are multiples of 4 (got %d / %d)", d, I, sp.global_size, sp.semantic_size);
     WeightStore& st = lm->store;
     bool ok = true;
     std::vector<std::pair<const float**, size_t>> pend;
@@ -285,7 +282,7 @@ struct SampleCfg {
     unsigned long long seed;
 };
 
-// one pass of the Llama body over `n` new positions per sequence, positions pos0..pos0+n-1 (prefill; per-op decode fallback)
+// one pass of the Llama body over `n` new positions per sequence, positions pos0..pos0+n-1 (the prefill)
 int lm_body(qa_lm* lm, Ctx& c, LMBuffers& b, int B, int n, int pos0, int max_len, bool skip_last_mlp) {
     const qa_lm_spec& sp = lm->spec;
     const int d = sp.hidden, H = sp.n_heads, hd = d / H;
@@ -307,12 +304,7 @@ int lm_body(qa_lm* lm, Ctx& c, LMBuffers& b, int B, int n, int pos0, int max_len
             }
             QA_TRY(launch_rope_kv(b.qkv, lm->rope, kc, vc, B, n, H, hd, pos0, max_len, c.stream));
             if (last) break;
-            if (n == 1)
-                QA_TRY(launch_attention_decode(b.qkv, 3 * d, kc, vc, (long long)max_len * d, d, b.att, d, B, H, hd, pos0 + 1,
-                                               scale, c.stream));
-            else
-                QA_TRY(launch_attention(b.qkv, 3 * d, kc, vc, d, b.att, d, B, n, pos0 + n, (long long)max_len * d, H, hd, scale,
-                                        1, c.stream));
+            QA_TRY(launch_attention(b.qkv, 3 * d, kc, vc, d, b.att, d, B, n, pos0 + n, (long long)max_len * d, H, hd, scale, 1, c.stream));
             QA_TRY(lm_linear(c, b.att, rows, L.o, b.x, b.x));
             if (dec && L.gate_up) {
                 QA_TRY(launch_skinny_gemm(b.x, d, L.gate_up, nullptr, nullptr, 0, nullptr, 0, b.u, L.gate.N, (int)rows, L.gate.N, d,
@@ -326,13 +318,6 @@ int lm_body(qa_lm* lm, Ctx& c, LMBuffers& b, int B, int n, int pos0, int max_len
         }
     }
     return QA_OK;
-}
-
-// tile width of the head GEMV over a vocabulary slice of `width` entries (0: the slice does not tile)
-int head_nt(int width) {
-    int nt = lm_pick_nt(width);
-    while (nt >= 4 && width % nt) nt >>= 1;
-    return nt >= 4 ? nt : 0;
 }
 
 // ONE decode step as 5 launches per layer + 2 (lm_decode.hip).  Everything step-dependent (position, ids column, RNG step) is read
@@ -464,7 +449,6 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
     const int max_len = L + G + 1 + S;
     QA_REQUIRE(max_len <= LM_MAX_POS, "generate: %d positions exceed max_position_embeddings %d", max_len, LM_MAX_POS);
     const int cap = (int)round_up(max_len, 64);  // cache row stride: shapes that round alike share their captured step graphs
-    const bool tiles = lm->fused_ok && head_nt(sp.global_size) && head_nt(sp.semantic_size);
     // A caller that is CAPTURING its stream into a hipGraph gets the plain single-chain launches on that stream only: no
     // internal streams, no capture of our own inside theirs (the multi-chain replay path would fail there where the eager path works).
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
@@ -474,12 +458,13 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
     }
     const bool capturing = cap_status == hipStreamCaptureStatusActive;
     int nc = (int)knob(K_LM_CHAINS);
-    if (nc <= 0) nc = tiles ? (int)ceil_div(B, LM_MAX_ROWS) : 1;  // r05: one chain serves up to 64 sequences (two row groups per launch)
+    if (nc <= 0) nc = (int)ceil_div(B, LM_MAX_ROWS);  // r05: one chain serves up to 64 sequences (two row groups per launch)
     if (capturing) nc = 1;
     nc = std::max(1, std::min(std::min(nc, B), LM_MAX_CHAINS));
+    if (ceil_div(B, nc) > LM_MAX_ROWS) nc = (int)ceil_div(B, LM_MAX_ROWS);  // a forced count (or a capturing caller) that would put > 64 sequences in a chain
+    QA_REQUIRE(!capturing || nc == 1, "generate: a caller that captures its stream can pass at most %d sequences per call (got %d)", LM_MAX_ROWS, B);
     const int cb = (int)ceil_div(B, nc);
     nc = (int)ceil_div(B, cb);
-    const bool fused = tiles && cb <= LM_MAX_ROWS;
     std::vector<Chain> chains(nc);
     for (int i = 0; i < nc; ++i) {
         chains[i].b0 = i * cb;
@@ -525,12 +510,12 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
 
     // ---- decode: G+1 global tokens (the last is fed to the cache but discarded), then S semantic tokens
     int pos = L;
-    const bool graphs = fused && !capturing && (multi || use_graphs());
+    const bool graphs = !capturing && (multi || use_graphs());
     auto phase = [&](int which, long long first_id, int steps, int lo, int width, int keep) -> int {
         const int ids_ld = keep;
         for (Chain& ch : chains)
             QA_TRY(launch_lm_phase_init(ch.b.tok, first_id, ch.B, ch.b.state, pos, which == 0, sc.seed, ch.b0, ch.s));
-        if (fused && graphs && steps > 0) {
+        if (graphs && steps > 0) {
             if ((int)lm->graphs.size() < 2 * nc) lm->graphs.resize(2 * nc);
             for (int i = 0; i < nc; ++i) {
                 Chain& ch = chains[i];
@@ -563,41 +548,10 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
             pos += steps;
             return QA_OK;
         }
-        if (fused) {
-            for (int st = 0; st < steps; ++st)
-                for (Chain& ch : chains)
-                    QA_TRY(fused_step(lm, ch.b, ch.B, lo, width, which == 0 ? ch.b.ids_g : ch.b.ids_s, ids_ld, keep, sc, ch.s, pos + st, st));
-            pos += steps;
-            return QA_OK;
-        }
-        for (int st = 0; st < steps; ++st, ++pos) {  // per-op decode step (QA_LM_UNFUSED, or a spec the fused step does not tile)
-            for (Chain& ch : chains) {
-                LMBuffers& b = ch.b;
-                long long* ids = which == 0 ? b.ids_g : b.ids_s;
-                c.stream = ch.s;
-                int rc = launch_embed(b.tok, lm->codec_emb, b.x, ch.B, d, ch.s);
-                if (rc == QA_OK) rc = lm_body(lm, c, b, ch.B, 1, pos, cap, false);
-                if (rc == QA_OK) {
-                    if (skinny_ok(ch.B, lm->head)) {
-                        rc = lm_linear(c, b.x, ch.B, lm->head, b.logits, nullptr, nullptr, width, lm->head.w + (size_t)lo * d, sp.rms_eps);
-                    } else {
-                        rc = launch_rmsnorm(b.x, lm->ones, b.hn, ch.B, d, sp.rms_eps, ch.s);
-                        if (rc == QA_OK) rc = lm_linear(c, b.hn, ch.B, lm->head, b.logits, nullptr, nullptr, width, lm->head.w + (size_t)lo * d);
-                    }
-                }
-                if (rc == QA_OK) {
-                    if (sc.do_sample) {
-                        rc = launch_lm_sample(b.logits, width, width, ch.B, lo, sc.top_k, sc.top_p, sc.temperature, 1, b.tok, ids, ids_ld, keep,
-                                              b.state, ch.s);
-                        if (rc == QA_OK) rc = launch_lm_advance(b.state, ch.s);
-                    } else {
-                        rc = launch_argmax(b.logits, ch.B, width, width, lo, b.tok, st < keep ? ids : nullptr, ids_ld, st, ch.s);
-                    }
-                }
-                c.stream = caller;
-                QA_TRY(rc);
-            }
-        }
+        for (int st = 0; st < steps; ++st)
+            for (Chain& ch : chains)
+                QA_TRY(fused_step(lm, ch.b, ch.B, lo, width, which == 0 ? ch.b.ids_g : ch.b.ids_s, ids_ld, keep, sc, ch.s, pos + st, st));
+        pos += steps;
         return QA_OK;
     };
     QA_TRY(phase(0, 0, G + 1, 3, sp.global_size, G));                            // llm_sft.py:137-164

@@ -8,7 +8,8 @@ enum { GM_QKV = 0, GM_GATEUP = 1, GM_RESID = 2, GM_HEAD = 3 };
 constexpr int LM_MAX_ROWS = 64;  // sequences one fused decode step serves: two row groups of 32 in every launch (lm_decode.hip, row_group)
 // device-side loop state (int words): position of the token being processed (= keys already cached), ids column, RNG step, seed
 // ST_SEQ0: index of the chain's first sequence inside the call (the sampler keys its Philox stream by the GLOBAL sequence index)
-enum { ST_POS = 0, ST_COL = 1, ST_STEP = 2, ST_SEQ0 = 3, ST_SEED_LO = 4, ST_SEED_HI = 5, ST_WORDS = 8 };
+// ST_TICKET: arrival counter of lm_pick_kernel's workgroups (the last arrival advances the state and clears it)
+enum { ST_POS = 0, ST_COL = 1, ST_STEP = 2, ST_SEQ0 = 3, ST_SEED_LO = 4, ST_SEED_HI = 5, ST_TICKET = 6, ST_WORDS = 8 };
 
 struct GemvArgs {
     // A operand: rows of x (or, with tok != nullptr, rows table[tok[m]] - the codec_embedding gather of the step's token)
@@ -50,7 +51,6 @@ int lm_pick_nt(int N);
 bool lm_gemv_supported(int hidden, int intermediate);  // kernel instances exist for these K
 int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s);
 bool lm_mlp_fused_supported(int d, int I, int nt_gu);
-int lm_mlp_ac();
 int launch_lm_mlp(const GemvArgs& a, int I, int ac, const float* wd, float* partial, const float* res, long long ldr, float* y, long long ldy,
                   hipStream_t s);
 int launch_lm_attn(const float* q, long long ldq, const float* kc, const float* vc, long long kv_bstride, long long ldkv,

@@ -476,9 +476,6 @@ int lm_pick_nt(int N) {
     return nt;
 }
 
-// QA_LM_MFMA16=1: narrow tiles on the 16x16x4 kernel too (A/B switch for tests and measurements)
-static bool narrow_on_4x4() { return knob(K_LM_MFMA16) == 0; }
-
 // 32-wide chunks per batch of the 16x16x4 kernel for a given K: the whole per-wave share when it is at most 8 chunks (K <= 2048)
 static int gemv_nb(int K) {
     const int nchunk = K / 256;
@@ -489,17 +486,18 @@ static int gemv_nb(int K) {
 template <int MODE, bool ATT, int NB>
 static int launch_gemv_nb(const GemvArgs& a, int nt, hipStream_t s) {
     const dim3 grid((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, LM_ROWS_PER_GROUP));  // y: row groups of 32 (M <= 64: one or two)
-    const bool m4 = narrow_on_4x4() && nt < 16;
+    // narrow tiles (NT = 8 / 4) run on the 4x4x1 MFMA, where every FMA is useful (the 16x16x4 form on duplicated columns measured equal:
+    // the matrix pipe is not what bounds the step)
 #define QA_GV(MT, NT) hipLaunchKernelGGL((lm_gemv_kernel<MT, NT, MODE, ATT, NB>), grid, dim3(512), 0, s, a)
 #define QA_G4(MT, C) hipLaunchKernelGGL((lm_gemv4_kernel<MT, C, MODE, ATT, 2 * NB>), grid, dim3(512), 0, s, a)
     if (a.M <= 16) {
         if (nt == 16) QA_GV(1, 16);
-        else if (nt == 8) { if (m4) QA_G4(1, 2); else QA_GV(1, 8); }
-        else { if (m4) QA_G4(1, 1); else QA_GV(1, 4); }
+        else if (nt == 8) QA_G4(1, 2);
+        else QA_G4(1, 1);
     } else {
         if (nt == 16) QA_GV(2, 16);
-        else if (nt == 8) { if (m4) QA_G4(2, 2); else QA_GV(2, 8); }
-        else { if (m4) QA_G4(2, 1); else QA_GV(2, 4); }
+        else if (nt == 8) QA_G4(2, 2);
+        else QA_G4(2, 1);
     }
 #undef QA_GV
 #undef QA_G4
@@ -716,7 +714,6 @@ __global__ __launch_bounds__(64) void lm_mlp_reduce_kernel(const float* __restri
 bool lm_mlp_fused_supported(int d, int I, int nt_gu) {
     return nt_gu == 16 && I % 16 == 0 && d % 128 == 0 && d <= 512 && (d == 256 || d == 512);
 }
-int lm_mlp_ac() { return knob(K_LM_MLP_FUSED) == 2 ? 8 : 16; }  // read when the weights are laid out (qa_lm_create) and at launch
 
 // a: x / ldx / w (gate-up decode layout, NT = 16) / M / K = d / d / rms_eps; wd: W_down in slice-major layout [I / 16][d][16];
 // partial: [I / 16][16 * MT][d] scratch; y = res + down(act)
@@ -726,9 +723,8 @@ int launch_lm_mlp(const GemvArgs& a, int I, int ac, const float* wd, float* part
     const int mt = a.M <= 16 ? 1 : 2;
     const int n_part = I / ac;
     const dim3 grid((unsigned)n_part, (unsigned)ceil_div(a.M, LM_ROWS_PER_GROUP));  // partial: [row group][n_part][16 mt][d]
-#define QA_MLP(MT, NB) \
-    if (ac == 16) hipLaunchKernelGGL((lm_mlp_kernel<MT, NB, 16>), grid, dim3(512), 0, s, a, wd, partial); \
-    else hipLaunchKernelGGL((lm_mlp_kernel<MT, NB, 8>), grid, dim3(512), 0, s, a, wd, partial)
+    QA_REQUIRE(ac == 16, "lm_mlp: %d activation columns per workgroup (only 16 is built)", ac);
+#define QA_MLP(MT, NB) hipLaunchKernelGGL((lm_mlp_kernel<MT, NB, 16>), grid, dim3(512), 0, s, a, wd, partial)
     if (a.d == 512) {
         if (mt == 1) { QA_MLP(1, 2); } else { QA_MLP(2, 2); }
     } else {
@@ -877,14 +873,19 @@ int launch_lm_attn(const float* q, long long ldq, const float* kc, const float* 
 
 // ------------------------------------------------------------------------------------------------
 // Greedy pick (llm.py:286 with the range mask of llm_sft.py:150-153 / :180-182 already applied by restricting output_head to the
-// slice): arg-max over the head kernel's per-tile maxima, first maximum wins.  One workgroup (so it can advance the loop state
-// without a race): tok[b] = lo + argmax; ids[b, col] = argmax for col < keep; pos++, col++, step++.
-__global__ __launch_bounds__(1024) void lm_pick_kernel(const float* __restrict__ pmax, const int* __restrict__ pidx, int n_tiles,
-                                                       int B, int lo, long long* __restrict__ tok, long long* __restrict__ ids,
-                                                       long long ids_ld, int keep, int* __restrict__ state, int col_arg) {
+// slice): arg-max over the head kernel's per-tile maxima, first maximum wins.  tok[b] = lo + argmax; ids[b, col] = argmax for col < keep;
+// pos++, col++, step++.  r05: ONE WAVE PER SEQUENCE, four sequences per workgroup (it was one workgroup walking the batch in rounds of 16
+// sequences: 5.3 us at 16 sequences, 15.6 us at 64 - four dependent round trips for 250 KB).  The loop state is advanced exactly once, by
+// the workgroup that draws the last arrival ticket: every workgroup reads `col` BEFORE it takes its ticket, so nobody can observe the
+// advanced state, and the next kernel of the stream sees it through the kernel boundary.
+constexpr int PICK_SEQS = 4;
+__global__ __launch_bounds__(64 * PICK_SEQS) void lm_pick_kernel(const float* __restrict__ pmax, const int* __restrict__ pidx, int n_tiles,
+                                                                 int B, int lo, long long* __restrict__ tok, long long* __restrict__ ids,
+                                                                 long long ids_ld, int keep, int* __restrict__ state, int col_arg) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = col_arg >= 0 ? col_arg : state[ST_COL];
-    for (int b = wave; b < B; b += 16) {
+    const int b = blockIdx.x * PICK_SEQS + wave;
+    if (b < B) {
         float best = -INFINITY;
         int bi = 0x7fffffff;
         for (int t = lane; t < n_tiles; t += 64) {
@@ -912,15 +913,20 @@ __global__ __launch_bounds__(1024) void lm_pick_kernel(const float* __restrict__
     }
     __syncthreads();
     if (tid == 0) {
-        state[ST_POS] += 1;
-        state[ST_COL] = col + 1;
-        state[ST_STEP] += 1;
+        const int ticket = atomicAdd(&state[ST_TICKET], 1);
+        if (ticket == (int)gridDim.x - 1) {  // the last workgroup to arrive: everybody has read col
+            state[ST_TICKET] = 0;
+            state[ST_POS] += 1;
+            state[ST_COL] = col + 1;
+            state[ST_STEP] += 1;
+        }
     }
 }
 
 int launch_lm_pick(const float* pmax, const int* pidx, int n_tiles, int B, int lo, long long* tok, long long* ids, long long ids_ld,
                    int keep, int* state, int col, hipStream_t s) {
-    hipLaunchKernelGGL(lm_pick_kernel, dim3(1), dim3(1024), 0, s, pmax, pidx, n_tiles, B, lo, tok, ids, ids_ld, keep, state, col);
+    hipLaunchKernelGGL(lm_pick_kernel, dim3((unsigned)ceil_div(B, PICK_SEQS)), dim3(64 * PICK_SEQS), 0, s, pmax, pidx, n_tiles, B, lo, tok, ids,
+                       ids_ld, keep, state, col);
     QA_LAUNCH_CHECK();
     return QA_OK;
 }
@@ -934,6 +940,7 @@ __global__ void lm_phase_init_kernel(long long* tok, long long first_id, int B, 
         state[ST_POS] = pos;
         state[ST_COL] = 0;
         state[ST_SEQ0] = seq0;
+        state[ST_TICKET] = 0;
         if (reset_step) {
             state[ST_STEP] = 0;
             state[ST_SEED_LO] = (int)seed_lo;

@@ -1,6 +1,7 @@
-// lm_kernels.hip - kernels specific to the UniSE AR-LM generate loop:
-// prompt assembly, KV-cache append, token embedding gather, range-restricted greedy arg-max, the skinny-M
-// weight-streaming GEMM used by every decode step, and single-query attention over the KV cache.
+// lm_kernels.hip - the UniSE AR-LM's prefill-side kernels: prompt assembly, RoPE + KV-cache append over a whole
+// prompt, and the skinny-M weight-streaming GEMM (per-item linears of at most 32 rows: tiny prompts here, BiCodec's d-vector / AdaLN
+// linears in bicodec.cpp).  The decode step lives in lm_decode.hip; the round-1 per-op decode kernels (embedding gather, arg-max,
+// single-query attention behind QA_LM_UNFUSED) were removed in round 5.
 #include "kernels.h"
 
 namespace qa {
@@ -49,106 +50,6 @@ int launch_assemble_prompt(float* x, const float* task_vec, const float* enroll_
     const long long total = (long long)B * L * (d / 4);
     hipLaunchKernelGGL(assemble_prompt_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, x, task_vec,
                        enroll_sos, enroll_emb, mix_sos, mix_emb, B, Ne, Nm, d);
-    QA_LAUNCH_CHECK();
-    return QA_OK;
-}
-
-// K / V parts of a fused [B*n, 3d] QKV buffer (RoPE already applied) -> caches [B, max_len, d] at positions pos0..
-__global__ __launch_bounds__(256) void kv_store_kernel(const float* __restrict__ qkv, float* __restrict__ kc,
-                                                       float* __restrict__ vc, int B, int n, int pos0, int max_len,
-                                                       int d) {
-    const int d4 = d >> 2;
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)B * n * d4) return;
-    const int c = (int)(gid % d4) * 4;
-    const long long row = gid / d4;
-    const int b = (int)(row / n), t = (int)(row % n);
-    const float* src = qkv + row * 3 * d + d + c;
-    const long long dst = ((long long)b * max_len + pos0 + t) * d + c;
-    *reinterpret_cast<float4*>(kc + dst) = *reinterpret_cast<const float4*>(src);
-    *reinterpret_cast<float4*>(vc + dst) = *reinterpret_cast<const float4*>(src + d);
-}
-
-int launch_kv_store(const float* qkv, float* kc, float* vc, int B, int n, int pos0, int max_len, int d, hipStream_t s) {
-    const long long total = (long long)B * n * (d / 4);
-    hipLaunchKernelGGL(kv_store_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, qkv, kc, vc, B, n, pos0,
-                       max_len, d);
-    QA_LAUNCH_CHECK();
-    return QA_OK;
-}
-
-__global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict__ tok, const float* __restrict__ table,
-                                                    float* __restrict__ x, int B, int d) {
-    const int d4 = d >> 2;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= B * d4) return;
-    const int b = gid / d4, c = (gid % d4) * 4;
-    *reinterpret_cast<float4*>(x + (long long)b * d + c) =
-        *reinterpret_cast<const float4*>(table + tok[b] * (long long)d + c);
-}
-int launch_embed(const long long* tok, const float* table, float* x, int B, int d, hipStream_t s) {
-    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)ceil_div((long long)B * (d / 4), 256)), dim3(256), 0, s, tok, table, x,
-                       B, d);
-    QA_LAUNCH_CHECK();
-    return QA_OK;
-}
-
-__global__ void fill_i64_kernel(long long* p, long long v, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-int launch_fill_i64(long long* p, long long v, int n, hipStream_t s) {
-    hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, p, v, n);
-    QA_LAUNCH_CHECK();
-    return QA_OK;
-}
-
-// Greedy sampling restricted to a vocabulary slice (llm_sft.py:150-153,180-182 + llm.py:286): logits [B, width] are the
-// head outputs of tokens lo..lo+width-1 only.  First maximum wins.  tok[b] = lo + argmax; ids[b*ids_ld + col] = argmax
-// (the offset-subtracted id the reference returns) when ids != nullptr.
-__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int width, long long ld, int lo,
-                                                     long long* __restrict__ tok, long long* __restrict__ ids,
-                                                     long long ids_ld, int col) {
-    __shared__ float sv[4];
-    __shared__ int si[4];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* row = logits + (long long)b * ld;
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int i = tid; i < width; i += 256) {
-        const float v = row[i];
-        if (v > best) {  // ascending i per thread: strict '>' keeps the first maximum
-            best = v;
-            bi = i;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float v2 = __shfl_xor(best, o, 64);
-        const int i2 = __shfl_xor(bi, o, 64);
-        if (v2 > best || (v2 == best && i2 < bi)) {
-            best = v2;
-            bi = i2;
-        }
-    }
-    if (lane == 0) {
-        sv[wave] = best;
-        si[wave] = bi;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
-                best = sv[w];
-                bi = si[w];
-            }
-        tok[b] = lo + bi;
-        if (ids) ids[(long long)b * ids_ld + col] = bi;
-    }
-}
-int launch_argmax(const float* logits, int B, int width, long long ld, int lo, long long* tok, long long* ids,
-                  long long ids_ld, int col, hipStream_t s) {
-    hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(256), 0, s, logits, width, ld, lo, tok, ids, ids_ld, col);
     QA_LAUNCH_CHECK();
     return QA_OK;
 }
@@ -313,123 +214,5 @@ int launch_rope_kv(float* qkv, const float* cs, float* kc, float* vc, int B, int
     return QA_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Single-query attention over the KV cache (decode step): one workgroup per (batch, head), 4 waves split the keys.
-// A wave covers 16 keys per iteration: lane = (key = lane >> 2, 16-float slice = lane & 3), i.e. 64 contiguous bytes per
-// lane and 256 contiguous bytes per key, scores are finished with two shuffles, softmax is online per wave, and the
-// four partial (m, l, o) states are merged through LDS.
-template <int HD, int NW>
-__global__ __launch_bounds__(NW * 64) void attention_decode_kernel(const float* __restrict__ q, long long ldq,
-                                                               const float* __restrict__ kc,
-                                                               const float* __restrict__ vc, long long kv_bstride,
-                                                               long long ldkv, float* __restrict__ out, long long ldo,
-                                                               int n_keys, float scale) {
-    constexpr int SL = HD / 4;  // floats per lane slice
-    __shared__ float s_m[NW], s_l[NW];
-    __shared__ float s_o[NW][HD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y, h = blockIdx.x;
-    const int kl = lane >> 2, sl = lane & 3;
-    const float* qp = q + (long long)b * ldq + h * HD + sl * SL;
-    float qv[SL];
-#pragma unroll
-    for (int i = 0; i < SL; i += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(qp + i);
-        qv[i] = t.x * scale; qv[i + 1] = t.y * scale; qv[i + 2] = t.z * scale; qv[i + 3] = t.w * scale;
-    }
-    const float* kb = kc + (long long)b * kv_bstride + h * HD + sl * SL;
-    const float* vb = vc + (long long)b * kv_bstride + h * HD + sl * SL;
-    float m_run = -INFINITY, l_run = 0.f;
-    float o[SL];
-#pragma unroll
-    for (int i = 0; i < SL; ++i) o[i] = 0.f;
-    for (int k0 = wave * 16; k0 < n_keys; k0 += NW * 16) {
-        const int key = k0 + kl;
-        const bool ok = key < n_keys;
-        const int kk = ok ? key : n_keys - 1;
-        float sdot = 0.f;
-        const float* kp = kb + (long long)kk * ldkv;
-#pragma unroll
-        for (int i = 0; i < SL; i += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(kp + i);
-            sdot = fmaf(qv[i], t.x, sdot);
-            sdot = fmaf(qv[i + 1], t.y, sdot);
-            sdot = fmaf(qv[i + 2], t.z, sdot);
-            sdot = fmaf(qv[i + 3], t.w, sdot);
-        }
-        sdot += __shfl_xor(sdot, 1, 64);
-        sdot += __shfl_xor(sdot, 2, 64);
-        const float sc = ok ? sdot : -INFINITY;
-        float tmax = sc;
-#pragma unroll
-        for (int of = 4; of < 64; of <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, of, 64));
-        const float m_new = fmaxf(m_run, tmax);  // the first tile of every wave with k0 < n_keys has a valid key
-        const float alpha = expf(m_run - m_new);
-        const float p = ok ? expf(sc - m_new) : 0.f;
-        float psum = p;
-#pragma unroll
-        for (int of = 4; of < 64; of <<= 1) psum += __shfl_xor(psum, of, 64);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-        const float* vp = vb + (long long)kk * ldkv;
-#pragma unroll
-        for (int i = 0; i < SL; i += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(vp + i);
-            o[i] = fmaf(p, t.x, o[i] * alpha);
-            o[i + 1] = fmaf(p, t.y, o[i + 1] * alpha);
-            o[i + 2] = fmaf(p, t.z, o[i + 2] * alpha);
-            o[i + 3] = fmaf(p, t.w, o[i + 3] * alpha);
-        }
-    }
-    // sum the 16 key-lanes that share a slice
-#pragma unroll
-    for (int i = 0; i < SL; ++i) {
-#pragma unroll
-        for (int of = 4; of < 64; of <<= 1) o[i] += __shfl_xor(o[i], of, 64);
-    }
-    if (lane < 4) {
-#pragma unroll
-        for (int i = 0; i < SL; ++i) s_o[wave][lane * SL + i] = o[i];
-        if (lane == 0) {
-            s_m[wave] = m_run;
-            s_l[wave] = l_run;
-        }
-    }
-    __syncthreads();
-    if (tid < HD) {
-        float m = s_m[0];
-        for (int w = 1; w < NW; ++w) m = fmaxf(m, s_m[w]);
-        float l = 0.f, acc = 0.f;
-        for (int w = 0; w < NW; ++w) {
-            const float f = (s_m[w] == -INFINITY) ? 0.f : expf(s_m[w] - m);
-            l += s_l[w] * f;
-            acc += s_o[w][tid] * f;
-        }
-        out[(long long)b * ldo + h * HD + tid] = acc / l;
-    }
-}
-
-int launch_attention_decode(const float* q, long long ldq, const float* kc, const float* vc, long long kv_bstride,
-                            long long ldkv, float* out, long long ldo, int B, int H, int hd, int n_keys, float scale,
-                            hipStream_t s) {
-    QA_REQUIRE(n_keys >= 1, "attention_decode: empty cache");
-    switch (hd) {
-        case 64:
-            hipLaunchKernelGGL((attention_decode_kernel<64, 16>), dim3(H, B), dim3(1024), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, out,
-                               ldo, n_keys, scale);
-            break;
-        case 128:
-            hipLaunchKernelGGL((attention_decode_kernel<128, 16>), dim3(H, B), dim3(1024), 0, s, q, ldq, kc, vc, kv_bstride, ldkv,
-                               out, ldo, n_keys, scale);
-            break;
-        case 32:
-            hipLaunchKernelGGL((attention_decode_kernel<32, 16>), dim3(H, B), dim3(1024), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, out,
-                               ldo, n_keys, scale);
-            break;
-        default: set_error("attention_decode: head_dim=%d unsupported", hd); return QA_ERR_UNSUPPORTED;
-    }
-    QA_LAUNCH_CHECK();
-    return QA_OK;
-}
 
 }  // namespace qa

@@ -42,21 +42,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int MT, int NI>
 __global__ __launch_bounds__(512) void lstm_step_kernel(const float* __restrict__ xw, const float* __restrict__ w_hh,
                                                         float* __restrict__ h_out, float* __restrict__ c_state, int B,
-                                                        int T, int d, int t, int rows) {
+                                                        int T, int d, int t) {
     __shared__ float part[8][MT][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16;  // first permuted gate row of this workgroup
     const int li = lane & 15, kq = lane >> 4;
-    // QA_LSTM_GROUP_ROWS: gridDim.y groups of `rows` batch rows each - a workgroup then pulls only its group's slice of h_{t-1}
-    // (rows x d x 4 bytes instead of B x d x 4); a row's arithmetic does not depend on the grouping (bit-identical)
-    if (rows > 0) {
-        const int b0 = blockIdx.y * rows;
-        xw += (long long)b0 * T * 4 * d;
-        h_out += (long long)b0 * T * d;
-        c_state += (long long)b0 * d;
-        B = min(rows, B - b0);
-    }
-
     f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -141,9 +131,8 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const float* __restrict_
 }
 
 template <int MT>
-static void launch_step(int ni, dim3 grid, hipStream_t s, const float* xw, const float* w, float* h, float* c, int bn, int T, int d, int t,
-                        int rows) {
-#define QA_LS(NI) hipLaunchKernelGGL((lstm_step_kernel<MT, NI>), grid, dim3(512), 0, s, xw, w, h, c, bn, T, d, t, rows)
+static void launch_step(int ni, dim3 grid, hipStream_t s, const float* xw, const float* w, float* h, float* c, int bn, int T, int d, int t) {
+#define QA_LS(NI) hipLaunchKernelGGL((lstm_step_kernel<MT, NI>), grid, dim3(512), 0, s, xw, w, h, c, bn, T, d, t)
     switch (ni) {
         case 1: QA_LS(1); break;
         case 2: QA_LS(2); break;
@@ -156,54 +145,26 @@ static void launch_step(int ni, dim3 grid, hipStream_t s, const float* xw, const
 #undef QA_LS
 }
 
-// QA_LSTM_GROUP_ROWS = r > 0: the batch rows of a step launch are dealt to ceil(bn / r) workgroup groups (blockIdx.y)
-static int lstm_group_rows(int bn) {
-    const int r = (int)knob(K_LSTM_GROUP_ROWS);
-    return (r > 0 && r < bn) ? std::min(r, 64) : 0;
-}
-
 // One chain of T dependent step launches for batch rows [0, bn) of the given buffers.
 static void lstm_chain(const float* xw_b, const float* w_hh_ug, float* h_b, float* c_b, int bn, int T, int d, int t, hipStream_t s) {
     const int ni = (d % 128 == 0) ? d / 128 : 0;
-    const int rows = lstm_group_rows(bn);  // 0: one group of all bn rows
-    const int mt = (int)ceil_div(rows ? rows : bn, 16);
-    const dim3 grid(d / 4, rows ? (unsigned)ceil_div(bn, rows) : 1u);
+    const int mt = (int)ceil_div(bn, 16);
+    const dim3 grid(d / 4);
     switch (mt) {
-        case 1: launch_step<1>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t, rows); break;
-        case 2: launch_step<2>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t, rows); break;
-        case 3: launch_step<3>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t, rows); break;
-        default: launch_step<4>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t, rows); break;
+        case 1: launch_step<1>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
+        case 2: launch_step<2>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
+        case 3: launch_step<3>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
+        default: launch_step<4>(ni, grid, s, xw_b, w_hh_ug, h_b, c_b, bn, T, d, t); break;
     }
 }
 
-// A step is latency-bound (kernel floor + one dependent round trip for h_{t-1}), not throughput-bound, and the batch rows are
-// independent recurrences: with QA_LSTM_SPLIT=1 the batch is cut in two halves whose step chains run concurrently on two streams
-// (fork / join with events), each step kernel carrying half the rows (MT = 1 instead of 2).  Measured on MI355X (H-Codec 1.5,
-// 32 x 10 s): the half-row kernels take 7.3 / 4.7 us (d = 1024 / 512) against 9.8 / 6.0 us for the whole batch - the two chains
-// overlap too little to pay for that (147.4 vs 144.9 ms per step), so one chain stays the default.
-static int lstm_launch_steps(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d, hipStream_t s,
-                             hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
-    const bool split_ok = knob(K_LSTM_SPLIT) != 0;
+// The step chains of a call: batches above 64 rows as consecutive chains of 64 (MT <= 4).  (r02: two concurrent half-batch chains on two
+// streams were measured and lost, 147.4 vs 144.9 ms per H-Codec 1.5 step - DESIGN.md "measured and rejected".)
+static int lstm_launch_steps(const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T, int d, hipStream_t s) {
     for (int b0 = 0; b0 < B; b0 += 64) {
         const int bn = std::min(64, B - b0);
-        const float* xw_b = xw + (long long)b0 * T * 4 * d;
-        float* h_b = h_out + (long long)b0 * T * d;
-        float* c_b = c_state + (long long)b0 * d;
-        const bool split = split_ok && side && bn >= 32;
-        const int h0 = split ? (bn / 2 + 15) / 16 * 16 : bn;  // first half, a whole number of 16-row tiles
-        if (split) {
-            QA_HIP(hipEventRecord(ev_fork, s));
-            QA_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-        }
-        for (int t = 0; t < T; ++t) {
-            lstm_chain(xw_b, w_hh_ug, h_b, c_b, h0, T, d, t, s);
-            if (split)
-                lstm_chain(xw_b + (long long)h0 * T * 4 * d, w_hh_ug, h_b + (long long)h0 * T * d, c_b + (long long)h0 * d, bn - h0, T, d, t, side);
-        }
-        if (split) {
-            QA_HIP(hipEventRecord(ev_join, side));
-            QA_HIP(hipStreamWaitEvent(s, ev_join, 0));
-        }
+        for (int t = 0; t < T; ++t)
+            lstm_chain(xw + (long long)b0 * T * 4 * d, w_hh_ug, h_out + (long long)b0 * T * d, c_state + (long long)b0 * d, bn, T, d, t, s);
         QA_LAUNCH_CHECK();
     }
     return QA_OK;
@@ -612,6 +573,7 @@ struct LstmCall {
     unsigned launches = 0;  // in-launch recurrences this call issued
     unsigned pending = 0;   // ... of which not yet behind a host synchronisation of the call's stream
     bool failed = false;    // an observed synchronisation found the error word set
+    bool counted = false;   // this call is one of LstmPersistentDev::inflight_calls (it has an in-launch recurrence behind no host sync yet)
     int dev = -1, slot = -1;
 };
 constexpr int LSTM_ERR_POOL = 64;  // error words (= concurrent model-graph calls) per device; further calls share the device word
@@ -623,6 +585,12 @@ struct LstmPersistentDev {
     int cus = 0, next = 0;
     unsigned long long launches = 0;  // persistent launches so far on this device (diagnostics)
     bool degraded = false;            // a barrier timed out on this device: the auto mode stops choosing the persistent kernel
+    // r05, co-residency ticket: model-graph calls that have launched an in-launch recurrence and not yet synchronised behind it.  The
+    // in-launch kernels need (nearly) the whole device resident at once, so a launch that finds ANOTHER call's recurrence possibly still
+    // running takes the per-step kernels at once (`diverted`) instead of starving that kernel's barrier and paying the 2^21-poll time-out
+    // plus a re-run (VERDICT r04 item 8 / ADVICE r04).  Conservative: a call counts until its own host synchronisation.
+    int inflight_calls = 0;
+    unsigned long long diverted = 0;
 };
 LstmPersistentDev g_lstm_p[16];
 std::mutex g_lstm_mu;  // guards the persistent-device table and the step-graph cache
@@ -642,6 +610,22 @@ void lstm_count_launch(LstmPersistentDev& P, int dev) {
     if (t_lstm_call && t_lstm_call->dev == dev) {
         ++t_lstm_call->launches;
         ++t_lstm_call->pending;
+        if (!t_lstm_call->counted) {
+            t_lstm_call->counted = true;
+            ++P.inflight_calls;
+        }
+    }
+}
+// another model-graph call of this device has an in-launch recurrence that may still be running (g_lstm_mu held)
+bool lstm_other_in_flight(const LstmPersistentDev& P, int dev) {
+    const int own = (t_lstm_call && t_lstm_call->dev == dev && t_lstm_call->counted) ? 1 : 0;
+    return P.inflight_calls - own > 0;
+}
+void lstm_call_settled(LstmPersistentDev& P, LstmCall* c) {  // the call's stream was synchronised on the host: nothing of it runs any more
+    c->pending = 0;
+    if (c->counted) {
+        c->counted = false;
+        --P.inflight_calls;
     }
 }
 }  // namespace
@@ -685,9 +669,6 @@ static int launch_lstm_persistent(const float* xw, const float* w_hh_ug, float* 
     // U hidden units per workgroup: the fewest that keep d / U workgroups (a multiple of the 8 barrier groups) <= CU count
     int U = 1;
     while (U <= 8 && (d % U || d / U > P.cus || (d / U) % 8)) ++U;
-    // QA_LSTM_PERSISTENT_U: more units per workgroup than necessary (fewer workgroups: a cheaper barrier, more MFMA work each)
-    const int u_force = (int)knob(K_LSTM_PERSISTENT_U);
-    if (u_force > U && u_force <= 8 && d % u_force == 0 && (d / u_force) % 8 == 0) U = u_force;
     const int NT = (4 * U + 15) / 16;
     if (U > 8 || NT > 2 || (NT == 1 && d == 1536)) return QA_OK;
     // QA_LSTM_FAULT (tests): the barrier waits for one workgroup more than exists, i.e. what a starved launch looks like
@@ -836,7 +817,7 @@ void lstm_call_note_sync() {
         *w = 0u;
         c->failed = true;
     }
-    c->pending = 0;
+    lstm_call_settled(P, c);
 }
 
 int lstm_call_end(void* ticket, hipStream_t s, bool* failed) {
@@ -860,12 +841,35 @@ int lstm_call_end(void* ticket, hipStream_t s, bool* failed) {
         if (knob(K_LSTM_FAULT) == 0) P.degraded = true;  // an injected fault (tests) says nothing about the device
         *failed = true;
     }
-    if (c->slot >= 0) P.pool_busy &= ~(1ull << c->slot);
+    if (st == QA_OK) {
+        lstm_call_settled(P, c);
+        if (c->slot >= 0) P.pool_busy &= ~(1ull << c->slot);
+    }
+    // a FAILED synchronisation: the recurrence may still be running and could write a word the next call would be handed -
+    // the slot stays busy (leaked: 64 per device) and the call stays counted as in flight, so later launches keep to the per-step kernels
     delete c;
     return st;
 }
 
 void lstm_force_per_step(bool on) { t_lstm_per_step = on; }
+
+}  // namespace qa
+// diagnostics (tests): out[0] in-launch recurrences launched so far on `device`, out[1] calls with one possibly still in flight,
+// out[2] launches diverted to the per-step kernels because another call's recurrence was in flight, out[3] degraded flag
+extern "C" int qa_debug_lstm_stats(int32_t device, int64_t* out) {
+    if (!out || device < 0 || device >= 16) {
+        qa::set_error("qa_debug_lstm_stats: bad argument");
+        return QA_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lock(qa::g_lstm_mu);
+    const qa::LstmPersistentDev& P = qa::g_lstm_p[device];
+    out[0] = (int64_t)P.launches;
+    out[1] = P.inflight_calls;
+    out[2] = (int64_t)P.diverted;
+    out[3] = P.degraded ? 1 : 0;
+    return QA_OK;
+}
+namespace qa {
 
 // The T step launches of one call as a hipGraph: captured once per (buffers, shape) - the model graphs re-use the same arena
 // addresses call after call - and replayed, so the host issues one graph launch instead of T kernel launches (eager launches go
@@ -873,14 +877,13 @@ void lstm_force_per_step(bool on) { t_lstm_per_step = on; }
 namespace {
 struct LstmGraph {
     const void *xw, *w, *h, *c;
-    int B, T, d, device, split;
+    int B, T, d, device;
     hipGraph_t graph;
     hipGraphExec_t exec;
     unsigned long long stamp;
 };
 std::vector<LstmGraph> g_lstm_graphs;
-hipStream_t g_lstm_cap[16] = {}, g_lstm_side[16] = {}, g_lstm_cap_side[16] = {};
-hipEvent_t g_lstm_ev[16][2] = {};
+hipStream_t g_lstm_cap[16] = {};
 unsigned long long g_lstm_clock = 0;
 constexpr size_t LSTM_GRAPH_CACHE = 24;
 }  // namespace
@@ -893,8 +896,10 @@ int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_st
     QA_HIP(hipGetDevice(&dev));
     QA_REQUIRE(dev >= 0 && dev < 16, "lstm: device index %d out of range", dev);
     std::lock_guard<std::mutex> lock(g_lstm_mu);
-    if (eager) return lstm_launch_steps(xw, w_hh_ug, h_out, c_state, B, T, d, s, nullptr, nullptr, nullptr);
-    {
+    if (eager) return lstm_launch_steps(xw, w_hh_ug, h_out, c_state, B, T, d, s);
+    if (lstm_other_in_flight(g_lstm_p[dev], dev)) {
+        ++g_lstm_p[dev].diverted;  // another handle's in-launch recurrence may be running: no second whole-device kernel beside it
+    } else {
         bool done = false;
         QA_TRY(launch_lstm_xcd(xw, w_hh_ug, h_out, c_state, B, T, d, s, dev, &done));
         if (done) return QA_OK;
@@ -903,25 +908,15 @@ int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_st
         QA_TRY(launch_lstm_persistent(xw, w_hh_ug, h_out, c_state, B, T, d, s, dev, &done));
         if (done) return QA_OK;
     }
-    if (!g_lstm_side[dev]) {
-        QA_HIP(hipStreamCreateWithFlags(&g_lstm_side[dev], hipStreamNonBlocking));
-        QA_HIP(hipStreamCreateWithFlags(&g_lstm_cap_side[dev], hipStreamNonBlocking));
-        QA_HIP(hipEventCreateWithFlags(&g_lstm_ev[dev][0], hipEventDisableTiming));
-        QA_HIP(hipEventCreateWithFlags(&g_lstm_ev[dev][1], hipEventDisableTiming));
-    }
-    hipStream_t side = serial_mode() ? nullptr : g_lstm_side[dev];  // qa_set_serial(1): every kernel alone on the device
-    if (!use_graph || T < 8) return lstm_launch_steps(xw, w_hh_ug, h_out, c_state, B, T, d, s, side, g_lstm_ev[dev][0], g_lstm_ev[dev][1]);
+    if (!use_graph || T < 8) return lstm_launch_steps(xw, w_hh_ug, h_out, c_state, B, T, d, s);
     LstmGraph* hit = nullptr;
-    const int split_tag = (side ? 1 : 0) | ((int)std::max<long long>(0, std::min<long long>(knob(K_LSTM_GROUP_ROWS), 64)) << 1);
     for (LstmGraph& g : g_lstm_graphs)
-        if (g.xw == xw && g.w == w_hh_ug && g.h == h_out && g.c == c_state && g.B == B && g.T == T && g.d == d && g.device == dev &&
-            g.split == split_tag)
+        if (g.xw == xw && g.w == w_hh_ug && g.h == h_out && g.c == c_state && g.B == B && g.T == T && g.d == d && g.device == dev)
             hit = &g;
     if (!hit) {
         if (!g_lstm_cap[dev]) QA_HIP(hipStreamCreateWithFlags(&g_lstm_cap[dev], hipStreamNonBlocking));
         QA_HIP(hipStreamBeginCapture(g_lstm_cap[dev], hipStreamCaptureModeThreadLocal));
-        const int st = lstm_launch_steps(xw, w_hh_ug, h_out, c_state, B, T, d, g_lstm_cap[dev], side ? g_lstm_cap_side[dev] : nullptr,
-                                         g_lstm_ev[dev][0], g_lstm_ev[dev][1]);
+        const int st = lstm_launch_steps(xw, w_hh_ug, h_out, c_state, B, T, d, g_lstm_cap[dev]);
         hipGraph_t graph = nullptr;
         const hipError_t e = hipStreamEndCapture(g_lstm_cap[dev], &graph);
         if (st != QA_OK) {
@@ -939,7 +934,7 @@ int launch_lstm(const float* xw, const float* w_hh_ug, float* h_out, float* c_st
             (void)hipGraphDestroy(g_lstm_graphs[lru].graph);
             g_lstm_graphs.erase(g_lstm_graphs.begin() + (long)lru);
         }
-        g_lstm_graphs.push_back(LstmGraph{xw, w_hh_ug, h_out, c_state, B, T, d, dev, split_tag, graph, exec, 0});
+        g_lstm_graphs.push_back(LstmGraph{xw, w_hh_ug, h_out, c_state, B, T, d, dev, graph, exec, 0});
         hit = &g_lstm_graphs.back();
     }
     hit->stamp = ++g_lstm_clock;

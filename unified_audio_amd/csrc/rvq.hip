@@ -228,6 +228,9 @@ __global__ __launch_bounds__(256) void rvq_lookup_kernel(const long long* __rest
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int q = 0; q < Q; ++q) {
         long long idx = indices[v * Q + q];
+        // -1 = a DROPPED code: upstream's get_codes_from_indices masks it to a zero vector (vector_quantize_pytorch residual_vq.py:
+        // `mask = indices == -1 ... all_codes.masked_fill(mask, 0.)`; the quantize-dropout convention) - the stage contributes nothing
+        if (idx == -1) continue;
         idx = idx < 0 ? 0 : (idx >= K ? K - 1 : idx);  // memory safety only; callers validate
         const float4 e = *reinterpret_cast<const float4*>(cb + ((long long)q * K + idx) * D + c);
         acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w;
@@ -257,7 +260,7 @@ int launch_rvq_search(const float* x, long long n_vec, const float* codebooks, c
     QA_REQUIRE(D % 8 == 0 && D >= 8, "rvq_search: D=%d must be a multiple of 8", D);
     QA_REQUIRE(Q >= 1 && K >= 1, "rvq_search: Q=%d K=%d", Q, K);
     if (n_vec <= 0) return QA_OK;
-    if (rvq_gemm_ok(K, D) && knob(K_RVQ_LEGACY) == 0) {
+    if (rvq_gemm_ok(K, D)) {
         QA_REQUIRE(scratch != nullptr, "rvq_search: the GEMM path needs rvq_scratch_floats() floats of workspace");
         const long long ch = std::min(n_vec, RVQ_CHUNK);
         const int ng = (K + 31) / 32;

@@ -313,7 +313,11 @@ class Codec(torch.nn.Module):
     @torch.no_grad()
     def decode(self, acoustic_codes: torch.Tensor, semantic_codes: torch.Tensor, token_lengths: Optional[torch.Tensor] = None):
         """codec.py:178-187.  int64 [B, nq, N25] x2 -> wav [B, N25 * 2 * hop].  H-Codec 1.5 (codec_adaptive.py:181-199):
-        length-injected codes [B, nq, G] (or plain codes + token_lengths [B, G])."""
+        length-injected codes [B, nq, G] (or plain codes + token_lengths [B, G]).
+        Codes: -1 = dropped (zero vector, as upstream's ResidualVQ masks it; 1.0 / 2.0 only - in the 1.5 wire format negative values carry
+        the group lengths).  Any other value outside [0, codebook_size) raises IndexError like F.embedding - AFTER the decode has run on
+        clamped indices (r04: the counter is read behind the decode's own host synchronisation, so the failing path costs a full decode;
+        `check_codes=False` skips the check)."""
         self._require_loaded()
         if self.spec.adaptive:
             return self._decode_adaptive(acoustic_codes, semantic_codes, token_lengths)
@@ -323,7 +327,8 @@ class Codec(torch.nn.Module):
                                            f"{tuple(acoustic_codes.shape)} / {tuple(semantic_codes.shape)}")
         ac = acoustic_codes.to(device=self.device, dtype=torch.int64).contiguous()
         sc = semantic_codes.to(device=self.device, dtype=torch.int64).contiguous()
-        pending = self._check_range_begin((ac, sc), self.spec.codebook_size)
+        # -1 is legal: a dropped code, masked to a zero vector by the third-party get_output_from_indices (INTEGRATION.md "Edge semantics")
+        pending = self._check_range_begin((ac, sc), self.spec.codebook_size, lo=-1)
         B, _, N = ac.shape
         wav = torch.empty((B, N * self.spec.dec_upsample * self.spec.hop), dtype=torch.float32, device=self.device)
         _lib.check(self._lib.qa_hcodec_decode(self._handle, ac.data_ptr(), sc.data_ptr(), B, N, wav.data_ptr(),
