@@ -18,8 +18,8 @@ def _components(device):
     fx = qa.SSLFeatureExtractor(qa.SSLSpec(**{f: getattr(sspec, f) for f in sspec.__dataclass_fields__}), device=device)
     fx.load_state_dict(S.synth_state_dict(4, sspec, "wavlm"))
     lspec = L.LMSpec(hidden=256, n_layers=2, n_heads=4, global_size=64, semantic_size=128, feats_dim=96)
-    lm = qa.LLM_SFT(feats_dim=96, llm_base_config=dict(global_size=64, semantic_size=128, hidden_size=128, num_layers=2,
-                                                       num_attention_heads=2), device=device)
+    lm = qa.LLM_SFT(feats_dim=96, llm_base_config=dict(global_size=64, semantic_size=128, hidden_size=256, num_layers=2,
+                                                       num_attention_heads=4), device=device)
     lm.load_state_dict(L.lm_state_dict(8, lspec))
     return fx, lm
 

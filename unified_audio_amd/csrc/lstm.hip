@@ -573,6 +573,7 @@ struct LstmCall {
     unsigned launches = 0;  // in-launch recurrences this call issued
     unsigned pending = 0;   // ... of which not yet behind a host synchronisation of the call's stream
     bool failed = false;    // an observed synchronisation found the error word set
+    bool fault_injected = false;  // QA_LSTM_FAULT was set when one of its recurrences was LAUNCHED (tests): its failure says nothing about the device
     bool counted = false;   // this call is one of LstmPersistentDev::inflight_calls (it has an in-launch recurrence behind no host sync yet)
     int dev = -1, slot = -1;
 };
@@ -610,6 +611,7 @@ void lstm_count_launch(LstmPersistentDev& P, int dev) {
     if (t_lstm_call && t_lstm_call->dev == dev) {
         ++t_lstm_call->launches;
         ++t_lstm_call->pending;
+        if (knob(K_LSTM_FAULT) != 0) t_lstm_call->fault_injected = true;
         if (!t_lstm_call->counted) {
             t_lstm_call->counted = true;
             ++P.inflight_calls;
@@ -838,7 +840,7 @@ int lstm_call_end(void* ticket, hipStream_t s, bool* failed) {
     volatile unsigned* w = c->err_host ? c->err_host : (P.err_host ? P.err_host + LSTM_ERR_POOL : nullptr);
     if (st == QA_OK && c->launches && ((w && *w != 0u) || c->failed)) {
         if (w) *w = 0u;
-        if (knob(K_LSTM_FAULT) == 0) P.degraded = true;  // an injected fault (tests) says nothing about the device
+        if (!c->fault_injected) P.degraded = true;  // an injected fault (tests; recorded at LAUNCH time) says nothing about the device
         *failed = true;
     }
     if (st == QA_OK) {
