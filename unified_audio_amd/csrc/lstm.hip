@@ -505,18 +505,20 @@ __global__ __launch_bounds__(NW * 64, 1) void lstm_team_kernel(const float* __re
             __syncthreads();
             if (!s_ok) break;
             asm volatile("" ::: "memory");
-            f32x4 hv[F4];
+            {
+                f32x4 hv[F4];
 #pragma unroll
-            for (int i = 0; i < F4; ++i) {
-                const int f = tid + i * NW * 64, sq = f / (D / 4), sc4 = f % (D / 4);
-                hv[i] = lstm_load_sc1_b128(h_out + ((long long)(team + n_teams * min(sq, nq - 1)) * T + (t - 1)) * D + 4 * sc4);
-            }
+                for (int i = 0; i < F4; ++i) {
+                    const int f = tid + i * NW * 64, sq = f / (D / 4), sc4 = f % (D / 4);
+                    hv[i] = lstm_load_sc1_b128(h_out + ((long long)(team + n_teams * min(sq, nq - 1)) * T + (t - 1)) * D + 4 * sc4);
+                }
 #pragma unroll
-            for (int i = 0; i < F4; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[i])::"memory");
+                for (int i = 0; i < F4; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[i])::"memory");
 #pragma unroll
-            for (int i = 0; i < F4; ++i) {
-                const int f = tid + i * NW * 64;
-                *reinterpret_cast<f32x4*>(&s_h[f / (D / 4)][4 * (f % (D / 4))]) = hv[i];
+                for (int i = 0; i < F4; ++i) {
+                    const int f = tid + i * NW * 64;
+                    *reinterpret_cast<f32x4*>(&s_h[f / (D / 4)][4 * (f % (D / 4))]) = hv[i];
+                }
             }
             __syncthreads();
 #pragma unroll
@@ -741,7 +743,7 @@ static int launch_lstm_xcd(const float* xw, const float* w_hh_ug, float* h_out, 
 }
 
 // QA_LSTM_TEAM: d = 1024 on 4 teams of 64 workgroups - see lstm_team_kernel; *done as above
-template <int D, int PT>
+template <int D, int PT, int NW>
 static int launch_lstm_team_t(LstmPersistentDev& P, int dev, const float* xw, const float* w_hh_ug, float* h_out, float* c_state, int B, int T,
                               hipStream_t s) {
     constexpr int SG = 2;
@@ -750,14 +752,14 @@ static int launch_lstm_team_t(LstmPersistentDev& P, int dev, const float* xw, co
     const int dyn = 96 * 1024;  // s_h (4 SG sequences x (D + 4) floats: 33 / 49 KB) + padding: with the static 16 KB one workgroup per CU
     static_assert(4 * SG * (D + 4) * 4 <= 96 * 1024, "lstm_team: h staging does not fit the dynamic segment");
     const int fault = knob(K_LSTM_FAULT) ? 1 : 0;
-    QA_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(lstm_team_kernel<D, 8, PT, SG>), dyn));
+    QA_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(lstm_team_kernel<D, NW, PT, SG>), dyn));
     const int per_launch = 4 * SG * n_teams;
     for (int b0 = 0; b0 < B; b0 += per_launch) {
         const int bn = std::min(per_launch, B - b0);
         unsigned* sy = P.sync + (size_t)P.next * SY_WORDS * SY_STRIDE;
         P.next = (P.next + 1) % LSTM_SYNC_RING;
         QA_HIP(hipMemsetAsync(sy, 0, sizeof(unsigned) * SY_WORDS * SY_STRIDE, s));
-        hipLaunchKernelGGL((lstm_team_kernel<D, 8, PT, SG>), dim3((unsigned)(n_teams * PT)), dim3(512), dyn, s, xw + (long long)b0 * T * 4 * D, w_hh_ug,
+        hipLaunchKernelGGL((lstm_team_kernel<D, NW, PT, SG>), dim3((unsigned)(n_teams * PT)), dim3(NW * 64), dyn, s, xw + (long long)b0 * T * 4 * D, w_hh_ug,
                            h_out + (long long)b0 * T * D, c_state + (long long)b0 * D, bn, T, sy, n_teams, fault, lstm_err_word(P, dev), spin_limit);
         QA_LAUNCH_CHECK();
         lstm_count_launch(P, dev);
@@ -769,12 +771,14 @@ static int launch_lstm_team(const float* xw, const float* w_hh_ug, float* h_out,
                             bool* done) {
     *done = false;
     LstmPersistentDev& P = g_lstm_p[dev];
-    // d = 1536 (H-Codec 2.0) on 2 teams of 128 was tried at compile time only: 192 resident weights + the h staging registers of a
-    // 512-thread workgroup spill (256 VGPRs + 72 bytes of scratch) - it stays on lstm_persistent_kernel
+    // d = 1024 (H-Codec 1.5 decoder): 4 teams of 64 workgroups x 8 waves, 16 hidden units per workgroup in 128 VGPRs per lane.
+    // d = 1536 (H-Codec 2.0) on 2 teams of 128 workgroups x 12 waves (again 128 resident weights per lane; h staged through registers or by
+    // LDS-DMA) was built and measured in r05: parity green, ~10 us per step against 8.5 for lstm_persistent_kernel (a 128-member arrival
+    // counter alone is ~1.5 us of serialised atomics; profiles/r05_lstm_team1536_ab.txt) - removed again, d = 1536 stays on that kernel
     if (t_lstm_per_step || knob(K_LSTM_TEAM) <= 0 || d != 1024 || P.degraded || T < 2) return QA_OK;
     QA_TRY(lstm_persistent_prepare(P, dev));
     if (P.cus != 256) return QA_OK;  // the team size is laid out for 256 CUs
-    QA_TRY((launch_lstm_team_t<1024, 64>(P, dev, xw, w_hh_ug, h_out, c_state, B, T, s)));
+    QA_TRY((launch_lstm_team_t<1024, 64, 8>(P, dev, xw, w_hh_ug, h_out, c_state, B, T, s)));
     *done = true;
     return QA_OK;
 }
