@@ -446,9 +446,9 @@ __global__ __launch_bounds__(NW * 64, 1) void lstm_xcd_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------ team recurrence for wider layers
-// QA_LSTM_TEAM (default 0: NOT YET MEASURED - written at the end of round 3 without GPU time left; tests/test_at_size_gpu.py holds its
-// parity test behind QA_TEST_EXPERIMENTAL).  The XCD-local idea for widths whose W_hh does not fit ONE XCD's registers: a team is PT
-// workgroups (64 at d = 1024: two XCDs' worth of register files per copy of W_hh, four teams; 128 at d = 1536, two teams), team =
+// QA_LSTM_TEAM (default 1 since r04: parity green on MI355X, 5.4 us per step against 9.7 for the per-step kernel at d = 1024,
+// profiles/r04_lstm_team_ab.txt).  The XCD-local idea for widths whose W_hh does not fit ONE XCD's registers: a team is PT
+// workgroups (64 at d = 1024: two XCDs' worth of register files per copy of W_hh, four teams; the 128-workgroup / two-team form for d = 1536 lost to lstm_persistent_kernel in r05), team =
 // blockIdx % n_teams, slot = blockIdx / n_teams - nothing depends on where a workgroup lands, because every hand-off uses the
 // agent-scope forms (sc1 write-through stores, drained vmcnt, agent atomic on the team's counter, sc1 loads).  A team runs
 // 4 SG sequences (two MFMA chains per wave at SG = 2: the resident A operand is used twice), so B = 32 at d = 1024 is ONE launch.
