@@ -353,7 +353,14 @@ int fused_step(qa_lm* lm, const LMBuffers& b, int B, int lo, int width, long lon
         o.w = L.o.w; o.N = d; o.K = d; o.ldx = d;
         if (i == 0) { o.res_tok = b.tok; o.res_table = lm->codec_emb; } else { o.res = b.x; }
         o.ldr = d; o.y = b.x; o.ldy = d;
-        QA_TRY(launch_lm_gemv(o, GM_RESID, lm->nt_o, s));
+        // tile width by the batch: the 8-row groups (lm_gemv4_kernel R8) hold a workgroup's pull of attention partials at 52 KB whatever the
+        // batch, but every column tile re-reads and re-merges the partials of its rows - so the launch keeps ~256 workgroups: 4 columns x 2
+        // row groups at 16 sequences, 8 x 4 at 32, 16 x 8 at 64 (r05 A/B, generate ms at 16 / 32 / 64 sequences: width 4 110.4 / 147.4 / 206.5,
+        // width 8 113.1 / 143.7 / 198.6, width 16 118.5 / 149.2 / 196.4; profiles/r05_lm_oproj_ab.txt)
+        int nt_o = lm->nt_o;
+        if (B > 16 && nt_o < 8 && d % 8 == 0) nt_o = 8;
+        if (B > 32 && nt_o < 16 && d % 16 == 0) nt_o = 16;
+        QA_TRY(launch_lm_gemv(o, GM_RESID, nt_o, s));
         // 4. RMSNorm + gate / up + SwiGLU
         GemvArgs g = a;
         g.x = b.x; g.ldx = d; g.w = L.gu_dec; g.N = 2 * I; g.K = d; g.y = b.u; g.ldy = I;

@@ -124,9 +124,13 @@ struct EpiPre {
 // the second reader hits the XCD's L2, HBM still streams every weight once per step, and the step issues 50 launches for 64 sequences
 // instead of 2 x 50.  A row's arithmetic does not depend on its group (rows never mix inside a GEMV), so tokens do not change.
 constexpr int LM_ROWS_PER_GROUP = 32;
-__device__ __forceinline__ void row_group(GemvArgs& a, int rg, int n_tiles) {
-    const long long r0 = (long long)rg * LM_ROWS_PER_GROUP;
-    a.M = min(LM_ROWS_PER_GROUP, a.M - (int)r0);
+// `rows` = rows per group = 16 MT of the kernel instance that calls it: 32 everywhere except the o_proj launch, which runs 16-row groups
+// (MT = 1) as soon as there are more than 16 sequences - its workgroups pull the attention partials of ALL their rows (S records of
+// 272 bytes per row and head, 6.4 KB per row at S = 3), and a launch costs ~3.3 us + 0.047 us per KB a workgroup pulls (DESIGN.md
+// section 11): 204 KB -> 13 us at 32 rows per workgroup, 102 KB -> 8 us at 16
+__device__ __forceinline__ void row_group(GemvArgs& a, int rg, int n_tiles, int rows) {
+    const long long r0 = (long long)rg * rows;
+    a.M = min(rows, a.M - (int)r0);
     if (a.x) a.x += r0 * a.ldx;
     if (a.tok) a.tok += r0;
     if (a.att_part) a.att_part += r0 * a.H * a.S * (a.hd + 4);
@@ -268,7 +272,7 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const float (*p
 template <int MT, int NT, int MODE, bool ATT, int NB>
 __global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a_in) {
     GemvArgs a = a_in;
-    if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x);
+    if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x, 16 * MT);
     __shared__ float part[8][MT][16][17];
     __shared__ float s_sq[8][MT * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -366,18 +370,23 @@ __global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a_in) {
 // columns (B: lane & 3 selects the column) at K phase p: a lane's float4 holds k = 16 * step + 4p .. + 3, one component per MFMA.
 // Every FMA is useful (the 16x16x4 form wastes 16 / NT of the matrix pipe on duplicated columns: 1.3 us per down_proj
 // workgroup); the four K phases are summed with two shuffles at the end.  NS = 16-wide K steps per wave loaded as one batch.
-template <int MT, int C, int MODE, bool ATT, int NS>
+// R8 (r05, the o_proj launch): EIGHT batch rows per workgroup - row blocks g = 0, 1 only, and lane bit 5 becomes a third K-phase bit
+// (8 phases of 4 k, 32-wide steps), so a workgroup pulls the attention partials of 8 rows instead of 16 (row_group above).  A row's
+// products are the same set in the same per-lane order; only the cross-lane fold gains one shuffle.
+template <int MT, int C, int MODE, bool ATT, int NS, bool R8 = false>
 __global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a_in) {
+    static_assert(!R8 || MT == 1, "8-row groups exist for one row tile");
     GemvArgs a = a_in;
-    if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x);
+    if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x, R8 ? 8 : 16 * MT);
     constexpr int NT = 4 * C;
     __shared__ float part[8][MT][16][17];
     __shared__ float s_sq[8][MT * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, p = (lane >> 2) & 3, i4 = lane & 3;
+    constexpr int KS = R8 ? 32 : 16;  // k per step
+    const int g = R8 ? (lane >> 4) & 1 : lane >> 4, p = R8 ? ((lane >> 2) & 3) + 4 * (lane >> 5) : (lane >> 2) & 3, i4 = lane & 3;
     const int tile = blockIdx.x;
     const int K = a.K, M = a.M;
-    const int kw = K >> 3, k0 = wave * kw, nstep = kw >> 4;
+    const int kw = K >> 3, k0 = wave * kw, nstep = kw / KS;
     LMT_DECL
     const int kbase = k0 + 4 * p;
     const float* wp[C];
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a_in) {
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int c = 0; c < C; ++c) wr[s][c] = ldg_nt(wp[c] + s * 16);
+        for (int c = 0; c < C; ++c) wr[s][c] = ldg_nt(wp[c] + s * KS);
     const float* xrow[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -409,15 +418,15 @@ __global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a_in) {
 #pragma unroll
             for (int s = 0; s < NS; ++s)
 #pragma unroll
-                for (int c = 0; c < C; ++c) wr[s][c] = ldg_nt(wp[c] + (s0 + s) * 16);
+                for (int c = 0; c < C; ++c) wr[s][c] = ldg_nt(wp[c] + (s0 + s) * KS);
         }
         float4 xa[MT][NS];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                if (ATT) att_merge<1>(a, min(m * 16 + 4 * g + i4, M - 1), kbase + (s0 + s) * 16, &xa[m][s]);
-                else xa[m][s] = *reinterpret_cast<const float4*>(xrow[m] + kbase + (s0 + s) * 16);
+                if (ATT) att_merge<1>(a, min(m * 16 + 4 * g + i4, M - 1), kbase + (s0 + s) * KS, &xa[m][s]);
+                else xa[m][s] = *reinterpret_cast<const float4*>(xrow[m] + kbase + (s0 + s) * KS);
             }
         __builtin_amdgcn_sched_barrier(0);
         LMT_TICK(0)
@@ -450,6 +459,7 @@ __global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a_in) {
                 float v = acc[m][c][r];
                 v += __shfl_xor(v, 4, 64);
                 v += __shfl_xor(v, 8, 64);
+                if (R8) v += __shfl_xor(v, 32, 64);
                 if (p == 0) part[wave][m][4 * g + r][c * 4 + i4] = v;
             }
     if (MODE != GM_RESID) {
@@ -458,6 +468,7 @@ __global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a_in) {
             float v = sq[m];
             v += __shfl_xor(v, 4, 64);
             v += __shfl_xor(v, 8, 64);
+            if (R8) v += __shfl_xor(v, 32, 64);
             if (p == 0) s_sq[wave][m * 16 + 4 * g + i4] = v;
         }
     }
@@ -485,12 +496,24 @@ static int gemv_nb(int K) {
 
 template <int MODE, bool ATT, int NB>
 static int launch_gemv_nb(const GemvArgs& a, int nt, hipStream_t s) {
-    const dim3 grid((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, LM_ROWS_PER_GROUP));  // y: row groups of 32 (M <= 64: one or two)
+    // y: row groups.  16 rows each (MT = 1) for up to 16 sequences and for the o_proj launch (ATT: see row_group), 32 rows (MT = 2) otherwise
+    const bool mt1 = a.M <= 16 || ATT;
+    if constexpr (ATT) {  // the o_proj launch on narrow tiles: 8-row groups (lm_gemv4_kernel R8)
+        if (NB % 2 == 0) {
+            const dim3 grid8((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, 8));
+            if (nt == 16) hipLaunchKernelGGL((lm_gemv4_kernel<1, 4, MODE, ATT, NB, true>), grid8, dim3(512), 0, s, a);
+            else if (nt == 8) hipLaunchKernelGGL((lm_gemv4_kernel<1, 2, MODE, ATT, NB, true>), grid8, dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((lm_gemv4_kernel<1, 1, MODE, ATT, NB, true>), grid8, dim3(512), 0, s, a);
+            QA_LAUNCH_CHECK();
+            return QA_OK;
+        }
+    }
+    const dim3 grid((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, mt1 ? 16 : LM_ROWS_PER_GROUP));
     // narrow tiles (NT = 8 / 4) run on the 4x4x1 MFMA, where every FMA is useful (the 16x16x4 form on duplicated columns measured equal:
     // the matrix pipe is not what bounds the step)
 #define QA_GV(MT, NT) hipLaunchKernelGGL((lm_gemv_kernel<MT, NT, MODE, ATT, NB>), grid, dim3(512), 0, s, a)
 #define QA_G4(MT, C) hipLaunchKernelGGL((lm_gemv4_kernel<MT, C, MODE, ATT, 2 * NB>), grid, dim3(512), 0, s, a)
-    if (a.M <= 16) {
+    if (mt1) {
         if (nt == 16) QA_GV(1, 16);
         else if (nt == 8) QA_G4(1, 2);
         else QA_G4(1, 1);
@@ -553,7 +576,7 @@ int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s) {
 template <int MT, int NB, int AC>
 __global__ __launch_bounds__(512) void lm_mlp_kernel(const GemvArgs a_in, const float* __restrict__ wd, float* __restrict__ partial) {
     GemvArgs a = a_in;
-    if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x);
+    if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x, 16 * MT);
     constexpr int NTL = AC / 8;  // gate/up decode tiles (8 gate + 8 up rows each) per workgroup
     __shared__ float part[8][NTL][MT][16][17];
     __shared__ float s_sq[8][MT * 16];
