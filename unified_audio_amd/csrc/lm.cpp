@@ -62,7 +62,7 @@ struct qa_lm {
     bool fused_ok = false;   // the shapes fit the fused decode step (otherwise the per-op decode path runs)
     bool mlp_fused = false;  // QA_LM_MLP_FUSED at create time: gate/up + SwiGLU + down as one launch + a reduce launch
     int mlp_ac = 16;         // activation columns per workgroup of that launch (8 measured equal at B = 16, -4 % at B = 64: profiles/r03_lm_ab.txt)
-    int att_split = 256;     // keys per workgroup of the decode attention, at most 4 splits (flat between 256 and 384, worse below: same log)
+    int att_split = 256;     // keys per workgroup of the decode attention, at most 4 splits (flat between 256 and 384, worse below: same log; re-measured in r05 with the cheaper o_proj: 128 / 160 / 192 keys 112.2 - 112.5 ms against 110.4 at 16 segments)
     int nt_qkv = 0, nt_o = 0, nt_gu = 0, nt_down = 0;
     hipStream_t cap_stream = nullptr;
     std::vector<StepGraph> graphs;  // [2 * chain + phase]: phase 0 global, 1 semantic
