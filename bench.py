@@ -290,11 +290,11 @@ def lm_bench(dev, rank, world, dist, batch, reps=2, task="se", n_enroll=0):
     return {"metric": "UniSE AR tokens/sec (greedy generate, prefill included)", "value": world * batch * 283 / best,
             "unit": "tokens/sec", "ms_per_generate": 1e3 * best, "ms_per_decode_step_incl_prefill": ms_step,
             "ms_prefill": ms_prefill, "ms_per_decode_step": ms_decode, "prefill": prefill,
-            "chains": max(1, -(-batch // 32)),
+            "chains": max(1, -(-batch // 64)), "row_groups_per_launch": max(1, -(-min(batch, 64) // 32)),
             "roofline": {"bound": "hbm", "achieved": step_bytes / (ms_step * 1e-3) / 1e12, "peak": HBM_PEAK_TBS, "unit": "TB/s",
                          "frac": step_bytes / (ms_step * 1e-3) / 1e12 / HBM_PEAK_TBS,
                          "bytes_per_step": {"weights": w_body + w_head, "kv_cache_mean": kv},
-                         "note": "whole decode step (62 dependent launches: 5 per layer + head + pick), prefill time included in the "
+                         "note": "whole decode step (62 dependent launches: 5 per layer + head + pick; up to 64 sequences ride in ONE chain of such steps), prefill time included in the "
                                  "denominator; the step is bound by the latency of its dependent launches (3.1 us floor each, 5-10 us measured), not by bytes (DESIGN.md section 11)"},
             "config": {"workload": f"LLM_SFT.generate {task.upper()} task, {batch} segments x 5 s per GPU, prompt {prompt}, 33 global + 250 semantic steps",
                        "dtype": "f32"}}
@@ -834,8 +834,8 @@ def main():
         except Exception as e:  # noqa: BLE001
             extras["unise_lm_tse_b8"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         try:
-            # BASELINE configs[3] on ONE GPU is 64 segments: batches above 32 run as concurrent chains of 32 (csrc/lm.cpp)
-            log("UniSE LM at 64 segments per GPU (2 concurrent chains): SE and TSE ...")
+            # BASELINE configs[3] on ONE GPU is 64 segments: one chain, two row groups of 32 per launch (csrc/lm.cpp, r05; above 64: chains)
+            log("UniSE LM at 64 segments per GPU (one chain, two row groups per launch): SE and TSE ...")
             extras["unise_lm_b64"] = lm_bench(dev, rank, world, None, 64, reps=1)
         except Exception as e:  # noqa: BLE001
             extras["unise_lm_b64"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}

@@ -89,7 +89,7 @@ class UniSE:
         `detokenize(global_tokens [B, 1, 32], semantic_tokens [B, N]) -> wav [B, 1, t]`, model.py:193).
         max_segments: 5 s segments per pass through the three stages (the micro-batch).  The reference feeds one utterance per step
         (data_module.py:340); here all segments of a call are batched, 64 at a time: the LM's decode step costs about the same for 16
-        and for 64 sequences (two concurrent chains of 32: 79.8 k tok/s against 38.9 k at 16), memory stays
+        and for 64 sequences (one chain, two row groups per launch: 92 k tok/s against 41 k at 16), memory stays
         bounded for long file lists, and - every stage being batch-invariant - the result does not depend on the value."""
         self.dnn = dnn
         self.semantic_model = semantic_model
@@ -194,7 +194,7 @@ class UniSE:
         batch - the overlap is almost nil: the workgroups of the GEMM stages (30 - 300 us each) hold the wave slots of every CU, so
         the 5 us launches of the LM queue behind them exactly as the LSTM step launches do, and the work adds
         up instead of overlapping; with replayed LM graphs 194.8 ms.  Throughput comes from the batch size instead: 64 segments per
-        call (two LM chains) run at 692 audio-s/s end to end against 442 at 16."""
+        call run at 775 audio-s/s end to end against 463 at 16."""
         from . import _lib
 
         if self.detokenize is None:
