@@ -1004,8 +1004,8 @@ def main():
                                     "share_of_step_time": top["ms_per_step"] / (1e3 * elapsed / args.steps),
                                     "all": sorted(hbm_rows, key=lambda r_: -r_["ms_per_step"]),
                                     "byte_bound_ms_per_step": sum(r_["ms_per_step"] for r_ in hbm_rows),
-                                    "note": "isolated pass (qa_set_serial(1)); bytes are algorithmic, so a two-pass kernel (GroupNorm) or one that is VALU-bound "
-                                            "(the fused SEANet front: 3 small convolutions per sample on the vector ALUs) shows as a low fraction"}
+                                    "note": "isolated pass (qa_set_serial(1)); bytes are algorithmic, so a two-pass kernel (GroupNorm) or one that is matrix-pipe-bound in fp32 "
+                                            "(the fused SEANet front: three small contractions per sample, 50 FLOP/B, priced against both rooflines in its row) shows as a low fraction"}
         di = CFG_NAMES.index(dom["kernel"])
         if iso[4 * di + 2]:
             tf = iso[4 * di] / (iso[4 * di + 1] * 1e-3) / 1e12

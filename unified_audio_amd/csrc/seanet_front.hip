@@ -40,44 +40,54 @@ __device__ __forceinline__ f32x4 elu4(f32x4 v) {
     return r;
 }
 
+// r05: every contraction of the block on v_mfma_f32_16x16x4_f32 with the weights in REGISTERS.
+//   * The k3's hidden width is 16: one 16-channel MFMA row block holds it exactly - the round-2 kernel padded it to the 32 rows of the
+//     32x32x2 form and spent half of that contraction on zeros (48 MFMAs x 64 cycles per 32-frame wave tile; now 48 x 32).
+//   * conv0 (k7, 1 -> 32) is a K = 8 contraction over a sliding window of the wave: A = w0 (k = 7 padded with a zero row), B[k][frame] =
+//     the padded signal at frame + k, C-in = the bias - i.e. the SAME fma chain in the same order as conv_in_kernel (ew.hip): x is still
+//     bit-identical to the standalone kernel's, and ~110 of a thread's ~400 vector instructions per tile are gone.
+//   * All weights live in 52 VGPRs per lane for the life of the persistent workgroup (lane (i = lane & 15, kq = lane >> 4) holds row i of
+//     a 16-row block at k = 16 s + 4 kq .. + 3): no weight traffic through LDS, LDS holds only the two x tiles (38 KB: 4 workgroups per CU).
+// Operand convention as before (weights = the MFMA's row operand, activations = its column operand): D gives lane (frame = lane & 15)
+// the 4 consecutive channels 4 (lane >> 4) .. + 3 of its 16-channel block: float4 stores everywhere.
+// The K slots of a 16-wide chunk are visited in the order k = e + 4 kq (e = the float4 component = one MFMA, kq = the slot inside it):
+// a fixed permutation, the same for every frame and batch row.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
 template <int C>
 __global__ __launch_bounds__(256) void seanet_block_kernel(const SeanetFrontParams p) {
-    constexpr int ROWS = 128, XR = ROWS + 2, LDX = C + 4, HP = 32;
-    constexpr int K3 = 3 * C, LD3 = K3 + 4, KC = C + HP, LDC = KC + 4;  // row strides = 4 mod 32 floats: the 16 lanes of a ds_read_b128 phase hit distinct banks
-    constexpr int NT = C / 32, HSLD = C + 4, C4 = C / 4;
-    constexpr int WSN = XR + 6;  // wav samples under one x tile (k7)
+    static_assert(C == 32, "two 16-channel blocks");
+    constexpr int ROWS = 128, XR = ROWS + 2, LDX = C + 4, HSLD = C + 4, C4 = C / 4;
+    constexpr int WSN = XR + 6;       // wav samples under one x tile (k7)
+    constexpr int WSP = 9 * 16 + 8;   // padded window length: the 9th frame block of the conv0 phase reads up to sample 151
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* XS = smem;               // [XR][LDX]  x tile (raw): the shortcut operand
     float* XE = XS + XR * LDX;      // [XR][LDX]  ELU(x): the k3 operand
-    float* W3 = XE + XR * LDX;      // [HP][LD3]
-    float* WC = W3 + HP * LD3;      // [C][LDC]   (W_shortcut | W_1x1)
     float* HS = XE;                 // [4][32][HSLD]  per wave: hidden tile, then the output staging - ALIASES the ELU(x) tile, which is
-                                    // dead once every wave has finished its k3 contraction (barrier below); keeps the workgroup at 61 KB
+                                    // dead once every wave has finished its k3 contraction (barrier below)
     static_assert(4 * 32 * HSLD <= XR * LDX, "hidden / output staging must fit in the ELU(x) tile");
-    float* b3s = WC + C * LDC;
-    float* bcs = b3s + HP;
-    float* b0s = bcs + C;
-    float* w0s = b0s + C;           // [7][C]
-    float* WS = w0s + 7 * C;        // [2][WSN] wav window of the current / next tile (reflect padding of the k7 resolved at staging)
+    float* WS = XE + XR * LDX;      // [2][WSP] wav window of the current / next tile (reflect padding of the k7 resolved at staging)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 31, fh = lane >> 5;
-    for (int e = tid; e < HP * (K3 / 4); e += 256) {
-        const int n = e / (K3 / 4), c4 = (e % (K3 / 4)) * 4;
-        *reinterpret_cast<f32x4*>(W3 + n * LD3 + c4) = *reinterpret_cast<const f32x4*>(p.w3 + (long long)n * K3 + c4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    // ---- weights -> registers (row li of each 16-row block, k = 16 s + 4 kq .. + 3)
+    f32x4v w3r[6];     // k3 [16 hidden][3 taps x 32]: chunk s = tap * 2 + half
+    f32x4v wcr[2][3];  // [x | hidden] -> 32 channels: block cb, chunks 0, 1 = W_shortcut columns, chunk 2 = W_1x1 columns 0 .. 15
+    float w0r[2][2];   // conv0: block cb, k step st: w0[4 st + kq][16 cb + li] (k = 7: zero)
+    f32x4v b0r[2], b3r, bcr[2];  // biases of this lane's 4 output channels (4 kq .. + 3 of each block)
+#pragma unroll
+    for (int s = 0; s < 6; ++s) w3r[s] = *reinterpret_cast<const f32x4v*>(p.w3 + (long long)li * (3 * C) + 16 * s + 4 * kq);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) wcr[cb][s] = *reinterpret_cast<const f32x4v*>(p.wsc + (long long)(16 * cb + li) * C + 16 * s + 4 * kq);
+        wcr[cb][2] = *reinterpret_cast<const f32x4v*>(p.wpw + (long long)(16 * cb + li) * 32 + 4 * kq);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) w0r[cb][st] = (4 * st + kq) < 7 ? p.w0[(4 * st + kq) * C + 16 * cb + li] : 0.f;
+        b0r[cb] = *reinterpret_cast<const f32x4v*>(p.b0 + 16 * cb + 4 * kq);
+        bcr[cb] = *reinterpret_cast<const f32x4v*>(p.bsc + 16 * cb + 4 * kq) + *reinterpret_cast<const f32x4v*>(p.bpw + 16 * cb + 4 * kq);
     }
-    for (int e = tid; e < C * (KC / 4); e += 256) {
-        const int n = e / (KC / 4), c4 = (e % (KC / 4)) * 4;
-        const f32x4 v = c4 < C ? *reinterpret_cast<const f32x4*>(p.wsc + (long long)n * C + c4)
-                               : *reinterpret_cast<const f32x4*>(p.wpw + (long long)n * HP + (c4 - C));
-        *reinterpret_cast<f32x4*>(WC + n * LDC + c4) = v;
-    }
-    for (int e = tid; e < HP; e += 256) b3s[e] = p.b3[e];
-    for (int e = tid; e < C; e += 256) {
-        bcs[e] = p.bsc[e] + p.bpw[e];
-        b0s[e] = p.b0[e];
-    }
-    for (int e = tid; e < 7 * C; e += 256) w0s[e] = p.w0[e];
+    b3r = *reinterpret_cast<const f32x4v*>(p.b3 + 4 * kq);
 
     const int L = p.L;
     const int tiles_per_clip = (L + ROWS - 1) / ROWS, n_tiles = p.B * tiles_per_clip;
@@ -89,141 +99,108 @@ __global__ __launch_bounds__(256) void seanet_block_kernel(const SeanetFrontPara
         const int s_ = resolve_frame(r0_ - p.pl3 - p.pl0 + tid, L, p.Lp0, PAD_REFLECT);
         return s_ >= 0 ? p.wav[(long long)b_ * L + s_] : 0.f;
     };
-    if (tid < WSN) WS[tid] = wav_fetch(blockIdx.x);
+    if (tid < WSP) {
+        WS[tid] = tid < WSN ? wav_fetch(blockIdx.x) : 0.f;
+        WS[WSP + tid] = 0.f;
+    }
     int cur = 0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, cur ^= 1) {
         const int b = tile / tiles_per_clip, r0 = (tile - b * tiles_per_clip) * ROWS;
-        __syncthreads();  // the previous tile is no longer read (first trip: orders the weight / window stores too)
+        __syncthreads();  // the previous tile is no longer read (first trip: orders the window stores too)
         const float wnext = wav_fetch(tile + gridDim.x);  // in flight under this whole tile
-        const float* ws = WS + cur * WSN;
-        // ---- x tile: frames r0 - pl3 .. r0 - pl3 + XR - 1 with the k3's reflect padding resolved per row
-        for (int e = tid; e < XR * C4; e += 256) {
-            const int i = e / C4, c4 = (e - i * C4) * 4;
+        const float* ws = WS + cur * WSP;
+        // ---- x tile: rows i = 0 .. XR - 1 are frames q = r0 - pl3 + i with the k3's reflect padding resolved per row: x[src(q)] needs the
+        // conv0-padded signal at src - pl0 + k = window sample (src - r0 + pl3) + k.  Frame blocks of 16 rows dealt to the waves
+        // (9 blocks cover 144 rows; rows >= XR are not stored).
+        for (int fb = wave; fb < 9; fb += 4) {
+            const int i = 16 * fb + li;
             const int q = r0 - p.pl3 + i;
             const int src = resolve_frame(q, L, p.Lp3, PAD_REFLECT);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (src >= 0) {
-                {
-                    v = *reinterpret_cast<const f32x4*>(b0s + c4);
-                    if (src == q) {  // a frame of the clip itself: its 7 samples are ws[i .. i + 6]
+            const int u0 = max(0, min(src - r0 + p.pl3, WSP - 8)) + kq;  // rows whose window falls outside belong to frames past the clip: never stored
+            const float s0 = ws[u0], s1 = ws[u0 + 4];
 #pragma unroll
-                        for (int j = 0; j < 7; ++j) {  // same accumulation order as conv_in_kernel (ew.hip): bit-identical x
-                            const float xv = ws[i + j];
-                            const f32x4 w = *reinterpret_cast<const f32x4*>(w0s + j * C + c4);
-                            v.x = fmaf(xv, w.x, v.x); v.y = fmaf(xv, w.y, v.y); v.z = fmaf(xv, w.z, v.z); v.w = fmaf(xv, w.w, v.w);
-                        }
-                    } else {  // a halo row reflected at a clip edge (at most two rows per clip end): straight from memory
-                        const float* wb = p.wav + (long long)b * L;
-                        for (int j = 0; j < 7; ++j) {
-                            const int s = resolve_frame(src - p.pl0 + j, L, p.Lp0, PAD_REFLECT);
-                            const float xv = s >= 0 ? wb[s] : 0.f;
-                            const f32x4 w = *reinterpret_cast<const f32x4*>(w0s + j * C + c4);
-                            v.x = fmaf(xv, w.x, v.x); v.y = fmaf(xv, w.y, v.y); v.z = fmaf(xv, w.z, v.z); v.w = fmaf(xv, w.w, v.w);
-                        }
-                    }
+            for (int cb = 0; cb < 2; ++cb) {
+                f32x4v v = b0r[cb];  // C-in = bias, then k = 0 .. 7 in order: conv_in_kernel's fma chain
+                v = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[cb][0], s0, v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[cb][1], s1, v, 0, 0, 0);
+                if (src < 0) v = (f32x4v){0.f, 0.f, 0.f, 0.f};  // zero extension of a short clip (not reachable for L >= 8; kept for the contract)
+                if (i < XR) {
+                    *reinterpret_cast<f32x4v*>(XS + i * LDX + 16 * cb + 4 * kq) = v;
+                    *reinterpret_cast<f32x4v*>(XE + i * LDX + 16 * cb + 4 * kq) = elu4(v);
                 }
             }
-            *reinterpret_cast<f32x4*>(XS + i * LDX + c4) = v;
-            *reinterpret_cast<f32x4*>(XE + i * LDX + c4) = elu4(v);  // ELU(0) = 0: the zero extension of a short clip stays zero
         }
         __syncthreads();
 
-        // ---- hidden = ELU(k3(ELU(x)) + b3): K = 3 C, taps are row offsets 0, 1, 2 of the tile
-        f32x16 acc;
+        // ---- hidden = ELU(k3(ELU(x)) + b3): K = 3 taps x 32 channels = 6 chunks of 16; taps are row offsets 0, 1, 2 of the tile
+        f32x4v h[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        {
-            const float* arow = XE + (wave * 32 + fr) * LDX + 4 * fh;
-            const float* wrow = W3 + fr * LD3 + 4 * fh;
+        for (int fbk = 0; fbk < 2; ++fbk) {
+            h[fbk] = b3r;
+            const float* arow = XE + (wave * 32 + 16 * fbk + li) * LDX + 4 * kq;
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int c0 = 0; c0 < C; c0 += 8) {
-                    const f32x4 av = *reinterpret_cast<const f32x4*>(arow + j * LDX + c0);
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + j * C + c0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, av.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, av.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, av.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, av.w, acc, 0, 0, 0);
-                }
+            for (int s = 0; s < 6; ++s) {
+                const f32x4v av = *reinterpret_cast<const f32x4v*>(arow + (s >> 1) * LDX + 16 * (s & 1));
+                h[fbk] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3r[s].x, av.x, h[fbk], 0, 0, 0);
+                h[fbk] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3r[s].y, av.y, h[fbk], 0, 0, 0);
+                h[fbk] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3r[s].z, av.z, h[fbk], 0, 0, 0);
+                h[fbk] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3r[s].w, av.w, h[fbk], 0, 0, 0);
+            }
         }
         __syncthreads();  // every wave is done with the ELU(x) tile: it becomes the hidden tile
-        // D layout (operands swapped as in conv_gemm.hip): frame <- lane & 31, channel <- (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = 8 * g + 4 * fh;
-            if (n >= p.hid8) continue;  // padded hidden channels: never read by the second contraction
-            f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-            v += *reinterpret_cast<const f32x4*>(b3s + n);
-            *reinterpret_cast<f32x4*>(HSw + fr * HSLD + n) = elu4(v);
-        }
+        for (int fbk = 0; fbk < 2; ++fbk) *reinterpret_cast<f32x4v*>(HSw + (16 * fbk + li) * HSLD + 4 * kq) = elu4(h[fbk]);
         __syncthreads();
 
-        // ---- s = [x | hidden] [W_sc | W_1x1]^T + (b_sc + b_1x1)
-        f32x16 acc2[NT];
+        // ---- a = ELU([x | hidden] [W_sc | W_1x1]^T + (b_sc + b_1x1))
+        f32x4v o[2][2];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int fbk = 0; fbk < 2; ++fbk) {
+            const float* xrow = XS + (wave * 32 + 16 * fbk + li + p.pl3) * LDX + 4 * kq;
+            const float* hrow = HSw + (16 * fbk + li) * HSLD + 4 * kq;
+            const f32x4v a0 = *reinterpret_cast<const f32x4v*>(xrow), a1 = *reinterpret_cast<const f32x4v*>(xrow + 16);
+            const f32x4v a2 = *reinterpret_cast<const f32x4v*>(hrow);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
-        {
-            const float* xrow = XS + (wave * 32 + fr + p.pl3) * LDX + 4 * fh;
-            const float* wrow = WC + fr * LDC + 4 * fh;
+            for (int cb = 0; cb < 2; ++cb) {
+                f32x4v v = bcr[cb];
 #pragma unroll
-            for (int c0 = 0; c0 < C; c0 += 8) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(xrow + c0);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + t * 32 * LDC + c0);
-                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, av.x, acc2[t], 0, 0, 0);
-                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, av.y, acc2[t], 0, 0, 0);
-                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, av.z, acc2[t], 0, 0, 0);
-                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, av.w, acc2[t], 0, 0, 0);
+                for (int s = 0; s < 3; ++s) {
+                    const f32x4v av = s == 0 ? a0 : (s == 1 ? a1 : a2);
+                    v = __builtin_amdgcn_mfma_f32_16x16x4f32(wcr[cb][s].x, av.x, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x4f32(wcr[cb][s].y, av.y, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x4f32(wcr[cb][s].z, av.z, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x4f32(wcr[cb][s].w, av.w, v, 0, 0, 0);
                 }
-            }
-            const float* hrow = HSw + fr * HSLD + 4 * fh;
-            for (int c0 = 0; c0 < p.hid8; c0 += 8) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(hrow + c0);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + t * 32 * LDC + C + c0);
-                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, av.x, acc2[t], 0, 0, 0);
-                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, av.y, acc2[t], 0, 0, 0);
-                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, av.z, acc2[t], 0, 0, 0);
-                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, av.w, acc2[t], 0, 0, 0);
-                }
+                o[fbk][cb] = v;
             }
         }
         __syncthreads();  // every lane of the wave has read its hidden rows: the region becomes the output staging
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int fbk = 0; fbk < 2; ++fbk)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = t * 32 + 8 * g + 4 * fh;
-                f32x4 v = {acc2[t][4 * g], acc2[t][4 * g + 1], acc2[t][4 * g + 2], acc2[t][4 * g + 3]};
-                v += *reinterpret_cast<const f32x4*>(bcs + n);
-                *reinterpret_cast<f32x4*>(HSw + fr * HSLD + n) = elu4(v);
-            }
+            for (int cb = 0; cb < 2; ++cb)
+                *reinterpret_cast<f32x4v*>(HSw + (16 * fbk + li) * HSLD + 16 * cb + 4 * kq) = elu4(o[fbk][cb]);
         __syncthreads();
         // a store instruction of the wave covers 64 / C4 whole frames = 1 KB contiguous
 #pragma unroll
         for (int it = 0; it < 32 * C4 / 64; ++it) {
             const int e = it * 64 + lane, row = e / C4, c4 = (e - row * C4) * 4;
             const int t = r0 + wave * 32 + row;
-            if (t < L) *reinterpret_cast<f32x4*>(p.a + ((long long)b * L + t) * C + c4) = *reinterpret_cast<const f32x4*>(HSw + row * HSLD + c4);
+            if (t < L) *reinterpret_cast<f32x4v*>(p.a + ((long long)b * L + t) * C + c4) = *reinterpret_cast<const f32x4v*>(HSw + row * HSLD + c4);
         }
-        if (tid < WSN) WS[(cur ^ 1) * WSN + tid] = wnext;  // that buffer was last read before this tile's second barrier
+        if (tid < WSN) WS[(cur ^ 1) * WSP + tid] = wnext;  // that buffer was last read before this tile's second barrier
     }
 }
 
 static size_t seanet_block_lds_bytes(int C) {
-    const int XR = 130, LDX = C + 4, HP = 32;
-    return sizeof(float) * ((size_t)2 * XR * LDX + (size_t)HP * (3 * C + 4) + (size_t)C * (C + HP + 4) + HP + 2 * C + 7 * C + 2 * (XR + 6));
+    const int XR = 130, LDX = C + 4, WSP = 9 * 16 + 8;
+    return sizeof(float) * ((size_t)2 * XR * LDX + 2 * WSP);
 }
 
 bool seanet_front_supported(int C, int hid, int L) {
     const bool on = knob(K_SEANET_FUSED) != 0;
     // L >= 8: both reflect pads stay in their plain regime (no zero extension of a short clip)
-    return on && C == 32 && hid >= 1 && hid <= 32 && L >= 8;
+    return on && C == 32 && hid >= 1 && hid <= 16 && L >= 8;  // hid <= 16: ONE 16-channel MFMA row block holds the hidden tile
 }
 
 // k3 / pw in the padded library layouts of hcodec.cpp (k3 [32][3][C], pw [C][32]).
@@ -242,7 +219,7 @@ int launch_seanet_front(const float* wav, const float* w0, const float* b0, cons
     p.Lp0 = L <= mp0 ? mp0 + 1 : L;
     const size_t lds = seanet_block_lds_bytes(C);
     const long long n_tiles = (long long)B * ceil_div(L, 128);
-    const unsigned grid = (unsigned)std::min<long long>(n_tiles, 512);  // persistent: two workgroups per CU, weights staged once each
+    const unsigned grid = (unsigned)std::min<long long>(n_tiles, 1024);  // persistent: four workgroups per CU (38 KB of LDS each), weights loaded once each
     QA_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(seanet_block_kernel<32>), (int)lds));
     HbmProf prof_(HK_SEANET_FRONT, 4.0 * ((double)B * L + (double)B * L * C), s);  // wav in, the block output `a` written once
     hipLaunchKernelGGL((seanet_block_kernel<32>), dim3(grid), dim3(256), lds, s, p);
