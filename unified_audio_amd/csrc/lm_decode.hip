@@ -496,8 +496,9 @@ static int gemv_nb(int K) {
 
 template <int MODE, bool ATT, int NB>
 static int launch_gemv_nb(const GemvArgs& a, int nt, hipStream_t s) {
-    // y: row groups.  16 rows each (MT = 1) for up to 16 sequences and for the o_proj launch (ATT: see row_group), 32 rows (MT = 2) otherwise
-    const bool mt1 = a.M <= 16 || ATT;
+    // y: row groups.  16 rows each (MT = 1) for up to 16 sequences (8 for the o_proj launch, ATT: see row_group), 32 rows (MT = 2) otherwise
+    // ... and for the qkv launch up to 32 sequences (139.4 -> 136.0 ms at 32 segments; at 64 segments 32-row groups win: 196 vs 198 ms)
+    const bool mt1 = a.M <= 16 || ATT || (MODE == GM_QKV && a.M <= 32);
     if constexpr (ATT) {  // the o_proj launch on narrow tiles: 8-row groups (lm_gemv4_kernel R8)
         if (NB % 2 == 0) {
             const dim3 grid8((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, 8));
@@ -743,9 +744,11 @@ bool lm_mlp_fused_supported(int d, int I, int nt_gu) {
 int launch_lm_mlp(const GemvArgs& a, int I, int ac, const float* wd, float* partial, const float* res, long long ldr, float* y, long long ldy,
                   hipStream_t s) {
     QA_REQUIRE(a.M >= 1 && a.M <= LM_MAX_ROWS && a.K == a.d && lm_mlp_fused_supported(a.d, I, 16), "lm_mlp: unsupported shape M=%d d=%d I=%d", a.M, a.d, I);
-    const int mt = a.M <= 16 ? 1 : 2;
+    // 16-row groups up to 32 sequences (two groups x 128 workgroups: each pulls 32 KB of x instead of 64 beside its 96 KB of weights -
+    // 144.0 -> 139.4 ms per generate at 32 segments), 32-row groups above (at 64 segments four groups = 512 workgroups lose: 207 vs 196 ms)
+    const int mt = a.M <= 32 ? 1 : 2;
     const int n_part = I / ac;
-    const dim3 grid((unsigned)n_part, (unsigned)ceil_div(a.M, LM_ROWS_PER_GROUP));  // partial: [row group][n_part][16 mt][d]
+    const dim3 grid((unsigned)n_part, (unsigned)ceil_div(a.M, 16 * mt));  // partial: [row group][n_part][16 mt][d]
     QA_REQUIRE(ac == 16, "lm_mlp: %d activation columns per workgroup (only 16 is built)", ac);
 #define QA_MLP(MT, NB) hipLaunchKernelGGL((lm_mlp_kernel<MT, NB, 16>), grid, dim3(512), 0, s, a, wd, partial)
     if (a.d == 512) {
