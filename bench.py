@@ -484,13 +484,33 @@ def collect_ranks_seen(dist, rank, local_rank, world, dev):
     return {"ranks": seen, "distinct_devices": len({(s["host"], s["uuid"], s["pci_bus_id"]) for s in seen})}
 
 
+def all_ranks_ok(dist, err, what):
+    """Agree on a failure BEFORE anybody enters the next collective: every rank contributes its error string (or None); if any rank failed,
+    EVERY rank raises the same RuntimeError - so a leg that dies on one rank (out of memory while building a model, say) ends as an
+    `{"error": ...}` object on all of them instead of leaving the others in a barrier."""
+    errs = [None] * dist.get_world_size()
+    dist.all_gather_object(errs, err)
+    bad = [(r, e) for r, e in enumerate(errs) if e is not None]
+    if bad:
+        raise RuntimeError(f"{what}: " + "; ".join(f"rank {r}: {e}" for r, e in bad))
+
+
+def _guard(fn):
+    """-> (result, None) or (None, 'Type: message')"""
+    try:
+        return fn(), None
+    except Exception as e:  # noqa: BLE001
+        return None, f"{type(e).__name__}: {str(e)[:200]}"
+
+
 def exchange_leg(dist, rank, world, dev, hot_path, make_inputs, n_inputs, pad_values, fence, scatter_bytes):
     """The exchange step north_star names - scatter of the clips from rank 0, the per-GPU hot path, gather of codes + waveforms back
     (unified_audio_amd.dist.run_sharded: packed point-to-point transfers, the code path the gloo tests exercise) - timed NEXT TO the hot
     path, never inside `value`.  -> (exchange dict, gathered results on rank 0)"""
     from unified_audio_amd import dist as qd
 
-    inputs = make_inputs() if rank == 0 else [None] * n_inputs
+    inputs, err = _guard(make_inputs) if rank == 0 else ([None] * n_inputs, None)
+    all_ranks_ok(dist, err, "building the inputs on rank 0")
     tm = {}
     fence()
     res = qd.run_sharded(hot_path, inputs, dev, pad_values=pad_values, timings=tm)
@@ -504,19 +524,29 @@ def exchange_leg(dist, rank, world, dev, hot_path, make_inputs, n_inputs, pad_va
     return exchange, res
 
 
-def sharded_config_leg(dist, rank, world, dev, hot_path, make_local, units_per_rank, unit, pad_values, fence, reps, workload, config_ref):
+def sharded_config_leg(dist, rank, world, dev, setup, make_local, units_per_rank, unit, pad_values, fence, reps, workload, config_ref):
     """One multi-GPU BASELINE configuration at N > 1: every rank runs `hot_path` on ITS OWN share of the
     configuration (inputs resident, barrier + device fence on both sides, MAX over ranks) -> `value` = the units all ranks processed per
     second; beside it - never inside it - the exchange step of that configuration (rank 0 holds every rank's share, run_sharded scatters
     it, runs the same hot path, gathers the results; rank 0's block is checked against its own local run).  make_local(r) -> rank r's
-    input tensors [n_r, ...] (seeded by r, so rank 0 can rebuild everybody's share for the scatter)."""
-    local = [t.to(dev) for t in make_local(rank)]
-    hot_path(*local)  # warm-up (workspace growth, graphs)
-    best = float("inf")
+    input tensors [n_r, ...] (seeded by r, so rank 0 can rebuild everybody's share for the scatter); setup() -> hot_path builds the model
+    of the leg.  Every phase that can fail on ONE rank (model construction, warm-up, a timed pass) is followed by all_ranks_ok, so the
+    ranks leave a failing leg together."""
+    def prepare():
+        hp = setup()
+        loc = [t.to(dev) for t in make_local(rank)]
+        hp(*loc)  # warm-up (workspace growth, graphs)
+        return hp, loc
+
+    got, err = _guard(prepare)
+    all_ranks_ok(dist, err, "setting the leg up")
+    hot_path, local = got
+    best, own = float("inf"), None
     for _ in range(reps):
         fence()
         t0 = time.perf_counter()
-        own = hot_path(*local)
+        own, err = _guard(lambda: hot_path(*local))
+        all_ranks_ok(dist, err, "a timed pass")
         fence()
         dt = time.perf_counter() - t0
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -587,12 +617,22 @@ def bootstrap_selftest(args):
         def codec_stub(w, f):
             return (w[:, ::16] * 4).to(torch.int64)[:, None, :], (f[:, :, 0] * 4).to(torch.int64)[:, None, :], w * 0.5
 
+        fail_rank = int(os.environ.get("QA_SELFTEST_FAIL_RANK", "-1"))  # tests: the H-Codec 2.0 leg's setup dies on this rank only
+
+        def codec_setup():
+            if rank == fail_rank:
+                raise MemoryError("injected failure of one rank's model construction")
+            return codec_stub
+
         line["configs3_tse"] = sharded_config_leg(
-            dist, rank, world, dev, tse_stub, lambda r: [clips_of(r).reshape(B, 16, 4), clips_of(r).reshape(B, 16, 4) + 0.5], B * 6, "tokens/sec",
+            dist, rank, world, dev, lambda: tse_stub, lambda r: [clips_of(r).reshape(B, 16, 4), clips_of(r).reshape(B, 16, 4) + 0.5], B * 6, "tokens/sec",
             None, fence, 1, "stub hot path (self-test)", "configs[3]")
-        line["configs4_hcodec20"] = sharded_config_leg(
-            dist, rank, world, dev, codec_stub, lambda r: [clips_of(r), clips_of(r).reshape(B, 16, 4)], B * T / 48000.0, "audio-seconds/sec",
-            None, fence, 1, "stub hot path (self-test)", "configs[4]")
+        try:  # as main() does: a leg that fails - on ANY rank - becomes an error object on rank 0's line, and nobody hangs
+            line["configs4_hcodec20"] = sharded_config_leg(
+                dist, rank, world, dev, codec_setup, lambda r: [clips_of(r), clips_of(r).reshape(B, 16, 4)], B * T / 48000.0, "audio-seconds/sec",
+                None, fence, 1, "stub hot path (self-test)", "configs[4]")
+        except Exception as e:  # noqa: BLE001
+            line["configs4_hcodec20"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
@@ -766,38 +806,48 @@ def main():
         if not args.no_lm:
             try:
                 log("configs[3]: TSE share, 8 segments per GPU ...")
-                lm3 = qa.LLM_SFT(device=dev).load_state_dict(synth.lm_state_dict(4321))
-                mel3 = torch.zeros(1, 250, 80)
+                keep3 = {}
 
-                def tse_path(mix, enr):
-                    n_ = mix.shape[0]
-                    return lm3.generate("tse", mel3.expand(n_, -1, -1), enr, mel3.expand(n_, -1, -1), mix, do_sample=False)
+                def tse_setup():
+                    lm3 = keep3["lm"] = qa.LLM_SFT(device=dev).load_state_dict(synth.lm_state_dict(4321))
+                    mel3 = torch.zeros(1, 250, 80)
+
+                    def tse_path(mix, enr):
+                        n_ = mix.shape[0]
+                        return lm3.generate("tse", mel3.expand(n_, -1, -1), enr, mel3.expand(n_, -1, -1), mix, do_sample=False)
+
+                    return tse_path
 
                 multi["configs3_tse"] = sharded_config_leg(
-                    dist, rank, world, dev, tse_path, lambda r: [synth.synth_feats(50 + r, 8, 250), synth.synth_feats(90 + r, 8, 250)], 8 * 283,
+                    dist, rank, world, dev, tse_setup, lambda r: [synth.synth_feats(50 + r, 8, 250), synth.synth_feats(90 + r, 8, 250)], 8 * 283,
                     "tokens/sec", None, fence, 2, "LLM_SFT.generate TSE task (greedy, prefill included), 8 segments x 5 s per GPU, prompt 503 "
                     "(mixture 250 + enrollment 250 + 3), 33 global + 250 semantic steps; enrollment features scattered with their segment",
                     "configs[3]: UniSE TSE, batch 64 over 8 GPUs")
-                del lm3
+                keep3.clear()
             except Exception as e:  # noqa: BLE001
                 multi["configs3_tse"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         try:
             log("configs[4]: H-Codec 2.0 share, 16 x 30 s per GPU ...")
             spec20m = synth.Shapes20()
-            codec20m = qa.Codec(None, None, None, spec=qa.SPEC_20, device=dev).load_state_dict(synth.hcodec20_state_dict(1234, spec20m))
             B20m, T20m = 16, 30 * 48000 // spec20m.frame_hop * spec20m.frame_hop
+            keep4 = {}
 
-            def h20_path(w, f):
-                a_, s_ = codec20m.encode(w, f)
-                return a_, s_, codec20m.decode(a_, s_)
+            def h20_setup():
+                codec20m = keep4["codec"] = qa.Codec(None, None, None, spec=qa.SPEC_20, device=dev).load_state_dict(synth.hcodec20_state_dict(1234, spec20m))
+
+                def h20_path(w, f):
+                    a_, s_ = codec20m.encode(w, f)
+                    return a_, s_, codec20m.decode(a_, s_)
+
+                return h20_path
 
             multi["configs4_hcodec20"] = sharded_config_leg(
-                dist, rank, world, dev, h20_path,
+                dist, rank, world, dev, h20_setup,
                 lambda r: [synth.synth_wav_fullband(17 + r, B20m, T20m), synth.synth_feat(19 + r, B20m, T20m // spec20m.hop, 768)],
                 B20m * T20m / 48000.0, "audio-seconds/sec", None, fence, 2,
                 f"H-Codec 2.0 Codec.encode+Codec.decode (1.17 G parameters), 16 clips x {T20m / 48000:.0f} s @48 kHz per GPU, 16 + 16 codebooks, SSL features precomputed",
                 "configs[4]: H-Codec 2.0, 128 x 30 s over 8 GPUs")
-            del codec20m
+            keep4.clear()
         except Exception as e:  # noqa: BLE001
             multi["configs4_hcodec20"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
 

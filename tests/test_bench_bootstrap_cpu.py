@@ -79,3 +79,15 @@ def test_more_ranks_than_devices_fails_after_the_rendezvous_with_a_clear_message
     assert p.returncode != 0
     assert len(lines) == 1 and lines[0]["rendezvous"] == "ok" and lines[0]["n_gpus"] == 2 and lines[0]["devices_visible"] < 2
     assert "exposes only" in lines[0]["error"]
+
+
+def test_a_leg_that_fails_on_one_rank_ends_on_all_ranks_together():
+    """N > 1 robustness: the multi-GPU legs build their own models; if that fails on ONE rank (out of memory, say) the others must not be
+    left in the leg's barrier.  Every fallible phase is followed by an all-gather of error strings (bench.all_ranks_ok): here rank 1's setup of
+    the configs[4] leg dies - the run still ends in time with ONE line, that leg an error object naming the rank, the other leg intact."""
+    p, lines = _run([BENCH, "--gpus", "2", "--bootstrap-selftest"], env_extra={"QA_SELFTEST_FAIL_RANK": "1"}, timeout=180)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    leg = lines[0]["configs4_hcodec20"]
+    assert "error" in leg and "rank 1" in leg["error"] and "injected failure" in leg["error"], leg
+    assert lines[0]["configs3_tse"]["exchange"]["rank0_block_matches_local_run"] is True
