@@ -23,6 +23,7 @@ struct GemvArgs {
     // B operand: [n_tiles * NT][K] rows in decode layout (tile-major; paired modes: NT/2 "first" rows then NT/2 "second" rows)
     const float* w;
     int M, N, K;
+    int rpg;  // rows per row group of this launch (0: 16 per 16-row tile of the kernel instance); set by the launchers
     float rms_eps;
     const int* state;
     int pos;  // >= 0: position of the step (host-driven loop); < 0: read it from state (captured step)

@@ -272,7 +272,7 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const float (*p
 template <int MT, int NT, int MODE, bool ATT, int NB>
 __global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a_in) {
     GemvArgs a = a_in;
-    if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x, 16 * MT);
+    if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x, a.rpg ? a.rpg : 16 * MT);
     __shared__ float part[8][MT][16][17];
     __shared__ float s_sq[8][MT * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -499,6 +499,13 @@ static int launch_gemv_nb(const GemvArgs& a, int nt, hipStream_t s) {
     // y: row groups.  16 rows each (MT = 1) for up to 16 sequences (8 for the o_proj launch, ATT: see row_group), 32 rows (MT = 2) otherwise
     // ... and for the qkv launch up to 32 sequences (139.4 -> 136.0 ms at 32 segments; at 64 segments 32-row groups win: 196 vs 198 ms)
     const bool mt1 = a.M <= 16 || ATT || (MODE == GM_QKV && a.M <= 32);
+    if (MODE == GM_QKV && a.M > 8 && a.M <= 16 && nt == 16) {  // 9 .. 16 sequences: two 8-row groups (see launch_lm_mlp)
+        GemvArgs a8 = a;
+        a8.rpg = 8;
+        hipLaunchKernelGGL((lm_gemv_kernel<1, 16, MODE, ATT, NB>), dim3((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, 8)), dim3(512), 0, s, a8);
+        QA_LAUNCH_CHECK();
+        return QA_OK;
+    }
     if constexpr (ATT) {  // the o_proj launch on narrow tiles: 8-row groups (lm_gemv4_kernel R8)
         if (NB % 2 == 0) {
             const dim3 grid8((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, 8));
@@ -577,7 +584,7 @@ int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s) {
 template <int MT, int NB, int AC>
 __global__ __launch_bounds__(512) void lm_mlp_kernel(const GemvArgs a_in, const float* __restrict__ wd, float* __restrict__ partial) {
     GemvArgs a = a_in;
-    if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x, 16 * MT);
+    if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x, a.rpg ? a.rpg : 16 * MT);
     constexpr int NTL = AC / 8;  // gate/up decode tiles (8 gate + 8 up rows each) per workgroup
     __shared__ float part[8][NTL][MT][16][17];
     __shared__ float s_sq[8][MT * 16];
@@ -705,11 +712,11 @@ __global__ __launch_bounds__(512) void lm_mlp_kernel(const GemvArgs a_in, const 
 // 4-column slot l8); a lane adds the partials j = g, g + 8, ... (RJ loads in flight at once), then the 8 groups fold with three xor
 // shuffles - a fixed order: deterministic.
 template <int RJ>
-__global__ __launch_bounds__(64) void lm_mlp_reduce_kernel(const float* __restrict__ partial, int n_part, int m_pad, int d,
+__global__ __launch_bounds__(64) void lm_mlp_reduce_kernel(const float* __restrict__ partial, int n_part, int m_pad, int rpg, int d,
                                                            const float* __restrict__ res, long long ldr, float* __restrict__ y, long long ldy) {
     const int lane = threadIdx.x, g = lane >> 3, l8 = lane & 7;
     const int row = blockIdx.y, col = blockIdx.x * 32 + 4 * l8;
-    const int rg = row / m_pad, rl = row - rg * m_pad;  // row group (m_pad rows each) and row inside it
+    const int rg = row / rpg, rl = row - rg * rpg;  // row group (rpg rows each, in slabs of m_pad rows) and row inside it
     const float* p0 = partial + ((long long)rg * n_part * m_pad + rl) * d + col;
     const long long pstride = (long long)m_pad * d;
     f32x4 res4 = {0.f, 0.f, 0.f, 0.f};
@@ -748,9 +755,14 @@ int launch_lm_mlp(const GemvArgs& a, int I, int ac, const float* wd, float* part
     // 144.0 -> 139.4 ms per generate at 32 segments), 32-row groups above (at 64 segments four groups = 512 workgroups lose: 207 vs 196 ms)
     const int mt = a.M <= 32 ? 1 : 2;
     const int n_part = I / ac;
-    const dim3 grid((unsigned)n_part, (unsigned)ceil_div(a.M, 16 * mt));  // partial: [row group][n_part][16 mt][d]
+    // 9 .. 16 sequences: two groups of 8 rows on the 16-row tile (rows 8 .. 15 of a group re-read its last row): x 16 KB per workgroup
+    // instead of 32; with the same split of the qkv launch 111.0 -> 109.7 ms per generate at 16 segments
+    const int rpg = (a.M > 8 && a.M <= 16) ? 8 : 16 * mt;
+    GemvArgs ag = a;
+    ag.rpg = rpg;
+    const dim3 grid((unsigned)n_part, (unsigned)ceil_div(a.M, rpg));  // partial: [row group][n_part][16 mt][d]
     QA_REQUIRE(ac == 16, "lm_mlp: %d activation columns per workgroup (only 16 is built)", ac);
-#define QA_MLP(MT, NB) hipLaunchKernelGGL((lm_mlp_kernel<MT, NB, 16>), grid, dim3(512), 0, s, a, wd, partial)
+#define QA_MLP(MT, NB) hipLaunchKernelGGL((lm_mlp_kernel<MT, NB, 16>), grid, dim3(512), 0, s, ag, wd, partial)
     if (a.d == 512) {
         if (mt == 1) { QA_MLP(1, 2); } else { QA_MLP(2, 2); }
     } else {
@@ -758,7 +770,7 @@ int launch_lm_mlp(const GemvArgs& a, int I, int ac, const float* wd, float* part
     }
 #undef QA_MLP
     QA_LAUNCH_CHECK();
-    hipLaunchKernelGGL((lm_mlp_reduce_kernel<16>), dim3((unsigned)(a.d / 32), (unsigned)a.M), dim3(64), 0, s, partial, n_part, 16 * mt, a.d, res,
+    hipLaunchKernelGGL((lm_mlp_reduce_kernel<16>), dim3((unsigned)(a.d / 32), (unsigned)a.M), dim3(64), 0, s, partial, n_part, 16 * mt, rpg, a.d, res,
                        ldr, y, ldy);
     QA_LAUNCH_CHECK();
     return QA_OK;
