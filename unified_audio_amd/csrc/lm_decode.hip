@@ -703,7 +703,7 @@ __global__ __launch_bounds__(512) void lm_mlp_kernel(const GemvArgs a_in, const 
 #pragma unroll
             for (int i = 0; i < KL; ++i) o = __builtin_amdgcn_mfma_f32_16x16x4f32(wdr[t][i], av[i], o, 0, 0, 0);
             const int n = wave * (d >> 3) + t * 16 + 4 * kq;
-            *reinterpret_cast<f32x4*>(pj + (long long)(m * 16 + li) * d + n) = o;
+            if (m * 16 + li < M) *reinterpret_cast<f32x4*>(pj + (long long)(m * 16 + li) * d + n) = o;  // rows past the group's M are never read back
         }
     }
 }
