@@ -59,7 +59,7 @@ struct StepGraph {  // one captured decode step of a phase, replayable because e
 struct qa_lm {
     qa_lm_spec spec{};
     int device = 0;
-    bool fused_ok = false;   // the shapes fit the fused decode step (otherwise the per-op decode path runs)
+    bool fused_ok = false;   // the shapes fit the fused decode step (required since r05: build_lm refuses a spec that does not tile)
     bool mlp_fused = false;  // QA_LM_MLP_FUSED at create time: gate/up + SwiGLU + down as one launch + a reduce launch
     int mlp_ac = 16;         // activation columns per workgroup of that launch (8 measured equal at B = 16, -4 % at B = 64: profiles/r03_lm_ab.txt)
     int att_split = 256;     // keys per workgroup of the decode attention, at most 4 splits (flat between 256 and 384, worse below: same log; re-measured in r05 with the cheaper o_proj: 128 / 160 / 192 keys 112.2 - 112.5 ms against 110.4 at 16 segments)
@@ -402,7 +402,7 @@ uint64_t mix_key(uint64_t h, uint64_t v) {
 // device memory - one more dependent load per kernel - and cannot size the attention grid to the current key count: off by default.
 bool use_graphs() { return knob(K_LM_GRAPH) != 0; }
 
-// One chain = one batch of <= 64 sequences (LM_MAX_ROWS) with its own buffers, KV cache and (for B > 32, or QA_LM_CHAINS) its own internal stream.
+// One chain = one batch of <= 64 sequences (LM_MAX_ROWS) with its own buffers, KV cache and (for B > 64, or QA_LM_CHAINS) its own internal stream.
 struct Chain {
     int b0 = 0, B = 0;  // sequences [b0, b0 + B) of the call
     LMBuffers b{};
