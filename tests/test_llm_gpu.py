@@ -345,6 +345,24 @@ def test_chains_full_width_b64_matches_b16_chunks(qa_lib, gpu_device, B):
         assert torch.equal(g1, g[B - 5:]) and torch.equal(s1, s[B - 5:])
 
 
+@pytest.mark.parametrize("spec_name", ["small", "unise"])
+def test_row_group_boundaries_do_not_change_a_token(qa_lib, gpu_device, spec_name):
+    """r05: which row groups a decode launch carries depends on the batch - 8-row groups for o_proj always and for MLP / qkv at 9 .. 16
+    sequences, 16-row groups at 17 .. 32, 32-row groups above, the o_proj tile width 4 / 8 / 16, chains above 64 - but a row's arithmetic
+    never knows its group: the first B sequences of one fixed batch must produce the same tokens for EVERY B across those boundaries."""
+    spec = SMALL if spec_name == "small" else L.SPEC_UNISE
+    _, lm = _model(spec, 29, gpu_device)
+    Bmax, Nm, Ne, S, G = 66, 6, 5, (9 if spec_name == "small" else 6), 3
+    mix = L.synth_feats(15, Bmax, Nm, spec.feats_dim).to(gpu_device)
+    enr = L.synth_feats(16, Bmax, Ne, spec.feats_dim).to(gpu_device)
+    mel = torch.zeros(Bmax, S, 80)
+    g, s = lm.generate("tse", mel, enr, mel, mix, global_length=G, do_sample=False)
+    sizes = (1, 7, 8, 9, 15, 16, 17, 31, 32, 33, 47, 48, 63, 64, 65) if spec_name == "small" else (8, 9, 16, 17, 32, 33, 64, 65)
+    for B in sizes:
+        gb, sb = lm.generate("tse", mel[:B], enr[:B], mel[:B], mix[:B], global_length=G, do_sample=False)
+        assert torch.equal(gb, g[:B]) and torch.equal(sb, s[:B]), B
+
+
 def test_sampled_chains_key_the_rng_by_the_global_sequence_index(qa_lib, gpu_device, knob):
     """The device sampler's Philox stream is keyed by (seed, sequence index IN THE CALL, step): splitting a call into chains must not
     change a draw."""
