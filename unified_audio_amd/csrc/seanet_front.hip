@@ -47,7 +47,8 @@ __device__ __forceinline__ f32x4 elu4(f32x4 v) {
 //     the padded signal at frame + k, C-in = the bias - i.e. the SAME fma chain in the same order as conv_in_kernel (ew.hip): x is still
 //     bit-identical to the standalone kernel's, and ~110 of a thread's ~400 vector instructions per tile are gone.
 //   * All weights live in 52 VGPRs per lane for the life of the persistent workgroup (lane (i = lane & 15, kq = lane >> 4) holds row i of
-//     a 16-row block at k = 16 s + 4 kq .. + 3): no weight traffic through LDS, LDS holds only the two x tiles (38 KB: 4 workgroups per CU).
+//     a 16-row block at k = 16 s + 4 kq .. + 3): no weight traffic through LDS; LDS holds the two x tiles and a wave-private hidden tile per wave (49 KB: 3
+//     workgroups per CU); TWO workgroup barriers per tile (x tile written / previous tile no longer read) instead of five; outputs are stored from registers.
 // Operand convention as before (weights = the MFMA's row operand, activations = its column operand): D gives lane (frame = lane & 15)
 // the 4 consecutive channels 4 (lane >> 4) .. + 3 of its 16-channel block: float4 stores everywhere.
 // The K slots of a 16-wide chunk are visited in the order k = e + 4 kq (e = the float4 component = one MFMA, kq = the slot inside it):
@@ -57,16 +58,15 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int C>
 __global__ __launch_bounds__(256) void seanet_block_kernel(const SeanetFrontParams p) {
     static_assert(C == 32, "two 16-channel blocks");
-    constexpr int ROWS = 128, XR = ROWS + 2, LDX = C + 4, HSLD = C + 4, C4 = C / 4;
+    constexpr int ROWS = 128, XR = ROWS + 2, LDX = C + 4, HLD = 16 + 4;
     constexpr int WSN = XR + 6;       // wav samples under one x tile (k7)
     constexpr int WSP = 9 * 16 + 8;   // padded window length: the 9th frame block of the conv0 phase reads up to sample 151
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* XS = smem;               // [XR][LDX]  x tile (raw): the shortcut operand
     float* XE = XS + XR * LDX;      // [XR][LDX]  ELU(x): the k3 operand
-    float* HS = XE;                 // [4][32][HSLD]  per wave: hidden tile, then the output staging - ALIASES the ELU(x) tile, which is
-                                    // dead once every wave has finished its k3 contraction (barrier below)
-    static_assert(4 * 32 * HSLD <= XR * LDX, "hidden / output staging must fit in the ELU(x) tile");
-    float* WS = XE + XR * LDX;      // [2][WSP] wav window of the current / next tile (reflect padding of the k7 resolved at staging)
+    float* HS = XE + XR * LDX;      // [4][32][HLD]  per WAVE: its 32 x 16 hidden tile - wave-private, so the k3 -> hidden -> 1x1 chain of a wave
+                                    // needs no workgroup barrier (the round-2 kernel aliased it onto the ELU(x) tile: two barriers per tile)
+    float* WS = HS + 4 * 32 * HLD;  // [2][WSP] wav window of the current / next tile (reflect padding of the k7 resolved at staging)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void seanet_block_kernel(const SeanetFrontPara
 
     const int L = p.L;
     const int tiles_per_clip = (L + ROWS - 1) / ROWS, n_tiles = p.B * tiles_per_clip;
-    float* HSw = HS + wave * 32 * HSLD;
+    float* HSw = HS + wave * 32 * HLD;
     // sample u of a tile's window is wav[reflect(r0 - pl3 - pl0 + u)]; one sample per thread, fetched one tile ahead
     auto wav_fetch = [&](int tile_) -> float {
         if (tile_ >= n_tiles || tid >= WSN) return 0.f;
@@ -147,17 +147,19 @@ __global__ __launch_bounds__(256) void seanet_block_kernel(const SeanetFrontPara
                 h[fbk] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3r[s].w, av.w, h[fbk], 0, 0, 0);
             }
         }
-        __syncthreads();  // every wave is done with the ELU(x) tile: it becomes the hidden tile
+        // hidden tile: written and read by this wave only (LDS operations of a wave complete in order; the compiler's lgkmcnt waits cover it)
 #pragma unroll
-        for (int fbk = 0; fbk < 2; ++fbk) *reinterpret_cast<f32x4v*>(HSw + (16 * fbk + li) * HSLD + 4 * kq) = elu4(h[fbk]);
-        __syncthreads();
+        for (int fbk = 0; fbk < 2; ++fbk) *reinterpret_cast<f32x4v*>(HSw + (16 * fbk + li) * HLD + 4 * kq) = elu4(h[fbk]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         // ---- a = ELU([x | hidden] [W_sc | W_1x1]^T + (b_sc + b_1x1))
         f32x4v o[2][2];
 #pragma unroll
         for (int fbk = 0; fbk < 2; ++fbk) {
             const float* xrow = XS + (wave * 32 + 16 * fbk + li + p.pl3) * LDX + 4 * kq;
-            const float* hrow = HSw + (16 * fbk + li) * HSLD + 4 * kq;
+            const float* hrow = HSw + (16 * fbk + li) * HLD + 4 * kq;
             const f32x4v a0 = *reinterpret_cast<const f32x4v*>(xrow), a1 = *reinterpret_cast<const f32x4v*>(xrow + 16);
             const f32x4v a2 = *reinterpret_cast<const f32x4v*>(hrow);
 #pragma unroll
@@ -174,27 +176,24 @@ __global__ __launch_bounds__(256) void seanet_block_kernel(const SeanetFrontPara
                 o[fbk][cb] = v;
             }
         }
-        __syncthreads();  // every lane of the wave has read its hidden rows: the region becomes the output staging
+        // output: a lane holds 4 consecutive channels of a frame per (frame block, channel block); the four lanes kq = 0 .. 3 of a frame write
+        // 64 contiguous bytes, the two channel blocks complete the frame's 128-byte line - straight from registers, no staging, no barrier
 #pragma unroll
-        for (int fbk = 0; fbk < 2; ++fbk)
+        for (int fbk = 0; fbk < 2; ++fbk) {
+            const int t = r0 + wave * 32 + 16 * fbk + li;
+            if (t < L) {
+                float* dst = p.a + ((long long)b * L + t) * C + 4 * kq;
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-                *reinterpret_cast<f32x4v*>(HSw + (16 * fbk + li) * HSLD + 16 * cb + 4 * kq) = elu4(o[fbk][cb]);
-        __syncthreads();
-        // a store instruction of the wave covers 64 / C4 whole frames = 1 KB contiguous
-#pragma unroll
-        for (int it = 0; it < 32 * C4 / 64; ++it) {
-            const int e = it * 64 + lane, row = e / C4, c4 = (e - row * C4) * 4;
-            const int t = r0 + wave * 32 + row;
-            if (t < L) *reinterpret_cast<f32x4v*>(p.a + ((long long)b * L + t) * C + c4) = *reinterpret_cast<const f32x4v*>(HSw + row * HSLD + c4);
+                for (int cb = 0; cb < 2; ++cb) *reinterpret_cast<f32x4v*>(dst + 16 * cb) = elu4(o[fbk][cb]);
+            }
         }
-        if (tid < WSN) WS[(cur ^ 1) * WSP + tid] = wnext;  // that buffer was last read before this tile's second barrier
+        if (tid < WSN) WS[(cur ^ 1) * WSP + tid] = wnext;  // that buffer was last read before this tile's second barrier (the conv0 phase)
     }
 }
 
 static size_t seanet_block_lds_bytes(int C) {
-    const int XR = 130, LDX = C + 4, WSP = 9 * 16 + 8;
-    return sizeof(float) * ((size_t)2 * XR * LDX + 2 * WSP);
+    const int XR = 130, LDX = C + 4, WSP = 9 * 16 + 8, HLD = 20;
+    return sizeof(float) * ((size_t)2 * XR * LDX + 4 * 32 * HLD + 2 * WSP);
 }
 
 bool seanet_front_supported(int C, int hid, int L) {
@@ -219,7 +218,7 @@ int launch_seanet_front(const float* wav, const float* w0, const float* b0, cons
     p.Lp0 = L <= mp0 ? mp0 + 1 : L;
     const size_t lds = seanet_block_lds_bytes(C);
     const long long n_tiles = (long long)B * ceil_div(L, 128);
-    const unsigned grid = (unsigned)std::min<long long>(n_tiles, 1024);  // persistent: four workgroups per CU (38 KB of LDS each), weights loaded once each
+    const unsigned grid = (unsigned)std::min<long long>(n_tiles, 768);  // persistent: three workgroups per CU (49 KB of LDS each), weights loaded once each
     QA_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(seanet_block_kernel<32>), (int)lds));
     HbmProf prof_(HK_SEANET_FRONT, 4.0 * ((double)B * L + (double)B * L * C), s);  // wav in, the block output `a` written once
     hipLaunchKernelGGL((seanet_block_kernel<32>), dim3(grid), dim3(256), lds, s, p);
