@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import Dict, Tuple
+from typing import Any, Dict, Mapping, Tuple
 
 import torch
 
@@ -50,6 +50,68 @@ class BiCodecSpec:
             n *= lv
         return n
 
+    @classmethod
+    def from_config(cls, audio_tokenizer: Mapping[str, Any]) -> "BiCodecSpec":
+        """The `audio_tokenizer` section of `{model_dir}/config.yaml`, block by block as `BiCodec.load_from_checkpoint` hands it to its
+        module constructors (bicodec.py:80-87): `quantizer` -> FactorizedVectorQuantize (factorized_vector_quantize.py:37-48),
+        `speaker_encoder` -> SpeakerEncoder (speaker_encoder.py:48-56), `prenet` -> Decoder (feat_decoder.py:37-47), `decoder` ->
+        WaveGenerator (wave_generator.py:60-67).  A missing required key is a TypeError and an unknown key in a block whose constructor
+        takes no **kwargs is a TypeError, as in the reference; a value the detokenizer kernels have no path for is refused by name
+        (QuarkAudioError -4) instead of being ignored.  `mel_params`, `encoder` and `postnet` configure the encoder / training side
+        (tokenize, forward) and are not read."""
+        def block(name, required, optional=(), open_kwargs=False):
+            if name not in audio_tokenizer:
+                raise KeyError(f"config.yaml: audio_tokenizer.{name} is missing (bicodec.py:80-87 reads it)")
+            b = dict(audio_tokenizer[name])
+            missing = [k for k in required if k not in b]
+            if missing:
+                raise TypeError(f"audio_tokenizer.{name}: missing required argument(s) {missing}")
+            unknown = [k for k in b if k not in required and k not in optional]
+            if unknown and not open_kwargs:
+                raise TypeError(f"audio_tokenizer.{name}: unexpected keyword argument(s) {unknown}")
+            return b
+
+        def refuse(what):
+            raise _lib.QuarkAudioError(-4, f"BiCodec config.yaml: {what} - the MI355X detokenizer has no path for it")
+
+        q = block("quantizer", ("input_dim", "codebook_size", "codebook_dim", "commitment"), open_kwargs=True)  # **kwargs: training-side keys pass
+        spk = block("speaker_encoder", (), ("input_dim", "out_dim", "latent_dim", "token_num", "fsq_levels", "fsq_num_quantizers"))
+        pre = block("prenet", ("input_channels", "vocos_dim", "vocos_intermediate_dim", "vocos_num_layers", "out_channels"),
+                    ("condition_dim", "sample_ratios", "use_tanh_at_final"))
+        dec = block("decoder", ("input_channel", "channels", "rates", "kernel_sizes"), ("d_out",))
+        latent = int(q["input_dim"])
+        if int(q["codebook_dim"]) == latent:
+            refuse("quantizer.input_dim == codebook_dim (Identity projections, factorized_vector_quantize.py:59-65)")
+        spk_out = int(spk.get("out_dim", 512))
+        if int(spk.get("fsq_num_quantizers", 1)) != 1:
+            refuse(f"speaker_encoder.fsq_num_quantizers = {spk['fsq_num_quantizers']} (one FSQ stage is built)")
+        levels = tuple(int(v) for v in spk.get("fsq_levels", (4, 4, 4, 4, 4, 4)))
+        if not 1 <= len(levels) <= 8:
+            refuse(f"speaker_encoder.fsq_levels with {len(levels)} entries (1 .. 8)")
+        if [int(r) for r in pre.get("sample_ratios", (1, 1))] != [1, 1]:
+            refuse(f"prenet.sample_ratios = {list(pre['sample_ratios'])} (the two ratio-1 SamplingBlocks of the published model are built)")
+        if bool(pre.get("use_tanh_at_final", False)):
+            refuse("prenet.use_tanh_at_final = true")
+        if int(dec.get("d_out", 1)) != 1:
+            refuse(f"decoder.d_out = {dec['d_out']} (mono)")
+        rates, ks = tuple(int(v) for v in dec["rates"]), tuple(int(v) for v in dec["kernel_sizes"])
+        if len(rates) != len(ks) or not 1 <= len(rates) <= 8:
+            refuse(f"decoder.rates / kernel_sizes of lengths {len(rates)} / {len(ks)} (equal, 1 .. 8)")
+        # the tensors that meet in detokenize (bicodec.py:193-199): z_q [latent] -> prenet -> + d_vector [spk_out] -> decoder
+        widths = {"quantizer.input_dim": latent, "prenet.input_channels": int(pre["input_channels"]), "prenet.out_channels": int(pre["out_channels"]),
+                  "prenet.condition_dim": int(pre["condition_dim"]) if pre.get("condition_dim") is not None else None,
+                  "speaker_encoder.out_dim": spk_out, "decoder.input_channel": int(dec["input_channel"])}
+        if widths["prenet.condition_dim"] is None:
+            refuse("prenet.condition_dim = null (detokenize conditions the prenet on the d-vector)")
+        if len(set(widths.values())) != 1:
+            raise ValueError(f"BiCodec config.yaml: widths that must agree in detokenize differ: {widths}")
+        mel = audio_tokenizer.get("mel_params") or {}
+        return cls(latent_dim=latent, codebook_size=int(q["codebook_size"]), codebook_dim=int(q["codebook_dim"]),
+                   mel_dim=int(spk.get("input_dim", mel.get("num_mels", 100))), spk_latent_dim=int(spk.get("latent_dim", 128)),
+                   token_num=int(spk.get("token_num", 32)), fsq_levels=levels, vocos_dim=int(pre["vocos_dim"]),
+                   vocos_inter=int(pre["vocos_intermediate_dim"]), vocos_layers=int(pre["vocos_num_layers"]),
+                   gen_channels=int(dec["channels"]), rates=rates, kernel_sizes=ks)
+
     def to_c(self) -> "_lib.qa_bicodec_spec":
         s = _lib.qa_bicodec_spec()
         s.latent_dim, s.codebook_size, s.codebook_dim = self.latent_dim, self.codebook_size, self.codebook_dim
@@ -66,6 +128,41 @@ class BiCodecSpec:
 SPEC_BICODEC = BiCodecSpec()
 
 
+def load_config(config_path) -> Dict[str, Any]:
+    """utils/file.py:116-130 (`OmegaConf.load` + the optional `base_config` merge) with PyYAML: omegaconf is not a dependency here.  A
+    value that uses OmegaConf interpolation (`${...}`) cannot be resolved by a plain YAML reader and is refused rather than passed on."""
+    import yaml
+
+    def read(path):
+        with open(path, "r") as f:
+            cfg = yaml.safe_load(f) or {}
+        if not isinstance(cfg, dict):
+            raise ValueError(f"{path}: a mapping is expected at the top level")
+        return cfg
+
+    def merge(base, over):  # OmegaConf.merge: mappings merge key by key, everything else is replaced
+        out = dict(base)
+        for k, v in over.items():
+            out[k] = merge(out[k], v) if isinstance(v, dict) and isinstance(out.get(k), dict) else v
+        return out
+
+    def check(node, where):
+        if isinstance(node, dict):
+            for k, v in node.items():
+                check(v, f"{where}.{k}")
+        elif isinstance(node, (list, tuple)):
+            for i, v in enumerate(node):
+                check(v, f"{where}[{i}]")
+        elif isinstance(node, str) and "${" in node:
+            raise _lib.QuarkAudioError(-4, f"{config_path}: {where} = {node!r} uses OmegaConf interpolation, which this loader does not resolve")
+
+    cfg = read(config_path)
+    if cfg.get("base_config") is not None:
+        cfg = merge(read(cfg["base_config"]), cfg)
+    check(cfg, "config")
+    return cfg
+
+
 class BiCodec(torch.nn.Module):
     """`detokenize(semantic_tokens, global_tokens)` of the reference's BiCodec.  Weights in the reference's key layout
     (`BiCodec.state_dict()` / the `model.safetensors` of the checkpoint; encoder-side entries are ignored)."""
@@ -79,10 +176,14 @@ class BiCodec(torch.nn.Module):
         self._handle = C.c_void_p()
 
     @classmethod
-    def load_from_checkpoint(cls, model_dir, device="cuda:0", spec: BiCodecSpec = SPEC_BICODEC, **kwargs) -> "BiCodec":
-        """bicodec.py:70-115: `{model_dir}/model.safetensors` (the architecture comes from `spec`; config.yaml is not parsed)."""
+    def load_from_checkpoint(cls, model_dir, device="cuda:0", spec: BiCodecSpec | None = None, **kwargs) -> "BiCodec":
+        """bicodec.py:69-115: the architecture from `{model_dir}/config.yaml['audio_tokenizer']` (BiCodecSpec.from_config), the weights
+        from `{model_dir}/model.safetensors`; missing detokenizer tensors are reported by name by qa_bicodec_create (the reference prints
+        them and goes on with random weights, bicodec.py:103-108).  `spec=` overrides the file (a directory without config.yaml)."""
         from safetensors.torch import load_file
 
+        if spec is None:
+            spec = BiCodecSpec.from_config(load_config(f"{model_dir}/config.yaml")["audio_tokenizer"])
         return cls(spec, device=device).load_state_dict(load_file(f"{model_dir}/model.safetensors"))
 
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = False, assign: bool = False):
@@ -161,12 +262,18 @@ class BiCodecTokenizer(torch.nn.Module):
     """Decode side of the reference's BiCodecTokenizer (QuarkAudio-UniSE/model/bicodec/audio_tokenizer.py:107-120), the object
     `Model.test_step` calls: `detokenize(global_tokens [B, 1, 32], semantic_tokens [B, T]) -> wav [B, 1, T * 320]`."""
 
-    def __init__(self, model_dir=None, device="cuda:0", *, model: BiCodec | None = None, spec: BiCodecSpec = SPEC_BICODEC, **kwargs):
+    def __init__(self, model_dir=None, device="cuda:0", *, model: BiCodec | None = None, spec: BiCodecSpec | None = None, **kwargs):
         super().__init__()
+        self.model_dir = model_dir
+        self.config = None
         if model is None:
             if model_dir is None:
-                raise ValueError("BiCodecTokenizer needs model_dir (with BiCodec/model.safetensors) or model=")
-            model = BiCodec.load_from_checkpoint(f"{model_dir}/BiCodec", device=device, spec=spec)  # audio_tokenizer.py:50-53
+                raise ValueError("BiCodecTokenizer needs model_dir (with BiCodec/config.yaml and BiCodec/model.safetensors) or model=")
+            import os
+
+            if os.path.isfile(f"{model_dir}/config.yaml"):  # audio_tokenizer.py:40 (sample_rate, ref_segment_duration, latent_hop_length: tokenize side)
+                self.config = load_config(f"{model_dir}/config.yaml")
+            model = BiCodec.load_from_checkpoint(f"{model_dir}/BiCodec", device=device, spec=spec)  # audio_tokenizer.py:45
         self.model = model
         self.device = model.device
 

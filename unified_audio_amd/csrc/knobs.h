@@ -11,7 +11,8 @@ namespace qa {
 
 #define QA_KNOB_TABLE(X)                                                                                                           \
     X(SERIAL, "QA_SERIAL", 0, "1: no internal stream concurrency (every kernel alone on the device; = qa_set_serial)")           \
-    X(GEMM_CFG, "QA_GEMM_CFG", -1, "force the conv_gemm tile: 0 = 128x32, 1 = 128x64, 2 = 128x128, 3 = 64x128, 4 = 64x64 (-1: cost model)")             \
+    X(GEMM_CFG, "QA_GEMM_CFG", -1, "force the conv_gemm tile: 0 = 128x32, 1 = 128x64, 2 = 128x128, 3 = 64x128, 4 = 64x64, 5 = 256x128 (LINEAR layers; else 128x128) (-1: cost model)")             \
+    X(GEMM_256, "QA_GEMM_256", 0, "r06 experiment: 256x128 block tile (4 waves, 4x2 accumulators each) for LINEAR layers with M >= 8000 and N >= 1024; value = its efficiency relative to 128x128 in 1/1000 for the cost model (0: never chosen; QA_GEMM_CFG=5 forces it)") \
     X(GEMM_BK16, "QA_GEMM_BK16", 1 << 30, "largest K that takes the BK = 16 K-chunk variant")                                     \
     X(GEMM_BK16_MIN_TILES, "QA_GEMM_BK16_MIN_TILES", 384, "fewest tiles of a launch that take BK = 16")                          \
     X(GEMM_LINEAR, "QA_GEMM_LINEAR", 1, "table-free K loop for ksize-1 layers")                                                  \
@@ -28,6 +29,8 @@ namespace qa {
     X(LSTM_FAULT, "QA_LSTM_FAULT", 0, "1 (tests): the persistent kernel's barrier waits for a workgroup that does not exist, like a starved launch") \
     X(LM_GRAPH, "QA_LM_GRAPH", 0, "1: replay one captured decode step per token")                                                \
     X(LM_MLP_FUSED, "QA_LM_MLP_FUSED", 1, "decode step: gate/up + SwiGLU + down of 16 activation columns per workgroup in one launch emitting K-slice partials, summed by a reduce launch (0: separate gate/up and down launches)") \
+    X(LM_PF, "QA_LM_PF", 7, "decode step: cross-launch L2 weight prefetch planes (bit mask; lm_decode.h PfArgs): 1 qkv launch -> o_proj weights, 2 o_proj launch -> fused-MLP weights, 4 MLP launch -> next layer's qkv weights (last layer: the head slice), 8 head launch -> layer 0 qkv weights") \
+    X(LM_ROWSPLIT, "QA_LM_ROWSPLIT", 3, "decode step at 9 .. 16 sequences: two 8-row groups instead of one 16-row group in the qkv launch (bit 1) and the fused-MLP launch (bit 2)") \
     X(LM_CHAINS, "QA_LM_CHAINS", 0, "generate: number of concurrent chains on internal streams (0: ceil(B / 64) - one chain serves up to 64 sequences, two row groups of 32 per launch; a count that would put more than 64 sequences into a chain is raised)")
 
 enum Knob {

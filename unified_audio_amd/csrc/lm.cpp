@@ -332,19 +332,40 @@ int fused_step(qa_lm* lm, const LMBuffers& b, int B, int lo, int width, long lon
     const size_t cache_stride = (size_t)B * b.cap * d;
     // key split of the attention launch: a workgroup's 8 waves hold 2 tiles of 16 keys each per round
     const int S_att = pos >= 0 ? std::max(1, std::min(4, (int)ceil_div(pos + 1, lm->att_split))) : b.S_att;
+    // cross-launch prefetch (QA_LM_PF, lm_decode.h PfArgs): which launch carries the prefetch plane for which consumer
+    const long long pfk = knob(K_LM_PF);
+    const bool fused_mlp = lm->mlp_fused;
+    auto pf_region = [](PfArgs& pf, int r, const float* w, long long tile_bytes, int n_tiles) {
+        pf.p[r] = reinterpret_cast<const char*>(w);
+        pf.tile_bytes[r] = tile_bytes;
+        pf.n_tiles[r] = n_tiles;
+    };
+    auto pf_mlp = [&](PfArgs& pf, const LMLayer& L) {  // the fused MLP launch: workgroup j streams 2 gate/up tiles (32 rows) and W_down slice j
+        if (!fused_mlp || !L.down_dec) return;
+        pf_region(pf, 0, L.gu_dec, (long long)2 * lm->mlp_ac * d * 4, I / lm->mlp_ac);
+        pf_region(pf, 1, L.down_dec, (long long)lm->mlp_ac * d * 4, I / lm->mlp_ac);
+    };
     for (int i = 0; i < sp.n_layers; ++i) {
         const LMLayer& L = lm->layers[i];
         float* kc = b.kc + i * cache_stride;
         float* vc = b.vc + i * cache_stride;
         GemvArgs a{};
         a.M = B; a.rms_eps = sp.rms_eps; a.state = b.state; a.pos = pos; a.H = H; a.hd = hd; a.d = d;
+        // o_proj's tile width (computed here: the qkv launch may prefetch its weights)
+        int nt_o = lm->nt_o;
+        if (gemv_r8_ok(d)) {
+            if (B > 16 && nt_o < 8 && d % 8 == 0) nt_o = 8;
+            if (B > 32 && nt_o < 16 && d % 16 == 0) nt_o = 16;
+        }
         // 1. RMSNorm + QKV + RoPE + cache append; layer 0 gathers its input rows from codec_embedding (llm_sft.py:140,169)
         GemvArgs q = a;
         q.x = b.x; q.ldx = d;
         if (i == 0) { q.tok = b.tok; q.table = lm->codec_emb; }
         q.w = L.qkv_dec; q.N = 3 * d; q.K = d;
         q.rope = lm->rope; q.q = b.q; q.kc = kc; q.vc = vc; q.kv_bstride = kv_bstride;
-        QA_TRY(launch_lm_gemv(q, GM_QKV, lm->nt_qkv, s));
+        PfArgs qpf{};
+        if (pfk & 1) pf_region(qpf, 0, L.o.w, (long long)nt_o * d * 4, d / nt_o);
+        QA_TRY(launch_lm_gemv(q, GM_QKV, lm->nt_qkv, s, &qpf));
         // 2. attention over the cache (pos + 1 keys), split over S_att workgroups per (sequence, head)
         QA_TRY(launch_lm_attn(b.q, d, kc, vc, kv_bstride, d, b.att_part, B, H, hd, S_att, b.state, scale, pos, s));
         // 3. merge of the partials + o_proj + residual
@@ -357,15 +378,19 @@ int fused_step(qa_lm* lm, const LMBuffers& b, int B, int lo, int width, long lon
         // batch, but every column tile re-reads and re-merges the partials of its rows - so the launch keeps ~256 workgroups: 4 columns x 2
         // row groups at 16 sequences, 8 x 4 at 32, 16 x 8 at 64 (r05 A/B, generate ms at 16 / 32 / 64 sequences: width 4 110.4 / 147.4 / 206.5,
         // width 8 113.1 / 143.7 / 198.6, width 16 118.5 / 149.2 / 196.4; profiles/r05_lm_oproj_ab.txt)
-        int nt_o = lm->nt_o;
-        if (B > 16 && nt_o < 8 && d % 8 == 0) nt_o = 8;
-        if (B > 32 && nt_o < 16 && d % 16 == 0) nt_o = 16;
-        QA_TRY(launch_lm_gemv(o, GM_RESID, nt_o, s));
+        PfArgs opf{};
+        if (pfk & 2) pf_mlp(opf, L);
+        QA_TRY(launch_lm_gemv(o, GM_RESID, nt_o, s, &opf));
         // 4. RMSNorm + gate / up + SwiGLU
         GemvArgs g = a;
         g.x = b.x; g.ldx = d; g.w = L.gu_dec; g.N = 2 * I; g.K = d; g.y = b.u; g.ldy = I;
         if (lm->mlp_fused && L.down_dec) {  // 4 + 5 as the fused MLP launch + the reduce launch (lm_decode.hip)
-            QA_TRY(launch_lm_mlp(g, I, lm->mlp_ac, L.down_dec, b.mlp_part, b.x, d, b.x, d, s));
+            PfArgs gpf{};
+            if (pfk & 4) {
+                if (i + 1 < sp.n_layers) pf_region(gpf, 0, lm->layers[i + 1].qkv_dec, (long long)lm->nt_qkv * d * 4, 3 * d / lm->nt_qkv);
+                else pf_region(gpf, 0, lm->head.w + (size_t)lo * d, (long long)head_nt(width) * d * 4, width / head_nt(width));
+            }
+            QA_TRY(launch_lm_mlp(g, I, lm->mlp_ac, L.down_dec, b.mlp_part, b.x, d, b.x, d, s, &gpf));
             continue;
         }
         QA_TRY(launch_lm_gemv(g, GM_GATEUP, lm->nt_gu, s));
@@ -381,7 +406,9 @@ int fused_step(qa_lm* lm, const LMBuffers& b, int B, int lo, int width, long lon
     hg.M = B; hg.rms_eps = sp.rms_eps; hg.state = b.state; hg.pos = pos; hg.H = H; hg.hd = hd; hg.d = d;
     hg.x = b.x; hg.ldx = d; hg.w = lm->head.w + (size_t)lo * d; hg.N = width; hg.K = d;
     hg.pmax = b.pmax; hg.pidx = b.pidx; hg.logits = sc.do_sample ? b.logits : nullptr; hg.ldl = width;
-    QA_TRY(launch_lm_gemv(hg, GM_HEAD, nt, s));
+    PfArgs hpf{};
+    if (pfk & 8) pf_region(hpf, 0, lm->layers[0].qkv_dec, (long long)lm->nt_qkv * d * 4, 3 * d / lm->nt_qkv);
+    QA_TRY(launch_lm_gemv(hg, GM_HEAD, nt, s, &hpf));
     // 7. next token
     if (!sc.do_sample) {
         QA_TRY(launch_lm_pick(b.pmax, b.pidx, width / nt, B, lo, b.tok, ids, ids_ld, keep, b.state, col, s));
@@ -531,7 +558,7 @@ int generate_graph(qa_lm* lm, Ctx& c, int task, const float* enroll, int Ne, con
                 uint64_t key = 0x51ull;
                 for (uint64_t v : {(uint64_t)(uintptr_t)lm->ws, (uint64_t)B, (uint64_t)nc, (uint64_t)ch.b0, (uint64_t)ch.B, (uint64_t)cap, (uint64_t)L,
                                    (uint64_t)G, (uint64_t)S, (uint64_t)Ne, (uint64_t)Nm, (uint64_t)(enroll != nullptr), (uint64_t)lo, (uint64_t)width, (uint64_t)keep, (uint64_t)sc.do_sample,
-                                   (uint64_t)sc.top_k, (uint64_t)(sc.top_p * 1e6f), (uint64_t)(sc.temperature * 1e6f)})
+                                   (uint64_t)sc.top_k, (uint64_t)(sc.top_p * 1e6f), (uint64_t)(sc.temperature * 1e6f), (uint64_t)knob(K_LM_PF)})
                     key = mix_key(key, v);
                 if (!g.exec || g.key != key) {
                     g.reset();

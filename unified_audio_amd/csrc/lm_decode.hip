@@ -39,6 +39,37 @@ __device__ __forceinline__ float4 ldg_nt(const float* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// The prefetch plane of a launch (lm_decode.h, PfArgs): workgroup `id` of `count` touches one word per 64 bytes of the consumer tiles
+// j = id, id + count, ...  Plain (cached) loads: the lines are meant to stay in this XCD's L2.  Four loads in flight per thread and pass;
+// the empty asm consumes the sum so that the loads exist.
+__device__ __forceinline__ void lm_prefetch(const PfArgs& pf, int id, int count) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    unsigned acc = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (!pf.p[r]) continue;
+        const long long tb = pf.tile_bytes[r], step = (long long)nthr * 64;
+        for (int j = id; j < pf.n_tiles[r]; j += count) {
+            const char* base = pf.p[r] + (long long)j * tb;
+            for (long long o = (long long)tid * 64; o < tb; o += 4 * step) {
+                unsigned v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long oo = o + u * step;
+                    v[u] = oo < tb ? *reinterpret_cast<const unsigned*>(base + oo) : 0u;
+                }
+                acc += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+        }
+    }
+    asm volatile("" ::"v"(acc));
+}
+#define QA_LM_PF_PLANE(pf)                                                                   \
+    if (__builtin_expect(blockIdx.z != 0, 0)) {                                              \
+        lm_prefetch(pf, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);         \
+        return;                                                                              \
+    }
+
 #ifdef QA_LM_TIMING  // tuning builds only (tools/variants.py): shader-cycle totals per GEMV kind and phase, wave 0 of every workgroup
 __device__ unsigned long long g_lm_timing[6][6];
 #define LMT_DECL long long lmt_last = __builtin_readcyclecounter(); const int lmt_kind = (MODE == GM_RESID && ATT) ? 4 : MODE;
@@ -270,7 +301,8 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const float (*p
 // activation load of the batch is issued before the first MFMA, so a wave pays one memory round trip per batch instead of one per
 // chunk (hipcc does not software-pipeline the chunk loop by itself).
 template <int MT, int NT, int MODE, bool ATT, int NB>
-__global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a_in) {
+__global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a_in, const PfArgs pf) {
+    QA_LM_PF_PLANE(pf)
     GemvArgs a = a_in;
     if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x, a.rpg ? a.rpg : 16 * MT);
     __shared__ float part[8][MT][16][17];
@@ -374,8 +406,9 @@ __global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a_in) {
 // (8 phases of 4 k, 32-wide steps), so a workgroup pulls the attention partials of 8 rows instead of 16 (row_group above).  A row's
 // products are the same set in the same per-lane order; only the cross-lane fold gains one shuffle.
 template <int MT, int C, int MODE, bool ATT, int NS, bool R8 = false>
-__global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a_in) {
+__global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a_in, const PfArgs pf) {
     static_assert(!R8 || MT == 1, "8-row groups exist for one row tile");
+    QA_LM_PF_PLANE(pf)
     GemvArgs a = a_in;
     if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x, R8 ? 8 : 16 * MT);
     constexpr int NT = 4 * C;
@@ -494,33 +527,46 @@ static int gemv_nb(int K) {
     return nchunk % 8 == 0 ? 8 : 0;
 }
 
+// the o_proj launch widens its column tile with the batch; widths 4 / 8 / 16 share one per-row summation order only on the
+// 8-row kernel (lm_gemv4_kernel R8, taken when a wave's K share is an even number of 32-wide chunks) - where it does not exist (hidden 256)
+// width 16 would fall to the 16x16x4 kernel with another K partition, so lm.cpp keeps the model's width there
+bool gemv_r8_ok(int K) { return gemv_nb(K) > 0 && gemv_nb(K) % 2 == 0; }
+
+// the prefetch plane: a second z-plane of workgroups when the launch carries prefetch work (lm_decode.h, PfArgs)
+static dim3 with_pf_plane(dim3 g, const PfArgs& pf) {
+    if (pf.p[0] || pf.p[1]) g.z = 2;
+    return g;
+}
+
 template <int MODE, bool ATT, int NB>
-static int launch_gemv_nb(const GemvArgs& a, int nt, hipStream_t s) {
+static int launch_gemv_nb(const GemvArgs& a_in, int nt, hipStream_t s, const PfArgs* pf_in) {
+    GemvArgs a = a_in;
+    PfArgs pf = pf_in ? *pf_in : PfArgs{};
     // y: row groups.  16 rows each (MT = 1) for up to 16 sequences (8 for the o_proj launch, ATT: see row_group), 32 rows (MT = 2) otherwise
     // ... and for the qkv launch up to 32 sequences (139.4 -> 136.0 ms at 32 segments; at 64 segments 32-row groups win: 196 vs 198 ms)
     const bool mt1 = a.M <= 16 || ATT || (MODE == GM_QKV && a.M <= 32);
-    if (MODE == GM_QKV && a.M > 8 && a.M <= 16 && nt == 16) {  // 9 .. 16 sequences: two 8-row groups (see launch_lm_mlp)
-        GemvArgs a8 = a;
-        a8.rpg = 8;
-        hipLaunchKernelGGL((lm_gemv_kernel<1, 16, MODE, ATT, NB>), dim3((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, 8)), dim3(512), 0, s, a8);
+    if (MODE == GM_QKV && a.M > 8 && a.M <= 16 && nt == 16 && (knob(K_LM_ROWSPLIT) & 1)) {  // 9 .. 16 sequences: two 8-row groups (see launch_lm_mlp)
+        a.rpg = 8;
+        const dim3 grid = with_pf_plane(dim3((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, 8)), pf);
+        hipLaunchKernelGGL((lm_gemv_kernel<1, 16, MODE, ATT, NB>), grid, dim3(512), 0, s, a, pf);
         QA_LAUNCH_CHECK();
         return QA_OK;
     }
     if constexpr (ATT) {  // the o_proj launch on narrow tiles: 8-row groups (lm_gemv4_kernel R8)
         if (NB % 2 == 0) {
-            const dim3 grid8((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, 8));
-            if (nt == 16) hipLaunchKernelGGL((lm_gemv4_kernel<1, 4, MODE, ATT, NB, true>), grid8, dim3(512), 0, s, a);
-            else if (nt == 8) hipLaunchKernelGGL((lm_gemv4_kernel<1, 2, MODE, ATT, NB, true>), grid8, dim3(512), 0, s, a);
-            else hipLaunchKernelGGL((lm_gemv4_kernel<1, 1, MODE, ATT, NB, true>), grid8, dim3(512), 0, s, a);
+            const dim3 grid8 = with_pf_plane(dim3((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, 8)), pf);
+            if (nt == 16) hipLaunchKernelGGL((lm_gemv4_kernel<1, 4, MODE, ATT, NB, true>), grid8, dim3(512), 0, s, a, pf);
+            else if (nt == 8) hipLaunchKernelGGL((lm_gemv4_kernel<1, 2, MODE, ATT, NB, true>), grid8, dim3(512), 0, s, a, pf);
+            else hipLaunchKernelGGL((lm_gemv4_kernel<1, 1, MODE, ATT, NB, true>), grid8, dim3(512), 0, s, a, pf);
             QA_LAUNCH_CHECK();
             return QA_OK;
         }
     }
-    const dim3 grid((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, mt1 ? 16 : LM_ROWS_PER_GROUP));
+    const dim3 grid = with_pf_plane(dim3((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, mt1 ? 16 : LM_ROWS_PER_GROUP)), pf);
     // narrow tiles (NT = 8 / 4) run on the 4x4x1 MFMA, where every FMA is useful (the 16x16x4 form on duplicated columns measured equal:
     // the matrix pipe is not what bounds the step)
-#define QA_GV(MT, NT) hipLaunchKernelGGL((lm_gemv_kernel<MT, NT, MODE, ATT, NB>), grid, dim3(512), 0, s, a)
-#define QA_G4(MT, C) hipLaunchKernelGGL((lm_gemv4_kernel<MT, C, MODE, ATT, 2 * NB>), grid, dim3(512), 0, s, a)
+#define QA_GV(MT, NT) hipLaunchKernelGGL((lm_gemv_kernel<MT, NT, MODE, ATT, NB>), grid, dim3(512), 0, s, a, pf)
+#define QA_G4(MT, C) hipLaunchKernelGGL((lm_gemv4_kernel<MT, C, MODE, ATT, 2 * NB>), grid, dim3(512), 0, s, a, pf)
     if (mt1) {
         if (nt == 16) QA_GV(1, 16);
         else if (nt == 8) QA_G4(1, 2);
@@ -538,16 +584,16 @@ static int launch_gemv_nb(const GemvArgs& a, int nt, hipStream_t s) {
 
 // K = hidden for every mode but the down projection (K = intermediate = 4 * hidden): only the batch sizes those shapes need exist
 template <int MODE, bool ATT>
-static int launch_gemv_mode(const GemvArgs& a, int nt, hipStream_t s) {
+static int launch_gemv_mode(const GemvArgs& a, int nt, hipStream_t s, const PfArgs* pf) {
     const int nb = gemv_nb(a.K);
     constexpr bool wide = MODE == GM_RESID && !ATT;  // down_proj
     if constexpr (!wide) {
-        if (nb == 1) return launch_gemv_nb<MODE, ATT, 1>(a, nt, s);
-        if (nb == 2) return launch_gemv_nb<MODE, ATT, 2>(a, nt, s);
-        if (nb == 4) return launch_gemv_nb<MODE, ATT, 4>(a, nt, s);
+        if (nb == 1) return launch_gemv_nb<MODE, ATT, 1>(a, nt, s, pf);
+        if (nb == 2) return launch_gemv_nb<MODE, ATT, 2>(a, nt, s, pf);
+        if (nb == 4) return launch_gemv_nb<MODE, ATT, 4>(a, nt, s, pf);
     } else {
-        if (nb == 4) return launch_gemv_nb<MODE, ATT, 4>(a, nt, s);
-        if (nb == 8) return launch_gemv_nb<MODE, ATT, 8>(a, nt, s);
+        if (nb == 4) return launch_gemv_nb<MODE, ATT, 4>(a, nt, s, pf);
+        if (nb == 8) return launch_gemv_nb<MODE, ATT, 8>(a, nt, s, pf);
     }
     set_error("lm_gemv: K=%d has no kernel instance (mode %d)", a.K, MODE);
     return QA_ERR_UNSUPPORTED;
@@ -558,15 +604,15 @@ bool lm_gemv_supported(int hidden, int intermediate) {
     return hidden % 256 == 0 && intermediate % 256 == 0 && (nb_d == 1 || nb_d == 2 || nb_d == 4) && (nb_i == 4 || nb_i == 8);
 }
 
-int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s) {
+int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s, const PfArgs* pf) {
     QA_REQUIRE(a.M >= 1 && a.M <= LM_MAX_ROWS, "lm_gemv: M=%d must be in [1, %d]", a.M, LM_MAX_ROWS);
     QA_REQUIRE(a.K % 256 == 0 && (a.ldx % 4) == 0, "lm_gemv: K=%d must be a multiple of 256", a.K);
     QA_REQUIRE((nt == 16 || nt == 8 || nt == 4) && a.N % nt == 0, "lm_gemv: N=%d not a multiple of the tile width %d", a.N, nt);
     switch (mode) {
-        case GM_QKV: return launch_gemv_mode<GM_QKV, false>(a, nt, s);
-        case GM_GATEUP: return launch_gemv_mode<GM_GATEUP, false>(a, nt, s);
-        case GM_RESID: return a.att_part ? launch_gemv_mode<GM_RESID, true>(a, nt, s) : launch_gemv_mode<GM_RESID, false>(a, nt, s);
-        case GM_HEAD: return launch_gemv_mode<GM_HEAD, false>(a, nt, s);
+        case GM_QKV: return launch_gemv_mode<GM_QKV, false>(a, nt, s, pf);
+        case GM_GATEUP: return launch_gemv_mode<GM_GATEUP, false>(a, nt, s, pf);
+        case GM_RESID: return a.att_part ? launch_gemv_mode<GM_RESID, true>(a, nt, s, pf) : launch_gemv_mode<GM_RESID, false>(a, nt, s, pf);
+        case GM_HEAD: return launch_gemv_mode<GM_HEAD, false>(a, nt, s, pf);
         default: set_error("lm_gemv: bad mode %d", mode); return QA_ERR_INVALID;
     }
 }
@@ -582,7 +628,8 @@ int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s) {
 // product on v_mfma_f32_16x16x4_f32 straight from an LDS copy of the activation tile, W_down slice prefetched at kernel entry.
 // AC = activation columns per workgroup: 16 (two gate/up tiles, I / 16 partials) or 8 (one tile, I / 8 partials, twice the workgroups)
 template <int MT, int NB, int AC>
-__global__ __launch_bounds__(512) void lm_mlp_kernel(const GemvArgs a_in, const float* __restrict__ wd, float* __restrict__ partial) {
+__global__ __launch_bounds__(512) void lm_mlp_kernel(const GemvArgs a_in, const float* __restrict__ wd, float* __restrict__ partial, const PfArgs pf) {
+    QA_LM_PF_PLANE(pf)
     GemvArgs a = a_in;
     if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x, a.rpg ? a.rpg : 16 * MT);
     constexpr int NTL = AC / 8;  // gate/up decode tiles (8 gate + 8 up rows each) per workgroup
@@ -749,7 +796,7 @@ bool lm_mlp_fused_supported(int d, int I, int nt_gu) {
 // a: x / ldx / w (gate-up decode layout, NT = 16) / M / K = d / d / rms_eps; wd: W_down in slice-major layout [I / 16][d][16];
 // partial: [I / 16][16 * MT][d] scratch; y = res + down(act)
 int launch_lm_mlp(const GemvArgs& a, int I, int ac, const float* wd, float* partial, const float* res, long long ldr, float* y, long long ldy,
-                  hipStream_t s) {
+                  hipStream_t s, const PfArgs* pf_in) {
     QA_REQUIRE(a.M >= 1 && a.M <= LM_MAX_ROWS && a.K == a.d && lm_mlp_fused_supported(a.d, I, 16), "lm_mlp: unsupported shape M=%d d=%d I=%d", a.M, a.d, I);
     // 16-row groups up to 32 sequences (two groups x 128 workgroups: each pulls 32 KB of x instead of 64 beside its 96 KB of weights -
     // 144.0 -> 139.4 ms per generate at 32 segments), 32-row groups above (at 64 segments four groups = 512 workgroups lose: 207 vs 196 ms)
@@ -757,12 +804,13 @@ int launch_lm_mlp(const GemvArgs& a, int I, int ac, const float* wd, float* part
     const int n_part = I / ac;
     // 9 .. 16 sequences: two groups of 8 rows on the 16-row tile (rows 8 .. 15 of a group re-read its last row): x 16 KB per workgroup
     // instead of 32; with the same split of the qkv launch 111.0 -> 109.7 ms per generate at 16 segments
-    const int rpg = (a.M > 8 && a.M <= 16) ? 8 : 16 * mt;
+    const int rpg = (a.M > 8 && a.M <= 16 && (knob(K_LM_ROWSPLIT) & 2)) ? 8 : 16 * mt;
     GemvArgs ag = a;
     ag.rpg = rpg;
-    const dim3 grid((unsigned)n_part, (unsigned)ceil_div(a.M, rpg));  // partial: [row group][n_part][16 mt][d]
+    PfArgs pf = pf_in ? *pf_in : PfArgs{};
+    const dim3 grid = with_pf_plane(dim3((unsigned)n_part, (unsigned)ceil_div(a.M, rpg)), pf);  // partial: [row group][n_part][16 mt][d]
     QA_REQUIRE(ac == 16, "lm_mlp: %d activation columns per workgroup (only 16 is built)", ac);
-#define QA_MLP(MT, NB) hipLaunchKernelGGL((lm_mlp_kernel<MT, NB, 16>), grid, dim3(512), 0, s, ag, wd, partial)
+#define QA_MLP(MT, NB) hipLaunchKernelGGL((lm_mlp_kernel<MT, NB, 16>), grid, dim3(512), 0, s, ag, wd, partial, pf)
     if (a.d == 512) {
         if (mt == 1) { QA_MLP(1, 2); } else { QA_MLP(2, 2); }
     } else {

@@ -88,6 +88,50 @@ class SSLFeatureExtractor:
         self._handle = handle
         return self
 
+    @classmethod
+    def from_pretrained(cls, path, spec: Optional[SSLSpec] = None, *, device: str | torch.device = "cuda:0") -> "SSLFeatureExtractor":
+        """The offline stand-in for the reference's `AutoModel.from_pretrained("bosonai/hubert_base" | "facebook/wav2vec2-large-xlsr-53" |
+        "microsoft/wavlm-base-plus")` (audio_tokenizer.py:28, HCodec-1.5/audio_tokenizer.py:47, model/model.py:30): `path` is a local
+        Hugging Face snapshot directory (`model.safetensors` or `pytorch_model.bin`, `config.json` optional) or a single weight file
+        (`.safetensors`, or a `torch.save`d state_dict).  Without `spec` the architecture is read from `config.json` (the HubertConfig /
+        Wav2Vec2Config / WavLMConfig field names SSLSpec uses); what the tokenizers add around the model (hidden states averaged, |x|^0.3)
+        is not in that file, so pass SPEC_HUBERT_BASE / SPEC_XLSR53 / SPEC_WAVLM_BASE_PLUS where it matters."""
+        import json
+        import os
+
+        def read(f):
+            if f.endswith(".safetensors"):
+                from safetensors.torch import load_file
+
+                return load_file(f)
+            sd = torch.load(f, map_location="cpu")
+            return sd["state_dict"] if isinstance(sd, dict) and "state_dict" in sd and not torch.is_tensor(sd["state_dict"]) else sd
+
+        path = os.fspath(path)
+        if os.path.isdir(path):
+            files = [os.path.join(path, n) for n in ("model.safetensors", "pytorch_model.bin") if os.path.isfile(os.path.join(path, n))]
+            if not files:
+                raise FileNotFoundError(f"{path}: neither model.safetensors nor pytorch_model.bin")
+            sd = read(files[0])
+            cfg_file = os.path.join(path, "config.json")
+            if spec is None and os.path.isfile(cfg_file):
+                with open(cfg_file) as f:
+                    cfg = json.load(f)
+                names = {f.name for f in dataclasses.fields(SSLSpec)}
+                kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in cfg.items() if k in names}
+                if cfg.get("model_type") == "wavlm":
+                    kw.setdefault("num_buckets", 320)
+                    kw["compress_exponent"] = 0.0  # model/model.py:46-49: the compression is commented out for WavLM
+                spec = SSLSpec(**kw)
+        else:
+            sd = read(path)
+        # a checkpoint saved from a task head (HubertForCTC, WavLMForXVector ...) prefixes the base model's entries
+        for prefix in ("hubert.", "wav2vec2.", "wavlm."):
+            if any(k.startswith(prefix) for k in sd):
+                sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+                break
+        return cls(spec or SPEC_HUBERT_BASE, device=device).load_state_dict(sd)
+
     def eval(self):
         return self
 

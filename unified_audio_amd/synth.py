@@ -470,3 +470,41 @@ def bicodec_tokens(seed: int, batch: int, frames: int, spec=None):
     sem = torch.from_numpy(rng.integers(0, spec.codebook_size, size=(batch, frames)).astype(np.int64))
     glob = torch.from_numpy(rng.integers(0, n_glob, size=(batch, 1, spec.token_num)).astype(np.int64))
     return sem, glob
+
+
+def ssl_state_dict(spec, seed: int = 21) -> Dict[str, torch.Tensor]:
+    """Seeded random weights in the transformers HubertModel / Wav2Vec2Model key layout (shapes only depend on the spec)."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *shape, scale=0.02: torch.randn(*shape, generator=g) * scale  # noqa: E731
+    sd = {}
+    cin = 1
+    for i, (c, k) in enumerate(zip(spec.conv_dim, spec.conv_kernel)):
+        pre = f"feature_extractor.conv_layers.{i}."
+        sd[pre + "conv.weight"] = rn(c, cin, k, scale=(2.0 / (cin * k)) ** 0.5)
+        if spec.conv_bias:
+            sd[pre + "conv.bias"] = rn(c)
+        if spec.feat_extract_norm == "layer" or i == 0:
+            sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"] = 1.0 + rn(c, scale=0.1), rn(c)
+        cin = c
+    d, inter = spec.hidden_size, spec.intermediate_size
+    sd["feature_projection.layer_norm.weight"], sd["feature_projection.layer_norm.bias"] = 1.0 + rn(cin, scale=0.1), rn(cin)
+    sd["feature_projection.projection.weight"], sd["feature_projection.projection.bias"] = rn(d, cin, scale=cin ** -0.5), rn(d)
+    cg = d // spec.num_conv_pos_embedding_groups
+    sd["encoder.pos_conv_embed.conv.weight"] = rn(d, cg, spec.num_conv_pos_embeddings, scale=(cg * spec.num_conv_pos_embeddings) ** -0.5)
+    sd["encoder.pos_conv_embed.conv.bias"] = rn(d)
+    sd["encoder.layer_norm.weight"], sd["encoder.layer_norm.bias"] = 1.0 + rn(d, scale=0.1), rn(d)
+    for i in range(spec.num_hidden_layers):
+        pre = f"encoder.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[pre + f"attention.{nm}.weight"], sd[pre + f"attention.{nm}.bias"] = rn(d, d, scale=d ** -0.5), rn(d)
+        sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"] = 1.0 + rn(d, scale=0.1), rn(d)
+        sd[pre + "feed_forward.intermediate_dense.weight"], sd[pre + "feed_forward.intermediate_dense.bias"] = rn(inter, d, scale=d ** -0.5), rn(inter)
+        sd[pre + "feed_forward.output_dense.weight"], sd[pre + "feed_forward.output_dense.bias"] = rn(d, inter, scale=inter ** -0.5), rn(d)
+        sd[pre + "final_layer_norm.weight"], sd[pre + "final_layer_norm.bias"] = 1.0 + rn(d, scale=0.1), rn(d)
+        if spec.num_buckets:  # WavLM
+            hd = d // spec.num_attention_heads
+            sd[pre + "attention.gru_rel_pos_linear.weight"], sd[pre + "attention.gru_rel_pos_linear.bias"] = rn(8, hd, scale=hd ** -0.5), rn(8)
+            sd[pre + "attention.gru_rel_pos_const"] = 1.0 + rn(1, spec.num_attention_heads, 1, 1, scale=0.1)
+            if i == 0:
+                sd[pre + "attention.rel_attn_embed.weight"] = rn(spec.num_buckets, spec.num_attention_heads, scale=0.5)
+    return sd

@@ -131,19 +131,29 @@ class UniSE:
     @torch.no_grad()
     def enhance_tokens(self, mode: str, srcs: Sequence[torch.Tensor], enrolls: Optional[Sequence[torch.Tensor]] = None
                        ) -> List[Tuple[torch.Tensor, torch.Tensor]]:
-        """srcs: utterances [1, T_i] (device tensors); enrolls (tse / rtse): one [1, T_e] per utterance, all of the same length.
+        """srcs: utterances [1, T_i] (device tensors); enrolls (tse / rtse): one [1, T_e_i] per utterance (any lengths).
         Returns per utterance (global_ids [n_seg_i, 32], semantic_ids [n_seg_i, 250])."""
         if mode not in ("se", "tse", "rtse"):
             raise KeyError(mode)
+        if mode != "se":
+            if enrolls is None or len(enrolls) != len(srcs):
+                raise ValueError(f"{mode} needs one enrollment per utterance")
+            lens = [int(e.size(-1)) for e in enrolls]
+            if len(set(lens)) > 1:
+                # every utterance keeps ITS enrollment length (the reference feeds one file per step, model.py:197-219, and never trims
+                # an enrollment to another file's): the prompt length of a generate call is common to its batch, so utterances are grouped
+                # by enrollment length, one pass per group, and handed back in the caller's order
+                out: List[Optional[Tuple[torch.Tensor, torch.Tensor]]] = [None] * len(srcs)
+                for n in sorted(set(lens)):
+                    idx = [i for i, v in enumerate(lens) if v == n]
+                    for i, r in zip(idx, self.enhance_tokens(mode, [srcs[i] for i in idx], [enrolls[i] for i in idx])):
+                        out[i] = r
+                return out  # type: ignore[return-value]
         segs = [segment(s, normalise=(mode == "se")) for s in srcs]
         counts = [s.size(0) for s in segs]
         seg_src = torch.cat(segs, dim=0)
         ef, n_enr = None, 0
         if mode != "se":
-            if enrolls is None or len(enrolls) != len(srcs):
-                raise ValueError(f"{mode} needs one enrollment per utterance")
-            if len({e.size(-1) for e in enrolls}) != 1:
-                raise ValueError("enrollments of one call must have the same length")
             ef = self.semantic_model(torch.cat(list(enrolls), dim=0))             # [U, N_e, d]
             n_enr = enrolls[0].size(-1)
         global_ids, semantic_ids = self._generate(mode, seg_src, counts, ef, n_enr)
@@ -299,3 +309,169 @@ class UniSE:
         rtse = self._split(counts, *self._generate("rtse", seg_src, counts, ef, SEG_LEN))
         w1, w2 = self._waves(srcs, tse), self._waves(srcs, rtse)
         return list(zip(w1, w2))
+
+
+class TestDataset:
+    """The reference's inference data iterator (QuarkAudio-UniSE/dataloader/data_module.py:296-410, built from
+    `config['dataset_config']['test_kwargs']`): every `*.flac` / `*.wav` of `data_src_dir` gives one batch tuple
+    `(mode, enroll, src, tgt, fs, lengths, names)` with `batch_size == 1` (:340), first channel only, 16 kHz; the enrollment is wrapped /
+    cut to `enroll_duration` seconds and scaled to a peak of 0.99 (:346-352).  Differences, both stated in INTEGRATION.md: wav files only
+    (soundfile / FLAC are not available offline - a FLAC file raises), and a file at another rate is resampled on the device with
+    qa_resample (torchaudio's sinc kernel) where the reference uses librosa's soxr_hq.  Sharding over ranks follows :364 (rank-strided)."""
+
+    __test__ = False  # not a pytest class
+
+    def __init__(self, data_enroll_dir, data_src_dir, data_tgt_dir, mode: str, enroll_duration: float = 5.0, batch_size: int = 1,
+                 num_workers: int = 1, prefetch: int = 0, *, device="cuda:0", rank: int = 0, world_size: int = 1):
+        import pathlib
+
+        if batch_size != 1:
+            raise AssertionError("batch_size == 1 (data_module.py:340); UniSE.enhance batches utterances itself")
+        self.mode, self.enroll_duration = mode, float(enroll_duration)
+        self.data_enroll_dir = pathlib.Path(data_enroll_dir) if data_enroll_dir is not None else None
+        self.data_src_dir, self.data_tgt_dir = pathlib.Path(data_src_dir), pathlib.Path(data_tgt_dir)
+        self.wav_names = [p.name for p in self.data_src_dir.glob("*.flac")] + [p.name for p in self.data_src_dir.glob("*.wav")]
+        self.device, self.rank, self.world_size = torch.device(device), rank, world_size
+
+    def load_wav(self, path):
+        from . import audio_io
+
+        if str(path).lower().endswith(".flac"):
+            raise ValueError(f"{path}: FLAC needs soundfile, which is not available here - convert to wav")
+        return audio_io.load_audio(str(path), 16000, self.device)
+
+    def process_one_sample(self, name):
+        import pathlib
+
+        src = self.load_wav(self.data_src_dir / name)
+        tgt = self.load_wav(self.data_tgt_dir / name)
+        enroll = None
+        if self.data_enroll_dir is not None:
+            enroll = self.load_wav(self.data_enroll_dir / name)
+            length = int(self.enroll_duration * 16000)
+            enroll = wrap_pad(enroll, length)[..., :length] if enroll.shape[-1] < length else enroll[..., :length]
+            enroll = enroll / (enroll.abs().max() + 1e-5) * 0.99
+        return enroll, src, tgt, 16000, src.shape[-1], pathlib.Path(name).stem
+
+    def __len__(self):
+        return len(range(self.rank, len(self.wav_names), self.world_size))
+
+    def __iter__(self):
+        for i in range(self.rank, len(self.wav_names), self.world_size):
+            enroll, src, tgt, fs, length, name = self.process_one_sample(self.wav_names[i])
+            yield (self.mode, enroll, src, tgt, torch.tensor([fs], dtype=torch.int64), torch.tensor([length], dtype=torch.int64), [name])
+
+
+class Model:
+    """The test path of the reference's `Model` (QuarkAudio-UniSE/model/model.py:20-36 constructor, :82-91 state-dict rules, :170-290
+    `test_step`), as `test.py:11-30` drives it: `Model(config)`, the Lightning checkpoint `config['ckpt_path']`, then one
+    `test_step(batch, batch_idx)` per file with `batch = (mode, enroll, src, tgt, fs, lengths, names)`, writing
+    `config['save_enhanced']/{name}.wav` ('se', 'tse') or `{name}_s1.wav` / `{name}_s2.wav` ('ss').
+
+    config keys read, as in the reference: `codec_ckpt_dir` (-> BiCodecTokenizer(model_dir=...): `BiCodec/config.yaml` +
+    `BiCodec/model.safetensors`), `llm_config` (-> LLM_SFT(**...)), `stft_config`, `save_enhanced`, `ckpt_path`.  One key is added:
+    `semantic_model_path` - a local snapshot of microsoft/wavlm-base-plus (the reference downloads it, model.py:30; there is no
+    network here); `semantic_model=` passes a loaded SSLFeatureExtractor instead.
+    `test_steps(batches)` is the batched form: any number of the same tuples in one pass (segments of all files share the launches).
+    """
+
+    def __init__(self, config, *, device: str | torch.device = "cuda:0", semantic_model=None, tokenizer=None, dnn=None, max_segments: int = 64):
+        from .bicodec import BiCodecTokenizer
+        from .llm import LLM_SFT
+        from .ssl import SPEC_WAVLM_BASE_PLUS, SSLFeatureExtractor
+
+        self.config = config
+        self.stft_conf = dict(config.get("stft_config") or dict(hop_length=HOP_LENGTH, win_length=WIN_LENGTH, n_fft=640, n_mels=80))
+        if (self.stft_conf["hop_length"], self.stft_conf["win_length"]) != (HOP_LENGTH, WIN_LENGTH):
+            raise ValueError(f"stft_config {self.stft_conf}: the LM's step count follows hop 320 / win 640 (conf/config.yaml:124-128)")
+        self.device = torch.device(device)
+        self.tokenizer = tokenizer if tokenizer is not None else BiCodecTokenizer(model_dir=config["codec_ckpt_dir"], device=self.device)
+        self.dnn = dnn if dnn is not None else LLM_SFT(**config["llm_config"], device=self.device)
+        if semantic_model is None:
+            path = config.get("semantic_model_path")
+            if path is None:
+                raise ValueError("Model needs config['semantic_model_path'] (a local microsoft/wavlm-base-plus snapshot) or semantic_model=: "
+                                 "the reference downloads the model (model.py:30), this machine has no network")
+            semantic_model = SSLFeatureExtractor.from_pretrained(path, SPEC_WAVLM_BASE_PLUS, device=self.device)
+        self.semantic_model = semantic_model
+        self.driver = UniSE(self.dnn, self.semantic_model, tokenizer=self.tokenizer, max_segments=max_segments)
+        if config.get("ckpt_path") and dnn is None:
+            import os
+
+            if os.path.isfile(str(config["ckpt_path"])):  # test.py:30 hands it to trainer.test(..., ckpt_path=)
+                self.load_checkpoint(config["ckpt_path"])
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """model.py:82-91: the checkpoint holds `dnn.*` only (tokenizer / semantic_model are excluded on save and loading is non-strict)."""
+        sd = {k: v for k, v in state_dict.items() if k.startswith("dnn.")}
+        if not sd:
+            raise KeyError("no 'dnn.*' entries: not a UniSE checkpoint (model.py:82-91)")
+        self.dnn.load_state_dict(sd)
+        return self
+
+    def load_checkpoint(self, ckpt_path):
+        """A Lightning checkpoint `{'state_dict': {'dnn.*': ...}, ...}` (what `trainer.test(model, dm, ckpt_path=...)` restores, test.py:30)."""
+        ck = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+        return self.load_state_dict(ck["state_dict"] if isinstance(ck, dict) and "state_dict" in ck else ck)
+
+    def eval(self):
+        return self
+
+    def to(self, *args, **kwargs):
+        return self
+
+    def extract_semantic_features(self, wavs: torch.Tensor) -> torch.Tensor:  # model.py:38-51
+        return self.semantic_model(wavs.to(self.device))
+
+    def stft_logmel(self, x: torch.Tensor) -> torch.Tensor:  # model.py:53-79
+        c = self.stft_conf
+        return stft_logmel(x, c["hop_length"], c["win_length"], c["n_fft"], c["n_mels"])
+
+    def _save(self, name: str, est: torch.Tensor, fs: int):
+        import os
+
+        from . import audio_io
+
+        out = self.config.get("save_enhanced") if hasattr(self.config, "get") else None
+        if out is not None:  # model.py:195-196 (the directory is made by test.py:17)
+            audio_io.write_wav(os.path.join(str(out), f"{name}.wav"), est, int(fs))
+
+    @staticmethod
+    def _unpack(batch):
+        mode, enroll, src, tgt, fs, lengths, names = batch
+        if src.dim() != 2 or src.size(0) != 1:
+            raise ValueError(f"src must be [1, T]: the reference's test batches hold one file (data_module.py:340), got {tuple(src.shape)}")
+        return mode, enroll, src, int(fs[0]), names[0]
+
+    @torch.no_grad()
+    def test_step(self, batch, batch_idx: int = 0):
+        """model.py:170-290.  Returns what it wrote: the estimate [T] ('se' / 'tse'), the pair ('ss'), None for any other mode (the
+        reference's if / elif chain falls through silently)."""
+        res = self.test_steps([batch])
+        return res[0] if res else None
+
+    @torch.no_grad()
+    def test_steps(self, batches):
+        """Any number of test batches in ONE pass per mode: all 5 s segments of all files go through WavLM, the LM and BiCodec together
+        (every stage is batch-invariant, so each file's result equals its own test_step bit for bit)."""
+        items = [self._unpack(b) for b in batches]
+        out = [None] * len(items)
+        for mode in ("se", "tse", "ss"):
+            idx = [i for i, it in enumerate(items) if it[0] == mode]
+            if not idx:
+                continue
+            srcs = [items[i][2].to(self.device, torch.float32) for i in idx]
+            enrolls = None
+            if mode == "tse":
+                if any(items[i][1] is None for i in idx):
+                    raise ValueError("'tse' needs an enrollment in every batch (data_enroll_dir)")
+                enrolls = [items[i][1].to(self.device, torch.float32) for i in idx]
+            for i, est in zip(idx, self.driver.enhance(mode, srcs, enrolls)):
+                _, _, _, fs, name = items[i]
+                if mode == "ss":
+                    self._save(f"{name}_s1", est[0], fs)
+                    self._save(f"{name}_s2", est[1], fs)
+                else:
+                    self._save(name, est, fs)
+                out[i] = est
+        return out
