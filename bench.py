@@ -26,7 +26,7 @@ SR = 16000
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD at 2.4 GHz
 CFG_NAMES = ["conv_gemm_kernel<128,32,4,1>", "conv_gemm_kernel<128,64,2,2>", "conv_gemm_kernel<128,128,2,2>", "conv_gemm_kernel<64,128,1,4>",
-             "conv_gemm_kernel<64,64,2,2>", "conv_gemm_kernel<256,128,2,2>"]
+             "conv_gemm_kernel<64,64,2,2>"]
 NPROF = 4 * len(CFG_NAMES)
 
 

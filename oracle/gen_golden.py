@@ -31,8 +31,16 @@ CASES_CAUSAL = [  # the reference's own encoder / decoder classes built with cau
 ]
 
 
-def run_case(name, seed, head_bias, batch, samples, causal=False):
+# RANGE STRESS: one case per codec version with synth.stress_state_dict applied - LSTM weights x 4 (saturated gates),
+# LayerScale / ConvNeXt gamma ~ 1 (full-size residual updates), ISTFT log-magnitude bias at ln 100 (half of the bins in the clip)
+CASES_STRESS = [("hcodec10_b1_stress", 79, 1.5, 1, 640 * 6 + 100)]
+CASES_15_STRESS = [("hcodec15_b2_stress", 1530, 2, 640 * 20 + 30, 0.6)]
+
+
+def run_case(name, seed, head_bias, batch, samples, causal=False, stress=False):
     sd = synth.hcodec10_state_dict(seed, head_logmag_bias=head_bias)
+    if stress:
+        sd = synth.stress_state_dict(sd)
     model = ref_shim.load_reference_codec("1.0")
     if causal:
         model = ref_shim.make_causal_10(model)
@@ -46,7 +54,7 @@ def run_case(name, seed, head_bias, batch, samples, causal=False):
         rec = model.decode(ac, sc)
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"),
-        seed=seed, head_bias=head_bias, batch=batch, samples=samples, causal=int(causal),
+        seed=seed, head_bias=head_bias, batch=batch, samples=samples, causal=int(causal), stress=int(stress),
         acoustic_codes=ac.numpy().astype(np.int16), semantic_codes=sc.numpy().astype(np.int16),
         wav_rec=rec.numpy().astype(np.float32),
         emb_sample=emb[:, ::37, ::3].numpy().astype(np.float32), sem_sample=sem[:, ::37, ::3].numpy().astype(np.float32),
@@ -73,13 +81,15 @@ CASES_15_FULL = [  # the published depth itself: 32-layer aggregators and bottle
 ]
 
 
-def run_case_15(name, seed, batch, samples, threshold, flags=None, layers=2):
+def run_case_15(name, seed, batch, samples, threshold, flags=None, layers=2, stress=False):
     import dataclasses
 
     from . import hcodec15_ref  # noqa: F401  (same spec object the tests use)
 
     spec = dataclasses.replace(R.SPEC_15, agg_layers=layers, bt_layers=layers, threshold=threshold, **(flags or {}))
     sd = synth.hcodec10_state_dict(seed, spec)
+    if stress:
+        sd = synth.stress_state_dict(sd)
     model = ref_shim.load_state(ref_shim.load_reference_codec("1.5", spec), sd)
     wav = R.pad_wav(synth.synth_wav(seed + 1, batch, samples))
     feat = synth.synth_feat(seed + 2, batch, wav.shape[-1] // 320, spec.sem_in)
@@ -87,7 +97,7 @@ def run_case_15(name, seed, batch, samples, threshold, flags=None, layers=2):
         codes = model.encode(wav.unsqueeze(1), feat)
         rec = model.decode(codes["acoustic_codes"], codes["semantic_codes"])
     np.savez_compressed(
-        os.path.join(OUT, name + ".npz"), seed=seed, batch=batch, samples=samples, threshold=threshold, layers=layers,
+        os.path.join(OUT, name + ".npz"), seed=seed, batch=batch, samples=samples, threshold=threshold, layers=layers, stress=int(stress),
         **{k: int(v) for k, v in (flags or {}).items()},
         acoustic_codes=codes["acoustic_codes"].numpy().astype(np.int32), semantic_codes=codes["semantic_codes"].numpy().astype(np.int32),
         wav_rec=rec.numpy().astype(np.float32))
@@ -98,20 +108,22 @@ SPEC20_SMALL = dict(enc_dim=256, enc_inter=512, enc_convnext_layers=2, enc_trans
                     codebook_size=64, num_quantizers=5, dec_dim=256, dec_inter=512, dec_convnext_layers=2, dec_transformer_layers=1)
 
 
-def run_case_20(name, seed, batch, samples, causal=False, full=False):
+def run_case_20(name, seed, batch, samples, causal=False, full=False, stress=False):
     """H-Codec 2.0 built by the reference from a reduced YAML (same code path as the 1.28 B-parameter configuration), or - `full` -
     from the shipped large_12.5hz_config.yaml shapes themselves (24 + 32 ConvNeXt blocks at width 1536, 16 + 16 codebooks)."""
     from . import hcodec20_ref as R20
 
     spec = R20.HCodec20Spec(causal=causal) if full else R20.HCodec20Spec(**SPEC20_SMALL, causal=causal)
     sd = synth.hcodec20_state_dict(seed, spec)
+    if stress:
+        sd = synth.stress_state_dict(sd)
     model = ref_shim.load_state(ref_shim.load_reference_codec("2.0", spec), sd)
     wav = R.pad_wav(synth.synth_wav_fullband(seed + 1, batch, samples), spec.frame_hop)
     feat = synth.synth_feat(seed + 2, batch, wav.shape[-1] // spec.hop, spec.sem_in)
     with torch.no_grad():
         ac, sc = model.encode(wav, feat)
         rec = model.decode(ac, sc)
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, batch=batch, samples=samples, causal=int(causal), full=int(full),
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, batch=batch, samples=samples, causal=int(causal), full=int(full), stress=int(stress),
                         acoustic_codes=ac.numpy().astype(np.int16), semantic_codes=sc.numpy().astype(np.int16),
                         wav_rec=rec.numpy().astype(np.float32))
     print(name, tuple(ac.shape), tuple(rec.shape))
@@ -125,6 +137,13 @@ def main():
         for c in CASES_15_FULL:
             run_case_15(*c)
         run_case_20("hcodec20_b1_full", 2010, 1, 3840 * 12 + 700, full=True)
+        return
+    if "--stress" in sys.argv:
+        for c in CASES_STRESS:
+            run_case(*c, stress=True)
+        for c in CASES_15_STRESS:
+            run_case_15(*c, stress=True)
+        run_case_20("hcodec20_small_b2_stress", 2002, 2, 3840 * 4 + 300, stress=True)
         return
     run_case_20("hcodec20_small_b2", 2000, 2, 3840 * 5 + 1000)
     run_case_20("hcodec20_small_b2_causal", 2001, 2, 3840 * 4 + 500, causal=True)

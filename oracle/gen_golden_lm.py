@@ -30,13 +30,20 @@ CASES = {  # name -> (spec kwargs or None for the UniSE shape, weight seed, task
     # segments with a 250-frame enrollment (prompt 503, KV 786): the shapes bench.py's tokens/s are quoted on
     "lm_config3_se_b16": (None, 35, "se", 16, 250, 0, 250, 32),
     "lm_config4_tse_b8": (None, 36, "tse", 8, 250, 250, 250, 32),
+    # RANGE STRESS: synth.stress_lm_state_dict - output head x 0.05 (near-degenerate top-2 gaps: the stored `gaps` are what a
+    # GPU stream is audited with), q / k projections x 3 (softmax rows dominated by one key)
+    "lm_small_stress": (SMALL, 23, "tse", 3, 9, 7, 24, 8, "stress"),
 }
 
 
 def case_tensors(name):
-    kw, seed, task, B, n_mix, n_enr, S_len, G = CASES[name]
+    kw, seed, task, B, n_mix, n_enr, S_len, G = CASES[name][:8]
     spec = L.LMSpec(**kw) if kw else L.SPEC_UNISE
     sd = L.lm_state_dict(seed, spec)
+    if "stress" in CASES[name][8:]:
+        from unified_audio_amd.synth import stress_lm_state_dict
+
+        sd = stress_lm_state_dict(sd)
     mix = L.synth_feats(seed + 100, B, n_mix, spec.feats_dim)
     enr = L.synth_feats(seed + 200, B, n_enr, spec.feats_dim) if n_enr else None
     return spec, sd, task, mix, enr, S_len, G

@@ -272,6 +272,30 @@ def rvq_search(x: Tensor, codebooks: Tensor) -> Tuple[Tensor, Tensor]:
     return torch.stack(idx, dim=-1), out
 
 
+def rvq_search_upstream_association(x: Tensor, codebooks: Tensor) -> Tuple[Tensor, Tensor]:
+    """The same residual search with the distance formed the way the THIRD-PARTY package forms it [upstream-memory:
+    vector_quantize_pytorch 1.22.15, `cdist` + `EuclideanCodebook.forward`; the package is pinned in requirements.txt:54 and absent here]:
+        cdist = ((|x|^2 + |e|^2) + (-2) * x.e).clamp(min=0).sqrt();  index = argmax(-cdist)
+    against the in-tree statement rvq_search follows (core_vq.py:223-231: `-(|x|^2 - 2 x.e + |e|^2)`, argmax).  Mathematically the same
+    arg-min; in fp32 the two associations round differently and the square root can merge neighbouring distances, so decisions at
+    near-ties can differ.  tests/test_rvq_pin_cpu.py counts those and shows each one lies inside tests/util.CODE_TIE_TOL."""
+    r = x
+    out = torch.zeros_like(x)
+    idx = []
+    for e in codebooks:
+        flat = r.reshape(-1, r.shape[-1])
+        x2 = flat.pow(2).sum(-1)
+        y2 = e.pow(2).sum(-1)
+        xy = (flat @ e.t()) * -2
+        dist = -((x2[:, None] + y2[None, :]) + xy).clamp(min=0).sqrt()
+        i = dist.argmax(dim=-1).view(r.shape[:-1])
+        q = e[i]
+        r = r - q
+        out = out + q
+        idx.append(i)
+    return torch.stack(idx, dim=-1), out
+
+
 def rvq_lookup(indices: Tensor, codebooks: Tensor) -> Tensor:
     """get_output_from_indices (codec.py:183-184; core_vq.py:406-412): sum_q E_q[idx_q].  idx == -1 = a dropped code: upstream
     vector_quantize_pytorch masks it to a zero vector (get_codes_from_indices: `mask = indices == -1` ... `masked_fill(mask, 0.)`); the

@@ -22,6 +22,8 @@ def test_hip_path_reproduces_reference_golden(qa_lib, gpu_device, path):
     g = np.load(path)
     seed = int(g["seed"])
     sd = synth.hcodec10_state_dict(seed, head_logmag_bias=float(g["head_bias"]))
+    if "stress" in g.files and int(g["stress"]):  # hcodec10_b1_stress (oracle/gen_golden.py CASES_STRESS)
+        sd = synth.stress_state_dict(sd)
     causal = bool(int(g["causal"])) if "causal" in g.files else False  # hcodec10_b2_causal: the reference's blocks built causal=True
     ospec = dataclasses.replace(R.SPEC_10, causal=causal)
     tok = qa.HCodecTokenizer(state_dict=sd, device=gpu_device, spec=qa.HCodecSpec(causal=causal))
@@ -63,6 +65,8 @@ def test_hip_path_reproduces_reference_golden_15(qa_lib, gpu_device, path):
     layers = int(g["layers"]) if "layers" in g.files else 2  # hcodec15_b2_full_depth: the published 32-layer stacks
     ospec = dataclasses.replace(R.SPEC_15, agg_layers=layers, bt_layers=layers, threshold=float(g["threshold"]), **flags)
     sd = synth.hcodec10_state_dict(seed, ospec)
+    if "stress" in g.files and int(g["stress"]):
+        sd = synth.stress_state_dict(sd)
     kw = {f: getattr(ospec, f) for f in ospec.__dataclass_fields__}
     tok = qa.HCodecTokenizer(state_dict=sd, device=gpu_device, spec=qa.HCodecSpec(**kw))
     wav = synth.synth_wav(seed + 1, int(g["batch"]), int(g["samples"]))
@@ -86,7 +90,7 @@ def test_hip_path_reproduces_reference_golden_15(qa_lib, gpu_device, path):
     assert rms < 1e-3 and rms / float(np.sqrt(np.mean(g["wav_rec"] ** 2))) < 1e-4, rms
 
 
-@pytest.mark.parametrize("name", ["hcodec20_small_b2", "hcodec20_small_b2_causal", "hcodec20_b1_full"])
+@pytest.mark.parametrize("name", ["hcodec20_small_b2", "hcodec20_small_b2_causal", "hcodec20_b1_full", "hcodec20_small_b2_stress"])
 def test_hip_path_reproduces_reference_golden_20(qa_lib, gpu_device, name):
     """H-Codec 2.0 against vectors produced by the reference's vq.Codec built from a reduced YAML (the second with `causal: true`) and -
     hcodec20_b1_full - from the shipped large_12.5hz_config.yaml shapes (24 + 32 ConvNeXt blocks at width 1536, 1.17 G parameters)."""
@@ -99,6 +103,8 @@ def test_hip_path_reproduces_reference_golden_20(qa_lib, gpu_device, name):
     full = bool(int(g["full"])) if "full" in g.files else False
     seed, o = int(g["seed"]), (R20.HCodec20Spec(causal=causal) if full else R20.HCodec20Spec(**SPEC20_SMALL, causal=causal))
     sd = synth.hcodec20_state_dict(seed, o)
+    if "stress" in g.files and int(g["stress"]):
+        sd = synth.stress_state_dict(sd)
     pspec = qa.HCodecSpec(version=20, enc_dim=o.enc_dim, enc_inter=o.enc_inter, enc_convnext_layers=o.enc_convnext_layers,
                           enc_layers=o.enc_transformer_layers, frame_stride=o.stride, tr_inter_cap=o.tr_inter_cap, dimension=o.dimension,
                           code_dim=o.dimension, sem_in=o.sem_in, sem_ch=o.sem_ch, sem_strides=o.sem_strides, codebook_size=o.codebook_size,

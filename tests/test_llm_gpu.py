@@ -11,10 +11,10 @@ pytestmark = pytest.mark.gpu
 SMALL = L.LMSpec(hidden=256, n_layers=2, n_heads=4, global_size=96, semantic_size=160, feats_dim=64, num_tasks=3)
 
 
-def _model(spec, seed, device):
+def _model(spec, seed, device, sd=None):
     import unified_audio_amd as qa
 
-    sd = L.lm_state_dict(seed, spec)
+    sd = sd if sd is not None else L.lm_state_dict(seed, spec)
     cfg = dict(global_size=spec.global_size, semantic_size=spec.semantic_size, hidden_size=spec.hidden,
                num_layers=spec.n_layers, num_attention_heads=spec.n_heads)
     lm = qa.LLM_SFT(num_tasks=spec.num_tasks, feats_dim=spec.feats_dim, llm_base_config=cfg, device=device)
@@ -75,7 +75,7 @@ def golden_stream_parity(name, device, audit=True, verbose=print):
 
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
     spec, sd, task, mix, enr, S, G = GG.case_tensors(name)
-    _, lm = _model(spec, GG.CASES[name][1], device)
+    _, lm = _model(spec, GG.CASES[name][1], device, sd=sd)  # the case's own weights (the stress case transforms them)
     mel = torch.zeros(mix.shape[0], S, 80)
     gids, sids = lm.generate(task, None if enr is None else mel, None if enr is None else enr.to(device), mel,
                              mix.to(device), global_length=G, do_sample=False)
@@ -95,7 +95,7 @@ def golden_stream_parity(name, device, audit=True, verbose=print):
     return left
 
 
-@pytest.mark.parametrize("name", ["lm_small_se", "lm_small_tse", "lm_small_rtse", "lm_unise_se", "lm_unise_tse"])
+@pytest.mark.parametrize("name", ["lm_small_se", "lm_small_tse", "lm_small_rtse", "lm_unise_se", "lm_unise_tse", "lm_small_stress"])
 def test_generate_matches_reference_token_goldens(qa_lib, gpu_device, name):
     """Token streams produced by the reference's OWN LLM_SFT.generate (oracle/gen_golden_lm.py): the HIP stream must be
     identical up to the first step whose top-2 logit gap (stored with the golden) is below fp32 noise; whatever follows such

@@ -25,6 +25,8 @@ def test_oracle_reproduces_reference_golden(path):
     g = np.load(path)
     seed = int(g["seed"])
     sd = synth.hcodec10_state_dict(seed, head_logmag_bias=float(g["head_bias"]))
+    if "stress" in g.files and int(g["stress"]):  # hcodec10_b1_stress: saturated LSTM gates, gamma ~ 1, half of the ISTFT bins in the clip
+        sd = synth.stress_state_dict(sd)
     wav = R.pad_wav(synth.synth_wav(seed + 1, int(g["batch"]), int(g["samples"])))
     feat = synth.synth_feat(seed + 2, int(g["batch"]), wav.shape[-1] // 320)
     taps = {}
@@ -138,6 +140,8 @@ def test_oracle15_reproduces_reference_golden(path):
     if "layers" in g.files:  # hcodec15_b2_full_depth: the published 32-layer stacks (654 M parameters), produced by the reference itself
         spec = dataclasses.replace(spec, agg_layers=int(g["layers"]), bt_layers=int(g["layers"]))
     sd = synth.hcodec10_state_dict(seed, spec)
+    if "stress" in g.files and int(g["stress"]):
+        sd = synth.stress_state_dict(sd)
     wav = R.pad_wav(synth.synth_wav(seed + 1, int(g["batch"]), int(g["samples"])))
     feat = synth.synth_feat(seed + 2, int(g["batch"]), wav.shape[-1] // 320, spec.sem_in)
     with torch.no_grad():
@@ -222,7 +226,7 @@ def _spec20_small():
     return R20.HCodec20Spec(**SPEC20_SMALL)
 
 
-@pytest.mark.parametrize("name", ["hcodec20_small_b2", "hcodec20_small_b2_causal", "hcodec20_b1_full"])
+@pytest.mark.parametrize("name", ["hcodec20_small_b2", "hcodec20_small_b2_causal", "hcodec20_b1_full", "hcodec20_small_b2_stress"])
 def test_oracle20_reproduces_reference_golden(name):
     from oracle import hcodec20_ref as R20
 
@@ -244,6 +248,8 @@ def test_oracle20_reproduces_reference_golden(name):
     if "causal" in g.files and int(g["causal"]):
         spec = dataclasses.replace(spec, causal=True)
     sd = synth.hcodec20_state_dict(seed, spec)
+    if "stress" in g.files and int(g["stress"]):
+        sd = synth.stress_state_dict(sd)
     wav = R.pad_wav(synth.synth_wav_fullband(seed + 1, int(g["batch"]), int(g["samples"])), spec.frame_hop)
     feat = synth.synth_feat(seed + 2, int(g["batch"]), wav.shape[-1] // spec.hop, spec.sem_in)
     with torch.no_grad():

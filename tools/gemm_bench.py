@@ -32,7 +32,9 @@ SHAPES = [  # name, M(rows), N, Cin, k, stride
 def bench_shape(lib, dev, M, N, C, k, s, reps=5):
     T = M * s  # one batch item; zero padding, enough frames for M outputs
     g = torch.Generator(device=dev).manual_seed(M + N + C)  # the same operands for every configuration of a sweep
-    x = torch.randn(1, T + k, C, device=dev, generator=g)
+    # ksize-1 / stride-1 layers get exactly M frames (T_in == T_out): that is what makes a launch LINEAR (conv_gemm.hip), as every nn.Linear of the
+    # model graphs is - with T + k frames the r06 256 x 128 tile silently fell back to 128 x 128 (first session of profiles/r06_gemm_256_ab.txt)
+    x = torch.randn(1, T if (k == 1 and s == 1) else T + k, C, device=dev, generator=g)
     w = torch.randn(N, k, C, device=dev, generator=g) * 0.05
     b = torch.randn(N, device=dev, generator=g)
     for _ in range(2):

@@ -21,7 +21,7 @@ def main():
     for name, M, N, Cc, k, s in SHAPES:
         if only and not any(name.startswith(o) for o in only.split(",")):
             continue
-        x = torch.randn(1, M * s + k, Cc, device=dev)
+        x = torch.randn(1, M * s if (k == 1 and s == 1) else M * s + k, Cc, device=dev)
         w = torch.randn(N, k, Cc, device=dev) * 0.05
         b = torch.randn(N, device=dev)
         for _ in range(2):

@@ -134,7 +134,7 @@ struct ConvParams {
 };
 
 // Live measurement hook (bench.py): when enabled every conv_gemm launch is bracketed by HIP events on its own stream.
-enum { PROF_CFG_128x32 = 0, PROF_CFG_128x64 = 1, PROF_CFG_128x128 = 2, PROF_CFG_64x128 = 3, PROF_CFG_64x64 = 4, PROF_CFG_256x128 = 5, PROF_NCFG = 6 };
+enum { PROF_CFG_128x32 = 0, PROF_CFG_128x64 = 1, PROF_CFG_128x128 = 2, PROF_CFG_64x128 = 3, PROF_CFG_64x64 = 4, PROF_NCFG = 5 };
 bool profile_enabled();
 // Byte-bound kernels (north_star: "rocprof HBM GB/s"): with qa_profile_begin_ex(2 | ...) their launches are bracketed by HIP events too,
 // each with its ALGORITHMIC bytes (every input and output element once), reduced per kind by qa_profile_end_hbm.

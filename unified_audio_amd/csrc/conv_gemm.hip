@@ -13,7 +13,6 @@
 // bank-conflict free; each lane fetches 4 consecutive k per read and the (lane>>5) halves take k-groups
 // {0..3},{4..7}: the K order inside a step is permuted identically for A and B, which leaves the sum unchanged.
 #include <cstdlib>
-#include <type_traits>
 
 #include "common.h"
 
@@ -46,14 +45,6 @@ namespace qa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (float4 arrays were left as scratch allocas)
-
-template <int N, int I = 0, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<N, I + 1>(f);
-    }
-}
 
 constexpr int TAP_WIN = 8;  // taps per LDS source-frame table window (ksize <= 8: built once per tile)
 
@@ -102,7 +93,7 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const ConvParams& p, long lo
 // disappear from the main loop - about 20 of its ~50 non-MFMA instructions, each of which costs ~30 cycles beside the co-resident
 // workgroup's MFMAs.
 template <int BM, int BN, int WM, int WN, bool PRO_ELU, int BK = 32, bool LINEAR = false>
-__global__ __launch_bounds__(256, (BM == 256 ? (BK == 16 ? 2 : 1) : (BM == 64 && (BK == 16 || BN == 64) ? 4 : (BK == 16 ? 3 : 2)))) void conv_gemm_kernel(const ConvParams p_in) {
+__global__ __launch_bounds__(256, (BM == 64 && (BK == 16 || BN == 64) ? 4 : (BK == 16 ? 3 : 2))) void conv_gemm_kernel(const ConvParams p_in) {
     ConvParams p = p_in;
     constexpr int LDS = BK + 4;
     constexpr int RPP = 256 / (BK / 4);  // rows staged per pass: 8 (BK=32) or 4 (BK=16) threads cover one row chunk
@@ -324,10 +315,8 @@ __global__ __launch_bounds__(256, (BM == 256 ? (BK == 16 ? 2 : 1) : (BM == 64 &&
         if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + ep_n);
         if (p.gamma) gamma4 = *reinterpret_cast<const f32x4*>(p.gamma + ep_n);
     }
-    // compile-time row-tile index: with four row tiles per wave (the 256 x 128 block) hipcc no longer unrolls this loop by pragma and the
-    // accumulators - indexed by a run-time i - fell back to scratch memory for the whole kernel
-    static_for<TM>([&](auto i_c) {
-        constexpr int i = decltype(i_c)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
         __syncthreads();  // operand buffers (i = 0) / previous pass (i > 0) no longer read
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -389,7 +378,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? (BK == 16 ? 2 : 1) : (BM == 64 &&
                 }
             }
         }
-    });
+    }
 #ifdef QA_TIMING
     if (lane == 0) {
         const long long tend = __builtin_readcyclecounter();
@@ -409,7 +398,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
     const long long tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     const bool prof = profile_enabled();
     if (prof) {
-        const int cfg = BM == 256 ? PROF_CFG_256x128 : BM == 64 ? (BN == 64 ? PROF_CFG_64x64 : PROF_CFG_64x128) : (BN == 32 ? PROF_CFG_128x32 : (BN == 64 ? PROF_CFG_128x64 : PROF_CFG_128x128));
+        const int cfg = BM == 64 ? (BN == 64 ? PROF_CFG_64x64 : PROF_CFG_64x128) : (BN == 32 ? PROF_CFG_128x32 : (BN == 64 ? PROF_CFG_128x64 : PROF_CFG_128x128));
         const double n = p.algo_n ? p.algo_n : p.N, k = p.algo_k ? p.algo_k : p.K;
         // algorithmic bytes: every input frame, weight and output element once (+ fused residual / gate reads)
         const double out_elems = p.am_dist ? 2.0 * (double)p.M * p.am_ld + p.M + n  // arg-min epilogue: (dist, idx) per 32 columns + |r|^2 + |e|^2
@@ -430,13 +419,6 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
     const bool linear = linear_on && p.ksize == 1 && p.stride == 1 && p.pad_left == 0 && p.in_rep <= 1 && p.T_in == p.T_out &&
                         (p.dilation <= 1);
     const bool bk16 = BN >= 64 && p.prologue != ACT_ELU && ((p.K <= bk16_max_k && tiles >= bk16_min_tiles) || p.C_in % 32 != 0);
-    if constexpr (BM == 256) {  // r06 experiment (QA_GEMM_256): LINEAR layers only, BK = 16 (61 KB of LDS: two workgroups per CU)
-        QA_REQUIRE(linear && p.prologue != ACT_ELU, "conv_gemm: the 256 x 128 tile exists for LINEAR layers only");
-        hipLaunchKernelGGL((conv_gemm_kernel<256, 128, 2, 2, false, 16, true>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
-        if (prof) profile_record_end(stream);
-        QA_LAUNCH_CHECK();
-        return QA_OK;
-    } else
     if (bk16 && linear)
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, (BN >= 64 ? 16 : 32), true>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
     else if (bk16)
@@ -503,17 +485,7 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
                                      {PROF_CFG_64x64, 64, 64, 0.871}};
         double best = 0.0;
         cfg = PROF_CFG_128x128;
-        const bool lin = knob(K_GEMM_LINEAR) != 0 && p.ksize == 1 && p.stride == 1 && p.pad_left == 0 && p.in_rep <= 1 && p.T_in == p.T_out &&
-                         p.dilation <= 1 && p.prologue != ACT_ELU;
-        const long long eff256 = knob(K_GEMM_256);  // 0: never; else the tile's efficiency relative to 128 x 128, in 1/1000
-        for (const Cand& c0 : cands) {
-            Cand c = c0;
-            if (&c0 == &cands[0] && eff256 > 0 && lin && p.M >= 8000 && p.N >= 1024) {  // try the 256 x 128 tile in front of the 128 x 128 one
-                const long long t256 = ceil_div(p.M, 256) * ceil_div(p.N, 128);
-                const double cost = (double)ceil_div(t256, 256) * 256 * 128 / (eff256 / 1000.0) * (t256 <= 256 ? 1.25 : 1.0);
-                best = cost;
-                cfg = PROF_CFG_256x128;
-            }
+        for (const Cand& c : cands) {
             const long long tiles = ceil_div(p.M, c.bm) * ceil_div(p.N, c.bn);
             // a launch that gives a CU at most ONE workgroup has nobody to cover that workgroup's barriers, prologue and epilogue: the
             // 256-tile 4032 x 512 x 512 launch runs 8 % faster as 504 tiles of 64 x 64 although those need two rounds (same sweep)
@@ -529,12 +501,6 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t stream) {
         case PROF_CFG_128x64: return launch_cfg<128, 64, 2, 2>(q, stream);
         case PROF_CFG_64x128: return launch_cfg<64, 128, 1, 4>(q, stream);
         case PROF_CFG_64x64: return launch_cfg<64, 64, 2, 2>(q, stream);
-        case PROF_CFG_256x128: {
-            const bool lin = knob(K_GEMM_LINEAR) != 0 && p.ksize == 1 && p.stride == 1 && p.pad_left == 0 && p.in_rep <= 1 && p.T_in == p.T_out &&
-                             p.dilation <= 1 && p.prologue != ACT_ELU;
-            if (lin) return launch_cfg<256, 128, 2, 2>(q, stream);
-            return launch_cfg<128, 128, 2, 2>(q, stream);  // a forced 256 x 128 on a layer it does not exist for
-        }
         default: return launch_cfg<128, 128, 2, 2>(q, stream);
     }
 }

@@ -11,14 +11,14 @@ namespace qa {
 
 #define QA_KNOB_TABLE(X)                                                                                                           \
     X(SERIAL, "QA_SERIAL", 0, "1: no internal stream concurrency (every kernel alone on the device; = qa_set_serial)")           \
-    X(GEMM_CFG, "QA_GEMM_CFG", -1, "force the conv_gemm tile: 0 = 128x32, 1 = 128x64, 2 = 128x128, 3 = 64x128, 4 = 64x64, 5 = 256x128 (LINEAR layers; else 128x128) (-1: cost model)")             \
-    X(GEMM_256, "QA_GEMM_256", 0, "r06 experiment: 256x128 block tile (4 waves, 4x2 accumulators each) for LINEAR layers with M >= 8000 and N >= 1024; value = its efficiency relative to 128x128 in 1/1000 for the cost model (0: never chosen; QA_GEMM_CFG=5 forces it)") \
+    X(GEMM_CFG, "QA_GEMM_CFG", -1, "force the conv_gemm tile: 0 = 128x32, 1 = 128x64, 2 = 128x128, 3 = 64x128, 4 = 64x64 (-1: cost model)")             \
     X(GEMM_BK16, "QA_GEMM_BK16", 1 << 30, "largest K that takes the BK = 16 K-chunk variant")                                     \
     X(GEMM_BK16_MIN_TILES, "QA_GEMM_BK16_MIN_TILES", 384, "fewest tiles of a launch that take BK = 16")                          \
     X(GEMM_LINEAR, "QA_GEMM_LINEAR", 1, "table-free K loop for ksize-1 layers")                                                  \
     X(GEMM_XCD, "QA_GEMM_XCD", 1, "XCD-aware tile order")                                                                        \
     X(GEMM_PANEL, "QA_GEMM_PANEL", 8, "conv_gemm tile order: column panels of this many tiles, row tiles fastest inside a panel (0: column tiles fastest over the whole row; 8: +4 % on N >= 4096 shapes, +1.2 % on H-Codec 2.0)") \
     X(ATT_DEBUG, "QA_ATT_DEBUG", 0, "attention_kernel debug bits: 1 always rescale, 2 extra barrier per tile, 4 wait for the prefetch at once") \
+    X(ATT_NW, "QA_ATT_NW", 0, "attention_kernel waves per workgroup: 0 = three (96-query blocks) where that needs fewer waves than four (128-query blocks) at head_dim <= 64, 3 / 4 force") \
     X(SEANET_FUSED, "QA_SEANET_FUSED", 1, "fused conv0 + first SEANet residual block")                                           \
     X(MIMI_ROPE_WINDOW, "QA_MIMI_ROPE_WINDOW", 8192, "mimi streaming: positions covered by the RoPE table before the rolling window takes over (tests shrink it)") \
     X(LSTM_GRAPH, "QA_LSTM_GRAPH", 1, "replay the T step launches of an LSTM call from a cached hipGraph")                       \

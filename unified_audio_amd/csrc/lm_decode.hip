@@ -999,7 +999,10 @@ __global__ __launch_bounds__(64 * PICK_SEQS) void lm_pick_kernel(const float* __
     }
     __syncthreads();
     if (tid == 0) {
-        const int ticket = atomicAdd(&state[ST_TICKET], 1);
+        // acquire-release at agent scope: the ticket orders every workgroup's read of `col` before the last arrival's writes of
+        // the state words without leaning on the kernel boundary.  PRECONDITION: state[ST_TICKET] == 0 on entry - lm_phase_init_kernel sets
+        // it and the last arrival below restores it; a step aborted in mid-kernel would leave it non-zero (the state would never advance).
+        const int ticket = __hip_atomic_fetch_add(&state[ST_TICKET], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (ticket == (int)gridDim.x - 1) {  // the last workgroup to arrive: everybody has read col
             state[ST_TICKET] = 0;
             state[ST_POS] += 1;

@@ -852,7 +852,14 @@ int lstm_call_end(void* ticket, hipStream_t s, bool* failed) {
         if (c->slot >= 0) P.pool_busy &= ~(1ull << c->slot);
     }
     // a FAILED synchronisation: the recurrence may still be running and could write a word the next call would be handed -
-    // the slot stays busy (leaked: 64 per device) and the call stays counted as in flight, so later launches keep to the per-step kernels
+    // the slot stays busy (leaked: 64 per device) and the call stays counted as in flight, so later launches keep to the per-step kernels.
+    // that fallback is permanent for the process - make it visible: the device is marked degraded (qa_debug_lstm_stats out[3],
+    // and the auto modes stop choosing the in-launch kernels by that flag rather than by a silently stuck counter)
+    if (st != QA_OK) {
+        P.degraded = true;
+        set_error("lstm: hipStreamSynchronize failed while collecting an in-launch recurrence; device %d keeps to the per-step kernels from here on "
+                  "(qa_debug_lstm_stats reports degraded = 1)", c->dev);
+    }
     delete c;
     return st;
 }

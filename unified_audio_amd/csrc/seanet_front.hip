@@ -31,7 +31,7 @@ struct SeanetFrontParams {
     const float *wsc, *bsc;  // shortcut 1x1: [C][C], [C]
     const float *wpw, *bpw;  // 1x1 after the k3: [C][32] (columns >= hid are zero), [C]
     float* a;                // [B, L, C]
-    int B, L, hid8;          // hid8 = hidden width rounded up to 8 (K steps of the second contraction)
+    int B, L;
     int pl3, Lp3, pl0, Lp0;  // left paddings and short-input lengths of the k3 / k7 reflect pads
 };
 
@@ -210,9 +210,12 @@ int launch_seanet_front(const float* wav, const float* w0, const float* b0, cons
                "shape C=%d hid=%d L=%d", C, hid, L);
     SeanetFrontParams p{};
     p.wav = wav; p.w0 = w0; p.b0 = b0; p.w3 = w3; p.b3 = b3; p.wsc = wsc; p.bsc = bsc; p.wpw = wpw; p.bpw = bpw; p.a = a;
-    p.B = B; p.L = L; p.hid8 = (int)round_up(hid, 8);
+    p.B = B; p.L = L;
     p.pl3 = causal ? 2 : 1;
     p.pl0 = causal ? 6 : 3;
+    // the x-tile rows read the staged waveform window at clamp(src - r0 + pl3): every reflected halo row a tile needs lies inside that
+    // window only for a left pad of 1 or 2 frames - any other layout must fail here, not read clamped samples
+    QA_REQUIRE(p.pl3 >= 1 && p.pl3 <= 2, "seanet_front: k3 left pad %d outside the staged window's reach", p.pl3);
     const int mp3 = causal ? 2 : 1, mp0 = causal ? 6 : 3;
     p.Lp3 = L <= mp3 ? mp3 + 1 : L;
     p.Lp0 = L <= mp0 ? mp0 + 1 : L;

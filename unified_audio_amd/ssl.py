@@ -89,13 +89,15 @@ class SSLFeatureExtractor:
         return self
 
     @classmethod
-    def from_pretrained(cls, path, spec: Optional[SSLSpec] = None, *, device: str | torch.device = "cuda:0") -> "SSLFeatureExtractor":
+    def from_pretrained(cls, path, spec: Optional[SSLSpec] = None, *, device: str | torch.device = "cuda:0",
+                        default_spec: Optional[SSLSpec] = None) -> "SSLFeatureExtractor":
         """The offline stand-in for the reference's `AutoModel.from_pretrained("bosonai/hubert_base" | "facebook/wav2vec2-large-xlsr-53" |
         "microsoft/wavlm-base-plus")` (audio_tokenizer.py:28, HCodec-1.5/audio_tokenizer.py:47, model/model.py:30): `path` is a local
         Hugging Face snapshot directory (`model.safetensors` or `pytorch_model.bin`, `config.json` optional) or a single weight file
-        (`.safetensors`, or a `torch.save`d state_dict).  Without `spec` the architecture is read from `config.json` (the HubertConfig /
-        Wav2Vec2Config / WavLMConfig field names SSLSpec uses); what the tokenizers add around the model (hidden states averaged, |x|^0.3)
-        is not in that file, so pass SPEC_HUBERT_BASE / SPEC_XLSR53 / SPEC_WAVLM_BASE_PLUS where it matters."""
+        (`.safetensors`, or a `torch.save`d state_dict).  `spec` fixes the architecture; without it the architecture is read from
+        `config.json` (the HubertConfig / Wav2Vec2Config / WavLMConfig field names SSLSpec uses) and what the tokenizers add around the
+        model - which hidden states are averaged, the |x|^0.3 compression - is taken from `default_spec` (SPEC_HUBERT_BASE when absent),
+        which is also the architecture when there is no config.json."""
         import json
         import os
 
@@ -117,12 +119,14 @@ class SSLFeatureExtractor:
             if spec is None and os.path.isfile(cfg_file):
                 with open(cfg_file) as f:
                     cfg = json.load(f)
-                names = {f.name for f in dataclasses.fields(SSLSpec)}
+                names = {f.name for f in dataclasses.fields(SSLSpec)} - {"pad", "select", "compress_exponent"}
                 kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in cfg.items() if k in names}
                 if cfg.get("model_type") == "wavlm":
                     kw.setdefault("num_buckets", 320)
-                    kw["compress_exponent"] = 0.0  # model/model.py:46-49: the compression is commented out for WavLM
-                spec = SSLSpec(**kw)
+                else:
+                    kw["num_buckets"] = 0
+                base = default_spec or SPEC_HUBERT_BASE
+                spec = dataclasses.replace(base, **kw)
         else:
             sd = read(path)
         # a checkpoint saved from a task head (HubertForCTC, WavLMForXVector ...) prefixes the base model's entries
@@ -130,7 +134,7 @@ class SSLFeatureExtractor:
             if any(k.startswith(prefix) for k in sd):
                 sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
                 break
-        return cls(spec or SPEC_HUBERT_BASE, device=device).load_state_dict(sd)
+        return cls(spec or default_spec or SPEC_HUBERT_BASE, device=device).load_state_dict(sd)
 
     def eval(self):
         return self

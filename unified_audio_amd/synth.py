@@ -172,6 +172,51 @@ def hcodec10_state_dict(seed: int = 1234, spec=SPEC_10, head_logmag_bias: float 
     return g.sd
 
 
+def stress_state_dict(sd: Dict[str, torch.Tensor], lstm_gain: float = 4.0, layer_scale: float = 1.0, head_clip_bias: float = 4.6
+                      ) -> Dict[str, torch.Tensor]:
+    """RANGE-STRESS variant of a codec state_dict: the dynamic ranges a trained checkpoint can have and the default
+    seeded weights do not - applied to the tensors of `sd` by name, so the reference (oracle/gen_golden.py) and every test regenerate the
+    same weights from the seed:
+      * nn.LSTM weights x `lstm_gain` (W_ih and W_hh): the gates saturate (|pre-activation| of tens: sigmoid / tanh in their flat ends);
+      * LayerScale of the mimi stacks (reference init 0.01) and the ConvNeXt gammas (init 1 / n_layers) -> about `layer_scale`: the
+        residual branches carry full-size updates, activations grow layer by layer;
+      * ISTFT head: the log-magnitude bias of the magnitude bins raised to `head_clip_bias` (ln 100 = 4.6): about half of the bins run
+        into the clip at 100 (heads.py:139-140), the rest stay in the exponential's steep part."""
+    out = {}
+    n_gamma = {}
+    for k in sd:
+        if k.endswith(".gamma"):
+            pre = k.rsplit(".", 2)[0]
+            n_gamma[pre] = n_gamma.get(pre, 0) + 1
+    for k, v in sd.items():
+        if k.endswith(("rnn.weight_hh_l0", "rnn.weight_ih_l0")):
+            v = v * lstm_gain
+        elif k.endswith((".layer_scale_1.scale", ".layer_scale_2.scale")):
+            v = v / v.mean() * layer_scale
+        elif k.endswith(".gamma"):
+            v = v * (layer_scale * n_gamma[k.rsplit(".", 2)[0]])
+        elif k == "decoder.head.out.bias":
+            nb = v.numel() // 2
+            v = v.clone()
+            v[:nb] += head_clip_bias - float(v[:nb].mean())
+        out[k] = v
+    return out
+
+
+def stress_lm_state_dict(sd: Dict[str, torch.Tensor], head_gain: float = 0.05, qk_gain: float = 3.0) -> Dict[str, torch.Tensor]:
+    """Range-stress variant of the UniSE LM weights: the output head scaled DOWN (top-2 logit gaps of the greedy arg-max shrink by
+    `head_gain`: many near-degenerate decisions, which the token goldens store gap by gap) and the q / k projections scaled up (peaky
+    attention: softmax rows dominated by one key, exp() of large negative scores for the rest)."""
+    out = {}
+    for k, v in sd.items():
+        if k == "output_head.weight":
+            v = v * head_gain
+        elif k.endswith(("self_attn.q_proj.weight", "self_attn.k_proj.weight")):
+            v = v * qk_gain
+        out[k] = v
+    return out
+
+
 def synth_wav(seed: int, batch: int, samples: int, sr: int = 16000) -> torch.Tensor:
     """band-limited noise (0.1*randn low-passed to ~4 kHz) + 3 sinusoids, peak 0.5."""
     rng = np.random.default_rng(seed)

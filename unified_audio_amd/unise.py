@@ -392,7 +392,7 @@ class Model:
             if path is None:
                 raise ValueError("Model needs config['semantic_model_path'] (a local microsoft/wavlm-base-plus snapshot) or semantic_model=: "
                                  "the reference downloads the model (model.py:30), this machine has no network")
-            semantic_model = SSLFeatureExtractor.from_pretrained(path, SPEC_WAVLM_BASE_PLUS, device=self.device)
+            semantic_model = SSLFeatureExtractor.from_pretrained(path, device=self.device, default_spec=SPEC_WAVLM_BASE_PLUS)
         self.semantic_model = semantic_model
         self.driver = UniSE(self.dnn, self.semantic_model, tokenizer=self.tokenizer, max_segments=max_segments)
         if config.get("ckpt_path") and dnn is None:
