@@ -343,6 +343,49 @@ def unise_pipeline_bench(dev, batches=6, seg_per_batch=16, lm_graph=False):
                                    "consecutive batches on three streams (UniSE.enhance_pipelined)", "dtype": "f32"}}
 
 
+def unise_micro_batch_bench(dev, n_seg=256, sizes=(64, 128, 256)):
+    """throughput beyond the 64-segment micro-batch.  The SAME 256 one-segment utterances through UniSE.enhance ('se':
+    WavLM -> LLM_SFT.generate -> BiCodec.detokenize) with max_segments = 64 / 128 / 256, i.e. 4 / 2 / 1 passes whose LM runs 1 / 2 / 4
+    chains of 64 sequences (csrc/lm.cpp: chains replay one captured step per token on internal streams).  Results are identical for every
+    value (each stage is batch-invariant); the default of unified_audio_amd.UniSE follows the fastest."""
+    import unified_audio_amd as qa
+    from unified_audio_amd import synth
+    from unified_audio_amd import unise as U
+
+    fx = qa.SSLFeatureExtractor(qa.SPEC_WAVLM_BASE_PLUS, device=dev).load_state_dict(_ssl_state_dict(qa.SPEC_WAVLM_BASE_PLUS))
+    lm = qa.LLM_SFT(device=dev).load_state_dict(synth.lm_state_dict(4321))
+    bic = qa.BiCodec(device=dev).load_state_dict(synth.bicodec_state_dict(77, synth.BiCodecShapes()))
+    base = [synth.synth_wav(300 + i, 1, U.SEG_LEN).to(dev) for i in range(16)]
+    srcs = [base[i % 16] * (1.0 - 0.002 * (i // 16)) for i in range(n_seg)]  # 256 distinct utterances from 16 generated ones
+    out, ref = {}, None
+    for m in sizes:
+        drv = U.UniSE(lm, fx, tokenizer=qa.BiCodecTokenizer(model=bic), max_segments=m)
+        best, lm_ms = float("inf"), None
+        for it in range(2):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            est = drv.enhance("se", srcs)
+            torch.cuda.synchronize(dev)
+            best = min(best, time.perf_counter() - t0)
+        chk = float(sum(float(e.double().abs().sum()) for e in est))
+        ref = chk if ref is None else ref
+        # the LM alone at this micro-batch (features precomputed): tokens/s of one generate call
+        feats = fx(torch.cat(srcs[:m], dim=0))
+        mel = torch.zeros(m, 250, 80)
+        lm.generate("se", None, None, mel, feats, do_sample=False)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        lm.generate("se", None, None, mel, feats, do_sample=False)
+        torch.cuda.synchronize(dev)
+        lm_ms = 1e3 * (time.perf_counter() - t0)
+        out[f"max_segments_{m}"] = {"value": n_seg * 5.0 / best, "unit": "audio-seconds/sec", "ms_per_256_segments": 1e3 * best,
+                                    "lm_generate_ms": lm_ms, "lm_tokens_per_sec": m * 283 / (lm_ms * 1e-3), "lm_chains": max(1, -(-m // 64)),
+                                    "same_output_as_first": bool(chk == ref)}
+        del feats
+    out["config"] = {"workload": f"UniSE 'se' end to end (WavLM | AR-LM | BiCodec), {n_seg} x 5 s segments per call of UniSE.enhance, micro-batch swept", "dtype": "f32"}
+    return out
+
+
 def rvq_bench(dev, lib, n_vec, Q, K=1024, D=512, reps=5):
     """The RVQ search by itself (qa_rvq_search = ResidualVQ.forward) at the shape of one stream of BASELINE configs[4]:
     n_vec residual vectors x Q stages against K x D codebooks (codebooks scaled 0.5^q per stage like the synthetic checkpoints).
@@ -878,6 +921,11 @@ def main():
             extras["unise_lm_tse_b64"] = lm_bench(dev, rank, world, None, 64, reps=1, task="tse", n_enroll=250)
         except Exception as e:  # noqa: BLE001
             extras["unise_lm_tse_b64"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        try:
+            log("UniSE micro-batch sweep (256 segments end to end at max_segments 64 / 128 / 256) ...")
+            extras["unise_micro_batch"] = unise_micro_batch_bench(dev)
+        except Exception as e:  # noqa: BLE001
+            extras["unise_micro_batch"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
 
     if rank == 0 and world == 1 and not args.lean and not args.no_extras and args.model == "1.5":
         try:

@@ -149,7 +149,7 @@ def test_bicodec_from_a_checkpoint_directory(qa_lib, gpu_device, tmp_path, which
     assert torch.equal(tok.detokenize(glob.to(gpu_device).unsqueeze(1), sem.to(gpu_device)), a)
     if which == "small":  # a config that disagrees with the weights fails at load time, by tensor name - not at the first call
         bad = copy.deepcopy(config)
-        bad["audio_tokenizer"]["decoder"]["channels"] = 256
+        bad["audio_tokenizer"]["decoder"]["channels"] = 1024
         _write_bicodec_dir(str(tmp_path / "bad"), bad, sd)
         with pytest.raises(qa.QuarkAudioError, match="decoder"):
             qa.BiCodec.load_from_checkpoint(str(tmp_path / "bad"), device=gpu_device)

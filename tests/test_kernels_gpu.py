@@ -337,32 +337,3 @@ def test_attention_kernel_long_ragged_sequences_are_exact_and_deterministic(qa_l
     ref = (torch.softmax(q @ k.transpose(2, 3) * hd ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(B, N, d)
     err = rel_err(outs[0], ref)
     assert err < 2e-6, err
-
-
-@pytest.mark.parametrize("B,N,H,hd,causal", [(3, 283, 8, 64, 0), (2, 283, 8, 64, 1), (2, 96, 4, 64, 0), (2, 97, 4, 32, 0), (1, 1500, 4, 64, 0),
-                                             (2, 283, 4, 128, 0), (2, 33, 2, 96, 1)])
-def test_attention_three_and_four_wave_workgroups_are_bit_identical(qa_lib, gpu_device, B, N, H, hd, causal):
-    """r06: attention_kernel<HD, BIAS, NW = 3> - 96-query workgroups, chosen where they need fewer waves than 128-query ones (N = 283:
-    9 waves instead of 12).  A query's arithmetic does not depend on the wave that owns it, so QA_ATT_NW = 3 and = 4 must agree bit
-    for bit (incl. the clamped last pass of the 192-thread K / V tile staging), and both with double-precision softmax attention."""
-    from unified_audio_amd import _lib
-
-    d = H * hd
-    g = torch.Generator().manual_seed(B * 5 + N + hd + causal)
-    qkv = torch.randn(B, N, 3 * d, generator=g).to(gpu_device)
-    outs = {}
-    old = _lib.get_knob("QA_ATT_NW")
-    try:
-        for nw in (3, 4, 0):
-            _lib.set_knob("QA_ATT_NW", nw)
-            outs[nw] = _attention_alone(qa_lib, qkv, H, hd, causal)
-            torch.cuda.synchronize()
-    finally:
-        _lib.set_knob("QA_ATT_NW", old)
-    assert torch.equal(outs[3], outs[4]) and torch.equal(outs[0], outs[4])
-    q, k, v = (t.reshape(B, N, H, hd).transpose(1, 2).double() for t in qkv.split(d, dim=2))
-    sc = q @ k.transpose(2, 3) * hd ** -0.5
-    if causal:
-        sc = sc.masked_fill(torch.triu(torch.ones(N, N, dtype=torch.bool, device=gpu_device), 1), float("-inf"))
-    ref = (torch.softmax(sc, dim=-1) @ v).transpose(1, 2).reshape(B, N, d)
-    assert rel_err(outs[3], ref) < 2e-6

@@ -48,11 +48,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // BIAS: WavLM's gated relative position bias (transformers WavLMAttention.forward): score(i, j) += gate[b, head, i] *
 // relbias[head][clamp(j - i, -R, R) + R]; the bucket function saturates below R, so the clamp is exact.
-// NW = waves per workgroup = 32-query blocks it owns: 4, or - r06 - 3 where that leaves fewer idle waves (N = 283: 3 x 3 waves cover 288
-// queries, 3 x 4 covered 384 with three waves owning none) and, at head_dim <= 64, three workgroups fit a CU instead of two.  A query's
-// arithmetic does not depend on the wave that owns it: the two forms are bit-identical.
-template <int HD, bool BIAS, int NW = 4>
-__global__ __launch_bounds__(NW * 64, (NW == 3 && HD <= 64) ? 3 : 2) void attention_kernel(const float* __restrict__ q, long long ldq,
+template <int HD, bool BIAS>
+__global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ q, long long ldq,
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         long long ldkv, long long kv_bstride, float* __restrict__ out,
                                                         long long ldo, int n_q, int n_keys, float scale, int causal,
@@ -76,8 +73,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 3 && HD <= 64) ? 3 : 2) void attent
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hh = lane >> 5;
     const int b = blockIdx.z, head = blockIdx.y;
-    constexpr int NT = NW * 64, QB = NW * 32;  // threads / queries per workgroup
-    const int q_blk0 = blockIdx.x * QB;
+    const int q_blk0 = blockIdx.x * 128;
     const int qi = q_blk0 + wave * 32 + ql;
     const int off = n_keys - n_q;  // causal: key j visible iff j <= qi + off
 
@@ -118,7 +114,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 3 && HD <= 64) ? 3 : 2) void attent
     const bool lin_causal = causal && !ring;
     int last_key = n_keys - 1, first_key = 0;
     if (lin_causal) {
-        const int q_last = min(q_blk0 + QB - 1, n_q - 1);
+        const int q_last = min(q_blk0 + 127, n_q - 1);
         last_key = min(last_key, q_last + off);
         if (context > 0) first_key = max(0, q_blk0 + off - context + 1);
     }
@@ -135,9 +131,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 3 && HD <= 64) ? 3 : 2) void attent
     // exec-masked region; with it hipcc (ROCm 7.2) re-used the staging registers while the loads were still in flight for
     // HD = 64 at n_keys = 1500: half of all outputs differed from run to run (tools/diag_attention.py on a build of that form,
     // profiles/r03_attention_determinism.txt).  Caught by the at-size parity test of H-Codec 2.0 (tests/test_at_size_gpu.py).
-    constexpr int NF4 = 32 * (HD / 4);           // float4 per operand tile: 32 keys x HD floats
-    constexpr int NLD = (NF4 + NT - 1) / NT;     // ... per thread; with 192 threads the last pass re-loads (and re-stores) the tile's last float4:
-                                                 // the index is CLAMPED, never predicated (see below: every load of the kernel stays unconditional)
+    constexpr int NLD = HD / 32;  // float4 per thread per operand: 32 keys x HD floats over 256 threads
     // native vector type, NOT float4: with float4 staging arrays hipcc funnels the unconditional loads through ONE temporary register
     // quad into AGPRs for HD >= 96 (global_load; s_waitcnt vmcnt(0); v_accvgpr_write - eight serialized round trips per tile: 110 -> 177 us
     // per launch at HD = 128); ext_vector_type values stay in VGPRs and the loads stay in flight
@@ -145,7 +139,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 3 && HD <= 64) ? 3 : 2) void attent
     auto fetch = [&](int kt) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int i = (NF4 % NT == 0) ? tid + NT * j : min(tid + NT * j, NF4 - 1);
+            const int i = tid + 256 * j;
             const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
             const int key = min(kt * 32 + row, n_keys - 1);
             kreg[j] = *reinterpret_cast<const f32x4*>(kb + (long long)key * ldkv + c4);
@@ -164,7 +158,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 3 && HD <= 64) ? 3 : 2) void attent
         __syncthreads();  // the previous tile is no longer read
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int i = (NF4 % NT == 0) ? tid + NT * j : min(tid + NT * j, NF4 - 1);
+            const int i = tid + 256 * j;
             const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
             *reinterpret_cast<f32x4*>(sK + row * LD + c4) = kreg[j];
             *reinterpret_cast<f32x4*>(sV + row * LD + c4) = vreg[j];
@@ -289,18 +283,12 @@ int launch_attention(const float* q, long long ldq, const float* k, const float*
     QA_REQUIRE((ldq % 4) == 0 && (ldkv % 4) == 0 && (ldo % 4) == 0, "attention: strides must be multiples of 4");
     QA_REQUIRE((gate == nullptr) == (relbias == nullptr) && (!gate || (R >= 0 && !causal && n_q == n_keys)),
                "attention: gate and relbias come together, for non-causal self-attention");
-    // waves per workgroup: 3 where 96-query blocks need fewer waves than 128-query blocks (QA_ATT_NW forces 3 / 4; 0 = this rule)
-    const long long nw_knob = knob(K_ATT_NW);
-    const bool nw3 = !gate && (nw_knob == 3 || (nw_knob == 0 && hd <= 64 && ceil_div(n_q, 96) * 3 < ceil_div(n_q, 128) * 4));
-    dim3 grid((unsigned)ceil_div(n_q, nw3 ? 96 : 128), H, B);
+    dim3 grid((unsigned)ceil_div(n_q, 128), H, B);
     const int dbg = (int)knob(K_ATT_DEBUG);
 #define QA_ATT(HD)                                                                                                          \
     if (gate)                                                                                                                \
         hipLaunchKernelGGL((attention_kernel<HD, true>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, \
                            n_keys, scale, causal, gate, relbias, R, context, q_pos0, ring_end, dbg);                             \
-    else if (nw3)                                                                                                            \
-        hipLaunchKernelGGL((attention_kernel<HD, false, 3>), grid, dim3(192), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, \
-                           n_keys, scale, causal, nullptr, nullptr, 0, context, q_pos0, ring_end, dbg);                          \
     else                                                                                                                     \
         hipLaunchKernelGGL((attention_kernel<HD, false>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, kv_batch_stride, out, ldo, n_q, \
                            n_keys, scale, causal, nullptr, nullptr, 0, context, q_pos0, ring_end, dbg)

@@ -564,7 +564,7 @@ static int launch_gemv_nb(const GemvArgs& a_in, int nt, hipStream_t s, const PfA
     }
     const dim3 grid = with_pf_plane(dim3((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, mt1 ? 16 : LM_ROWS_PER_GROUP)), pf);
     // narrow tiles (NT = 8 / 4) run on the 4x4x1 MFMA, where every FMA is useful (the 16x16x4 form on duplicated columns measured equal:
-    // the matrix pipe is not what bounds the step)
+    // the matrix pipe is not what bounds the step, DESIGN_HISTORY.md section 7a)
 #define QA_GV(MT, NT) hipLaunchKernelGGL((lm_gemv_kernel<MT, NT, MODE, ATT, NB>), grid, dim3(512), 0, s, a, pf)
 #define QA_G4(MT, C) hipLaunchKernelGGL((lm_gemv4_kernel<MT, C, MODE, ATT, 2 * NB>), grid, dim3(512), 0, s, a, pf)
     if (mt1) {
