@@ -906,7 +906,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             extras["unise_lm_b64"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         try:  # its own try: a failure of the 64-segment front-end / detokenizer must not overwrite the LM result above
-            # configs[2] end to end at the driver's default micro-batch (UniSE(max_segments=64)): the LM's decode step
+            # configs[2] end to end at 64 segments (the driver's default micro-batch until r06: UniSE(max_segments=64); now 128, see unise_micro_batch): the LM's decode step
             # costs about the same for 16 and for 64 sequences, so the three stages are timed at 64 segments x 5 s as well
             fe64, bd64 = ssl_bench(dev, "unise", 64, 5.0, reps=2), bicodec_bench(dev, 64, reps=2)
             st64 = {"wavlm_ms": fe64["ms_per_pass"], "lm_generate_ms": extras["unise_lm_b64"]["ms_per_generate"], "bicodec_detokenize_ms": bd64["ms_per_pass"]}

@@ -120,12 +120,21 @@ def test_hip_path_reproduces_reference_golden_20(qa_lib, gpu_device, name):
     taps = {}
     with torch.no_grad():
         ac_o, sc_o = R20.encode(sd, R.pad_wav(wav, 3840), feat, o, taps)
-    # the oracle on THIS host against the reference's codes: equal in the build container (tests/test_oracle_cpu.py), and on another host's
-    # BLAS (the GPU box: other core count, other summation order) equal up to audited near-ties - the range-stress case sits on several
-    audit_codes_bnq(taps["enc.emb"], R.rvq_codebooks(sd, "quantizer", o.num_quantizers), ac_o, ref_ac, max_flip_frac=0.2 if "stress" in name else 0.002)
-    audit_codes_bnq(taps["enc.sem"], R.rvq_codebooks(sd, "semantic_quantizer", o.num_quantizers), sc_o, ref_sc, max_flip_frac=0.2 if "stress" in name else 0.002)
-    audit_codes_bnq(taps["enc.emb"], R.rvq_codebooks(sd, "quantizer", o.num_quantizers), ac, ref_ac, max_flip_frac=0.2 if "stress" in name else 0.002)
-    audit_codes_bnq(taps["enc.sem"], R.rvq_codebooks(sd, "semantic_quantizer", o.num_quantizers), sc, ref_sc, max_flip_frac=0.2 if "stress" in name else 0.002)
+    cb_a, cb_s = R.rvq_codebooks(sd, "quantizer", o.num_quantizers), R.rvq_codebooks(sd, "semantic_quantizer", o.num_quantizers)
+    if "stress" in name:
+        # RANGE-STRESS case.  The chain is: reference == oracle, bit for bit, on the host that made the golden (tests/test_oracle_cpu.py in the
+        # build container); HIP == oracle ON THIS HOST up to audited near-ties at the usual tolerance (below).  What is NOT required is that the
+        # CPU oracle of another host reproduces every code of the golden: with LSTM weights x 4 and LayerScale ~ 1 the torch CPU kernels of two
+        # hosts differ by ~1e-4 of a frame's norm (measured: the GPU box's oracle and the HIP path agree to 2e-6 and BOTH leave the golden at
+        # the same vector, top-2 gap 6e-4 of E|x|^2 - profiles/r06_stress_goldens.txt), so that link is a count, not an audit.
+        left = int((ac_o != ref_ac).any(dim=1).sum() + (sc_o != ref_sc).any(dim=1).sum())
+        assert left <= max(1, ref_ac.shape[0] * ref_ac.shape[2] // 5), left
+        audit_codes_bnq(taps["enc.emb"], cb_a, ac, ac_o)
+        audit_codes_bnq(taps["enc.sem"], cb_s, sc, sc_o)
+    else:
+        assert torch.equal(ac_o, ref_ac) and torch.equal(sc_o, ref_sc)
+        audit_codes_bnq(taps["enc.emb"], cb_a, ac, ref_ac)
+        audit_codes_bnq(taps["enc.sem"], cb_s, sc, ref_sc)
     rec = tok.detokenize(ref_ac.to(gpu_device), ref_sc.to(gpu_device)).cpu().numpy()
     assert rec.shape == g["wav_rec"].shape
     assert float(np.sqrt(np.mean((rec - g["wav_rec"]) ** 2)) / np.sqrt(np.mean(g["wav_rec"] ** 2))) < 1e-4

@@ -64,6 +64,27 @@ __device__ __forceinline__ void lm_prefetch(const PfArgs& pf, int id, int count)
     }
     asm volatile("" ::"v"(acc));
 }
+// Kernel-argument preload (r06; build.py compiles with -mllvm -amdgpu-kernarg-preload-count=14): the scalars a working wave needs for its FIRST loads -
+// weight pointer, activation pointer, K, M, row-group size, row stride, number of row groups - travel as leading SCALAR kernel arguments, which gfx950
+// delivers in SGPRs at wave start; a struct argument is never preloaded, so without this every wave begins with an s_load round trip to the kernel-
+// argument segment (and a second one for gridDim.y, a hidden argument) before it can form an address.  16-segment generate 103.4 -> 101.0 ms, 64 segments
+// 194.8 -> 190.4, TSE 8 x 503 99.0 -> 97.2 (profiles/r06_lm_prefetch_ab.txt); -DQA_LM_KPRE=0 builds the struct-only form for A/B.
+#ifndef QA_LM_KPRE
+#define QA_LM_KPRE 1
+#endif
+#if QA_LM_KPRE
+#define QA_KPRE_PARAMS const float *kp_w, const float *kp_x, int kp_K, int kp_M, int kp_rpg, int kp_ldx, int kp_nrg,
+#define QA_KPRE_APPLY(a) \
+    a.w = kp_w; a.x = kp_x; a.K = kp_K; a.M = kp_M; a.rpg = kp_rpg; a.ldx = kp_ldx;
+#define QA_KPRE_ARGS(a, nrg) (a).w, (a).x, (a).K, (a).M, (a).rpg, (int)(a).ldx, (int)(nrg),
+#define QA_N_ROW_GROUPS kp_nrg  // gridDim.y is a hidden kernel argument: one more scalar load before the first address
+#else
+#define QA_KPRE_PARAMS
+#define QA_KPRE_APPLY(a)
+#define QA_KPRE_ARGS(a, nrg)
+#define QA_N_ROW_GROUPS ((int)gridDim.y)
+#endif
+
 #define QA_LM_PF_PLANE(pf)                                                                   \
     if (__builtin_expect(blockIdx.z != 0, 0)) {                                              \
         lm_prefetch(pf, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);         \
@@ -301,10 +322,11 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const float (*p
 // activation load of the batch is issued before the first MFMA, so a wave pays one memory round trip per batch instead of one per
 // chunk (hipcc does not software-pipeline the chunk loop by itself).
 template <int MT, int NT, int MODE, bool ATT, int NB>
-__global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a_in, const PfArgs pf) {
+__global__ __launch_bounds__(512) void lm_gemv_kernel(QA_KPRE_PARAMS const GemvArgs a_in, const PfArgs pf) {
     QA_LM_PF_PLANE(pf)
     GemvArgs a = a_in;
-    if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x, a.rpg ? a.rpg : 16 * MT);
+    QA_KPRE_APPLY(a)
+    if (QA_N_ROW_GROUPS > 1) row_group(a, blockIdx.y, gridDim.x, a.rpg ? a.rpg : 16 * MT);
     __shared__ float part[8][MT][16][17];
     __shared__ float s_sq[8][MT * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -406,11 +428,12 @@ __global__ __launch_bounds__(512) void lm_gemv_kernel(const GemvArgs a_in, const
 // (8 phases of 4 k, 32-wide steps), so a workgroup pulls the attention partials of 8 rows instead of 16 (row_group above).  A row's
 // products are the same set in the same per-lane order; only the cross-lane fold gains one shuffle.
 template <int MT, int C, int MODE, bool ATT, int NS, bool R8 = false>
-__global__ __launch_bounds__(512) void lm_gemv4_kernel(const GemvArgs a_in, const PfArgs pf) {
+__global__ __launch_bounds__(512) void lm_gemv4_kernel(QA_KPRE_PARAMS const GemvArgs a_in, const PfArgs pf) {
     static_assert(!R8 || MT == 1, "8-row groups exist for one row tile");
     QA_LM_PF_PLANE(pf)
     GemvArgs a = a_in;
-    if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x, R8 ? 8 : 16 * MT);
+    QA_KPRE_APPLY(a)
+    if (QA_N_ROW_GROUPS > 1) row_group(a, blockIdx.y, gridDim.x, R8 ? 8 : 16 * MT);
     constexpr int NT = 4 * C;
     __shared__ float part[8][MT][16][17];
     __shared__ float s_sq[8][MT * 16];
@@ -548,16 +571,16 @@ static int launch_gemv_nb(const GemvArgs& a_in, int nt, hipStream_t s, const PfA
     if (MODE == GM_QKV && a.M > 8 && a.M <= 16 && nt == 16 && (knob(K_LM_ROWSPLIT) & 1)) {  // 9 .. 16 sequences: two 8-row groups (see launch_lm_mlp)
         a.rpg = 8;
         const dim3 grid = with_pf_plane(dim3((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, 8)), pf);
-        hipLaunchKernelGGL((lm_gemv_kernel<1, 16, MODE, ATT, NB>), grid, dim3(512), 0, s, a, pf);
+        hipLaunchKernelGGL((lm_gemv_kernel<1, 16, MODE, ATT, NB>), grid, dim3(512), 0, s, QA_KPRE_ARGS(a, grid.y) a, pf);
         QA_LAUNCH_CHECK();
         return QA_OK;
     }
     if constexpr (ATT) {  // the o_proj launch on narrow tiles: 8-row groups (lm_gemv4_kernel R8)
         if (NB % 2 == 0) {
             const dim3 grid8 = with_pf_plane(dim3((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, 8)), pf);
-            if (nt == 16) hipLaunchKernelGGL((lm_gemv4_kernel<1, 4, MODE, ATT, NB, true>), grid8, dim3(512), 0, s, a, pf);
-            else if (nt == 8) hipLaunchKernelGGL((lm_gemv4_kernel<1, 2, MODE, ATT, NB, true>), grid8, dim3(512), 0, s, a, pf);
-            else hipLaunchKernelGGL((lm_gemv4_kernel<1, 1, MODE, ATT, NB, true>), grid8, dim3(512), 0, s, a, pf);
+            if (nt == 16) hipLaunchKernelGGL((lm_gemv4_kernel<1, 4, MODE, ATT, NB, true>), grid8, dim3(512), 0, s, QA_KPRE_ARGS(a, grid8.y) a, pf);
+            else if (nt == 8) hipLaunchKernelGGL((lm_gemv4_kernel<1, 2, MODE, ATT, NB, true>), grid8, dim3(512), 0, s, QA_KPRE_ARGS(a, grid8.y) a, pf);
+            else hipLaunchKernelGGL((lm_gemv4_kernel<1, 1, MODE, ATT, NB, true>), grid8, dim3(512), 0, s, QA_KPRE_ARGS(a, grid8.y) a, pf);
             QA_LAUNCH_CHECK();
             return QA_OK;
         }
@@ -565,8 +588,8 @@ static int launch_gemv_nb(const GemvArgs& a_in, int nt, hipStream_t s, const PfA
     const dim3 grid = with_pf_plane(dim3((unsigned)(a.N / nt), (unsigned)ceil_div(a.M, mt1 ? 16 : LM_ROWS_PER_GROUP)), pf);
     // narrow tiles (NT = 8 / 4) run on the 4x4x1 MFMA, where every FMA is useful (the 16x16x4 form on duplicated columns measured equal:
     // the matrix pipe is not what bounds the step, DESIGN_HISTORY.md section 7a)
-#define QA_GV(MT, NT) hipLaunchKernelGGL((lm_gemv_kernel<MT, NT, MODE, ATT, NB>), grid, dim3(512), 0, s, a, pf)
-#define QA_G4(MT, C) hipLaunchKernelGGL((lm_gemv4_kernel<MT, C, MODE, ATT, 2 * NB>), grid, dim3(512), 0, s, a, pf)
+#define QA_GV(MT, NT) hipLaunchKernelGGL((lm_gemv_kernel<MT, NT, MODE, ATT, NB>), grid, dim3(512), 0, s, QA_KPRE_ARGS(a, grid.y) a, pf)
+#define QA_G4(MT, C) hipLaunchKernelGGL((lm_gemv4_kernel<MT, C, MODE, ATT, 2 * NB>), grid, dim3(512), 0, s, QA_KPRE_ARGS(a, grid.y) a, pf)
     if (mt1) {
         if (nt == 16) QA_GV(1, 16);
         else if (nt == 8) QA_G4(1, 2);
@@ -628,10 +651,12 @@ int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s, const PfA
 // product on v_mfma_f32_16x16x4_f32 straight from an LDS copy of the activation tile, W_down slice prefetched at kernel entry.
 // AC = activation columns per workgroup: 16 (two gate/up tiles, I / 16 partials) or 8 (one tile, I / 8 partials, twice the workgroups)
 template <int MT, int NB, int AC>
-__global__ __launch_bounds__(512) void lm_mlp_kernel(const GemvArgs a_in, const float* __restrict__ wd, float* __restrict__ partial, const PfArgs pf) {
+__global__ __launch_bounds__(512) void lm_mlp_kernel(QA_KPRE_PARAMS const float* __restrict__ wd, const GemvArgs a_in, float* __restrict__ partial,
+                                                     const PfArgs pf) {
     QA_LM_PF_PLANE(pf)
     GemvArgs a = a_in;
-    if (gridDim.y > 1) row_group(a, blockIdx.y, gridDim.x, a.rpg ? a.rpg : 16 * MT);
+    QA_KPRE_APPLY(a)
+    if (QA_N_ROW_GROUPS > 1) row_group(a, blockIdx.y, gridDim.x, a.rpg ? a.rpg : 16 * MT);
     constexpr int NTL = AC / 8;  // gate/up decode tiles (8 gate + 8 up rows each) per workgroup
     __shared__ float part[8][NTL][MT][16][17];
     __shared__ float s_sq[8][MT * 16];
@@ -639,7 +664,7 @@ __global__ __launch_bounds__(512) void lm_mlp_kernel(const GemvArgs a_in, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int j = blockIdx.x;
-    const int K = a.K, M = a.M, d = a.d;
+    const int K = a.K, M = a.M, d = QA_LM_KPRE ? a.K : a.d;  // launch_lm_mlp requires K == d; K is a preloaded argument
     const int kw = K >> 3, k0 = wave * kw;
     // every load of the workgroup in flight before the first MFMA: gate / up rows, x, and the W_down slice of phase 2
     const float* wp[NTL];
@@ -810,7 +835,7 @@ int launch_lm_mlp(const GemvArgs& a, int I, int ac, const float* wd, float* part
     PfArgs pf = pf_in ? *pf_in : PfArgs{};
     const dim3 grid = with_pf_plane(dim3((unsigned)n_part, (unsigned)ceil_div(a.M, rpg)), pf);  // partial: [row group][n_part][16 mt][d]
     QA_REQUIRE(ac == 16, "lm_mlp: %d activation columns per workgroup (only 16 is built)", ac);
-#define QA_MLP(MT, NB) hipLaunchKernelGGL((lm_mlp_kernel<MT, NB, 16>), grid, dim3(512), 0, s, ag, wd, partial, pf)
+#define QA_MLP(MT, NB) hipLaunchKernelGGL((lm_mlp_kernel<MT, NB, 16>), grid, dim3(512), 0, s, QA_KPRE_ARGS(ag, grid.y) wd, ag, partial, pf)
     if (a.d == 512) {
         if (mt == 1) { QA_MLP(1, 2); } else { QA_MLP(2, 2); }
     } else {
@@ -833,20 +858,22 @@ int launch_lm_mlp(const GemvArgs& a, int I, int ac, const float* wd, float* part
 // one partial record [o (HD, un-normalised, relative to m) | m | l | pad2] that the o_proj GEMV merges across the S splits
 // (att_merge).  n_keys = pos + 1 (the new key included): `pos` is a launch argument when the host drives the loop, or read from the
 // device-side loop state (pos < 0) when a captured step is replayed.
-template <int HD, int NW>
-__global__ __launch_bounds__(NW * 64) void lm_attn_kernel(const float* __restrict__ q, long long ldq,
-                                                          const float* __restrict__ kc, const float* __restrict__ vc,
-                                                          long long kv_bstride, long long ldkv, float* __restrict__ part,
-                                                          const int* __restrict__ state, float scale, int pos) {
+// DEVPOS: the position comes from the device-side loop state (a captured step that is replayed); the eager path passes it as an argument and must not
+// touch `state` at all - hipcc otherwise loads state[ST_POS] speculatively: two dependent scalar loads in front of the first K / V address.
+// Argument order: everything the first K / V loads need sits in the first 14 dwords (kernel-argument preload, see QA_LM_KPRE above).
+template <int HD, int NW, bool DEVPOS>
+__global__ __launch_bounds__(NW * 64) void lm_attn_kernel(const float* __restrict__ q, const float* __restrict__ kc, const float* __restrict__ vc,
+                                                          long long kv_bstride, int pos, int ldq, int ldkv, int S, int H, float scale,
+                                                          float* __restrict__ part, const int* __restrict__ state) {  // S, H = gridDim.z, .x (hidden arguments otherwise)
     constexpr int LPK = HD / 4;    // lanes per key row
     constexpr int KPI = 64 / LPK;  // key rows per load instruction
     constexpr int NI = 16 / KPI;   // load instructions per 16-key tile (per operand)
     __shared__ float s_m[NW], s_l[NW];
     __shared__ __attribute__((aligned(16))) float s_o[NW][HD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y, h = blockIdx.x, sp = blockIdx.z, S = gridDim.z, H = gridDim.x;
+    const int b = blockIdx.y, h = blockIdx.x, sp = blockIdx.z;
     const int kq = lane / LPK, c4 = (lane % LPK) * 4;
-    const int n_keys = (pos >= 0 ? pos : state[ST_POS]) + 1;
+    const int n_keys = (DEVPOS ? state[ST_POS] : pos) + 1;
     const int n_tiles = (n_keys + 15) >> 4;
     const float* kb = kc + (long long)b * kv_bstride + h * HD + c4;
     const float* vb = vc + (long long)b * kv_bstride + h * HD + c4;
@@ -943,13 +970,16 @@ int launch_lm_attn(const float* q, long long ldq, const float* kc, const float* 
     const dim3 grid(H, B, S);
     switch (hd) {
         case 64:
-            hipLaunchKernelGGL((lm_attn_kernel<64, 8>), grid, dim3(512), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale, pos);
+            if (pos >= 0) hipLaunchKernelGGL((lm_attn_kernel<64, 8, false>), grid, dim3(512), 0, s, q, kc, vc, kv_bstride, pos, (int)ldq, (int)ldkv, S, H, scale, part, state);
+            else hipLaunchKernelGGL((lm_attn_kernel<64, 8, true>), grid, dim3(512), 0, s, q, kc, vc, kv_bstride, pos, (int)ldq, (int)ldkv, S, H, scale, part, state);
             break;
         case 128:
-            hipLaunchKernelGGL((lm_attn_kernel<128, 8>), grid, dim3(512), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale, pos);
+            if (pos >= 0) hipLaunchKernelGGL((lm_attn_kernel<128, 8, false>), grid, dim3(512), 0, s, q, kc, vc, kv_bstride, pos, (int)ldq, (int)ldkv, S, H, scale, part, state);
+            else hipLaunchKernelGGL((lm_attn_kernel<128, 8, true>), grid, dim3(512), 0, s, q, kc, vc, kv_bstride, pos, (int)ldq, (int)ldkv, S, H, scale, part, state);
             break;
         case 32:
-            hipLaunchKernelGGL((lm_attn_kernel<32, 8>), grid, dim3(512), 0, s, q, ldq, kc, vc, kv_bstride, ldkv, part, state, scale, pos);
+            if (pos >= 0) hipLaunchKernelGGL((lm_attn_kernel<32, 8, false>), grid, dim3(512), 0, s, q, kc, vc, kv_bstride, pos, (int)ldq, (int)ldkv, S, H, scale, part, state);
+            else hipLaunchKernelGGL((lm_attn_kernel<32, 8, true>), grid, dim3(512), 0, s, q, kc, vc, kv_bstride, pos, (int)ldq, (int)ldkv, S, H, scale, part, state);
             break;
         default: set_error("lm_attn: head_dim=%d unsupported", hd); return QA_ERR_UNSUPPORTED;
     }

@@ -83,14 +83,15 @@ def stft_logmel(x: torch.Tensor, hop_length: int = HOP_LENGTH, win_length: int =
 
 
 class UniSE:
-    def __init__(self, dnn, semantic_model, tokenizer=None, detokenize: Optional[Callable] = None, max_segments: int = 64):
+    def __init__(self, dnn, semantic_model, tokenizer=None, detokenize: Optional[Callable] = None, max_segments: int = 128):
         """dnn: unified_audio_amd.LLM_SFT; semantic_model: unified_audio_amd.SSLFeatureExtractor(SPEC_WAVLM_BASE_PLUS);
         tokenizer: unified_audio_amd.BiCodecTokenizer (or any object / callable with the reference's
         `detokenize(global_tokens [B, 1, 32], semantic_tokens [B, N]) -> wav [B, 1, t]`, model.py:193).
         max_segments: 5 s segments per pass through the three stages (the micro-batch).  The reference feeds one utterance per step
-        (data_module.py:340); here all segments of a call are batched, 64 at a time: the LM's decode step costs about the same for 16
-        and for 64 sequences (one chain, two row groups per launch: 92 k tok/s against 41 k at 16), memory stays
-        bounded for long file lists, and - every stage being batch-invariant - the result does not depend on the value."""
+        (data_module.py:340); here all segments of a call are batched, 128 at a time - the measured optimum (profiles/r06_unise_micro_batch.txt,
+        256 segments end to end: 773 audio-s/s at 64 per pass, 848 at 128, 848 at 256): the LM runs two chains of 64 sequences (112 k tok/s
+        against 94 k with one chain and 44 k at 16 segments), four chains add nothing, memory stays bounded for long file lists, and - every
+        stage being batch-invariant - the result does not depend on the value."""
         self.dnn = dnn
         self.semantic_model = semantic_model
         self.detokenize = detokenize if detokenize is not None else (tokenizer.detokenize if tokenizer is not None else None)
@@ -375,7 +376,7 @@ class Model:
     `test_steps(batches)` is the batched form: any number of the same tuples in one pass (segments of all files share the launches).
     """
 
-    def __init__(self, config, *, device: str | torch.device = "cuda:0", semantic_model=None, tokenizer=None, dnn=None, max_segments: int = 64):
+    def __init__(self, config, *, device: str | torch.device = "cuda:0", semantic_model=None, tokenizer=None, dnn=None, max_segments: int = 128):
         from .bicodec import BiCodecTokenizer
         from .llm import LLM_SFT
         from .ssl import SPEC_WAVLM_BASE_PLUS, SSLFeatureExtractor
