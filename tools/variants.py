@@ -43,7 +43,7 @@ def main():
                     path = os.path.join(out, src)
                     with open(path, "w") as f:
                         f.write(transform(open(os.path.join(B.CSRC, src)).read()))
-                subprocess.run([B._hipcc(), *B.FLAGS, *flags.split(), "-x", "hip", "-c", path, "-o", obj], check=True,
+                subprocess.run([B._hipcc(), *B.FLAGS, *B.EXTRA_FLAGS.get(src, []), *flags.split(), "-x", "hip", "-c", path, "-o", obj], check=True,
                                stderr=subprocess.DEVNULL)
             objs.append(obj)
         lib = os.path.join(out, "libquarkaudio_hip.so")

@@ -15,11 +15,12 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libquarkaudio_hip.so")
 SOURCES = ["api.cpp", "conv_gemm.hip", "ew.hip", "attention.hip", "lstm.hip", "rvq.hip", "lm_kernels.hip", "lm_decode.hip", "ssl_kernels.hip", "bicodec_kernels.hip", "seanet_front.hip", "hcodec.cpp", "lm.cpp", "ssl.cpp", "bicodec.cpp"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I", INCLUDE, "-I", CSRC]
 # -amdgpu-kernarg-preload-count: gfx950 delivers the first 14 dwords of a kernel's leading SCALAR arguments in SGPRs at wave start, so a wave can form
-# its first addresses without an s_load round trip to the kernel-argument segment (r06: -2.4 % on the latency-bound UniSE decode step, where
-# lm_decode.hip passes its hot scalars in front of the argument struct; kernels that start with a struct argument are unaffected)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-kernarg-preload-count=14",
-         "-I", INCLUDE, "-I", CSRC]
+# its first addresses without an s_load round trip to the kernel-argument segment.  Only for the latency-bound UniSE decode step, whose kernels pass
+# their hot scalars in front of the argument struct (r06: 103.4 -> 101.0 ms per 16-segment generate); applied to EVERY source the same generate took
+# 102.4 ms (profiles/r06_lm_prefetch_ab.txt), so the flag stays with the one file it was measured on.
+EXTRA_FLAGS = {"lm_decode.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"]}
 
 
 def _hipcc() -> str:
@@ -38,7 +39,7 @@ def _compile(src: str) -> str:
     obj = os.path.join(BUILD, src.rsplit(".", 1)[0] + ".o")
     if os.path.exists(obj) and os.path.getmtime(obj) >= _newest_dep():
         return obj
-    cmd = [_hipcc(), *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
