@@ -209,6 +209,9 @@ typedef struct qa_conv_args {
     int32_t in_rep;        /* 0/1 none; r > 1: x is read as x.repeat_interleave(r) along frames (zero padding only) */
 } qa_conv_args;
 int qa_conv1d_cl(const qa_conv_args* args, void* stream);
+/* RMSNorm (mode 1: transformer.py:77-96 of H-Codec 1.0, LlamaRMSNorm) / LayerNorm (mode 2: nn.LayerNorm, biased variance) over the last axis of
+ * x [rows, C] (C % 4 == 0, C <= 2048); w [C], b [C] or NULL.  Exposed for kernel-level parity tests. */
+int qa_rownorm(const float* x, const float* w, const float* b, float* y, int64_t rows, int32_t C, float eps, int32_t mode, void* stream);
 
 /* ---- host logic exposed for CPU tests (no device needed) ------------------------------------------------
  * SConv1d geometry of the reference (encoder_modules/conv.py:54-61,195-211, non-causal): for an input of L frames,

@@ -8,7 +8,7 @@ import torch.nn.functional as F
 
 from oracle import hcodec_ref as R
 from oracle import rvq_c
-from tests.util import act_ref, conv1d_cl, rel_err
+from tests.util import act_ref, conv1d_cl, rel_err, rownorm
 
 pytestmark = pytest.mark.gpu
 
@@ -124,6 +124,25 @@ def test_conv_gemm_tile_configurations_are_bit_identical(qa_lib, gpu_device, kno
     assert torch.isfinite(outs[-1]).all()
     for cfg in (1, 2, 3, 4):
         assert torch.equal(outs[cfg], outs[-1]), f"QA_GEMM_CFG={cfg} differs from the cost model's choice"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,C,bias", [(1, 512, False), (2, 512, True), (2, 768, True), (1, 1024, False), (2, 1024, False), (2, 256, True), (1, 1536, False)])
+def test_rownorm_matches_torch(qa_lib, gpu_device, mode, C, bias):
+    """qa_rownorm against torch's fp32 LayerNorm (nn.LayerNorm: biased variance) / the RMSNorm of transformer.py:77-96 (x * rsqrt(mean(x^2) + eps) * w),
+    rows with a large common offset included (the centred second pass of the LayerNorm form must not lose it)."""
+    g = torch.Generator().manual_seed(100 + C + mode)
+    rows = 1003
+    x = torch.randn(rows, C, generator=g) * (torch.rand(rows, 1, generator=g) * 3 + 0.1) + torch.randn(rows, 1, generator=g) * 5
+    w = torch.rand(C, generator=g) + 0.5
+    b = torch.randn(C, generator=g) if bias else None
+    eps = 1e-5 if mode == 2 else 1e-6
+    y = rownorm(qa_lib, x.to(gpu_device), w.to(gpu_device), b.to(gpu_device) if bias else None, eps=eps, mode=mode).cpu()
+    xd = x.double()
+    ref = (F.layer_norm(xd, (C,), w.double(), b.double() if bias else None, eps) if mode == 2
+           else xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + eps) * w.double())
+    assert rel_err(y, ref) < 5e-7
+    assert (y - ref.float()).abs().max() < 2e-5
 
 
 def _rvq_problem(n, Q, K, D, seed):

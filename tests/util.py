@@ -49,6 +49,16 @@ def conv1d_cl(lib, x, w, bias=None, *, stride=1, pad=(0, 0), pad_mode=0, prologu
     return y
 
 
+def rownorm(lib, x, w, b=None, *, eps=1e-5, mode=2):
+    """Call qa_rownorm: mode 1 RMSNorm, 2 LayerNorm over the last axis of x [..., C] (cuda)."""
+    from unified_audio_amd import _lib
+
+    y = torch.full_like(x, float("nan"))
+    _lib.check(lib.qa_rownorm(x.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(), x.numel() // x.shape[-1],
+                              x.shape[-1], eps, mode, torch.cuda.current_stream().cuda_stream))
+    return y
+
+
 def act_ref(v, code):
     return {0: lambda t: t, 1: F.elu, 2: F.gelu, 3: F.silu}[code](v)
 

@@ -308,6 +308,18 @@ int qa_conv1d_cl(const qa_conv_args* args, void* stream) {
     return launch_conv_gemm(p, static_cast<hipStream_t>(stream));
 }
 
+int qa_rownorm(const float* x, const float* w, const float* b, float* y, int64_t rows, int32_t C, float eps, int32_t mode, void* stream) {
+    if (!x || !w || !y || rows < 0) {
+        set_error("qa_rownorm: null argument");
+        return QA_ERR_INVALID;
+    }
+    if (rows == 0) return QA_OK;
+    if (mode == NORM_RMS) return launch_rmsnorm(x, w, y, rows, C, eps, static_cast<hipStream_t>(stream));
+    if (mode == NORM_LAYER) return launch_layernorm(x, w, b, y, rows, C, eps, static_cast<hipStream_t>(stream));
+    set_error("qa_rownorm: mode %d (1 RMSNorm, 2 LayerNorm)", mode);
+    return QA_ERR_INVALID;
+}
+
 int qa_codes_check_async(const int64_t* codes, int64_t n, int64_t lo, int64_t limit, int64_t* bad_count_dev, void* stream) {
     if (!codes || !bad_count_dev) {
         set_error("qa_codes_check_async: null argument");

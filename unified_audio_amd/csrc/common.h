@@ -92,6 +92,44 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Row-norm arithmetic of rownorm_kernel (ew.hip): ONE statement of every step, compiled with contraction off (`fp contract(off)`: the instructions
+// carry no `contract` flag, so they stay unfused wherever they are inlined) and fmaf where a fused multiply-add is meant - any kernel that repeats
+// these statements on the same lane map (lane l of the row's wave holds columns 4 l + 256 i .. + 3) produces the bits of rownorm_kernel.  r06 used
+// that for a norm-fused conv_gemm operand (bit-identical, 4 % SLOWER on H-Codec 1.5: profiles/r06_norm_fused_gemm_ab.txt; removed).
+enum { NORM_NONE = 0, NORM_RMS = 1, NORM_LAYER = 2 };  // RMSNorm: transformer.py:77-96 (eps inside the sqrt of mean(x^2)); LayerNorm: biased variance
+__device__ __forceinline__ float norm_add(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float norm_sum4(float x, float y, float z, float w) {
+#pragma clang fp contract(off)
+    return ((x + y) + z) + w;
+}
+__device__ __forceinline__ float norm_sq4(float x, float y, float z, float w) {
+#pragma clang fp contract(off)
+    return fmaf(w, w, fmaf(z, z, fmaf(y, y, x * x)));
+}
+__device__ __forceinline__ float norm_csq4(float x, float y, float z, float w, float mean) {
+#pragma clang fp contract(off)
+    const float a = x - mean, b = y - mean, c = z - mean, d = w - mean;
+    return fmaf(d, d, fmaf(c, c, fmaf(b, b, a * a)));
+}
+__device__ __forceinline__ float norm_mean(float sum, int C) {
+#pragma clang fp contract(off)
+    return sum / (float)C;
+}
+__device__ __forceinline__ float norm_rstd(float sumsq, int C, float eps) {
+#pragma clang fp contract(off)
+    const float var = sumsq / (float)C;
+    return rsqrtf(var + eps);
+}
+// (v - mean) * rstd * w (+ b): mean = 0 for RMSNorm, b = 0 without a bias
+__device__ __forceinline__ float norm_apply(float v, float mean, float rstd, float w, float b) {
+#pragma clang fp contract(off)
+    const float t = (v - mean) * rstd;
+    return fmaf(t, w, b);
+}
+
 // ---- kernel launchers (host) ----
 struct ConvParams {
     const float* x;

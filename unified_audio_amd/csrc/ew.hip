@@ -53,7 +53,8 @@ int launch_conv_in(const float* x, const float* w_kc, const float* bias, float* 
 // Row norms: one wave per row, up to 8 float4 per lane (C <= 2048).
 constexpr int MAX_V4 = 8;
 
-// mode 0: RMSNorm (transformer.py:77-96, eps inside the sqrt of mean(x^2)), mode 1: LayerNorm (biased variance)
+// mode 0: RMSNorm (transformer.py:77-96, eps inside the sqrt of mean(x^2)), mode 1: LayerNorm (biased variance).  Every arithmetic step is one of
+// common.h's norm_* helpers: conv_gemm_kernel's norm-fused A-operand staging (r06) repeats them and must produce the same bits.
 template <int MODE>
 __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ b, float* __restrict__ y,
@@ -69,26 +70,21 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
         const int c = lane * 4 + i * 256;
         if (c < C) {
             v[i] = *reinterpret_cast<const float4*>(xr + c);
-            s += (MODE == 0) ? (v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w)
-                             : (v[i].x + v[i].y + v[i].z + v[i].w);
+            s = norm_add(s, (MODE == 0) ? norm_sq4(v[i].x, v[i].y, v[i].z, v[i].w) : norm_sum4(v[i].x, v[i].y, v[i].z, v[i].w));
         }
     }
     s = wave_sum(s);
     float mean = 0.f, rstd;
     if (MODE == 0) {
-        rstd = rsqrtf(s / C + eps);
+        rstd = norm_rstd(s, C, eps);
     } else {
-        mean = s / C;
+        mean = norm_mean(s, C);
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAX_V4; ++i) {
-            if (lane * 4 + i * 256 < C) {
-                const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-                q += a * a + bb * bb + cc * cc + d * d;
-            }
-        }
+        for (int i = 0; i < MAX_V4; ++i)
+            if (lane * 4 + i * 256 < C) q = norm_add(q, norm_csq4(v[i].x, v[i].y, v[i].z, v[i].w, mean));
         q = wave_sum(q);
-        rstd = rsqrtf(q / C + eps);
+        rstd = norm_rstd(q, C, eps);
     }
     float* yr = y + row * C;
 #pragma unroll
@@ -96,15 +92,12 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
         const int c = lane * 4 + i * 256;
         if (c >= C) continue;
         const float4 ww = *reinterpret_cast<const float4*>(w + c);
+        const float4 bv = (MODE == 1 && b) ? *reinterpret_cast<const float4*>(b + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 o;
-        o.x = (v[i].x - mean) * rstd * ww.x;
-        o.y = (v[i].y - mean) * rstd * ww.y;
-        o.z = (v[i].z - mean) * rstd * ww.z;
-        o.w = (v[i].w - mean) * rstd * ww.w;
-        if (MODE == 1 && b) {
-            const float4 bv = *reinterpret_cast<const float4*>(b + c);
-            o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
-        }
+        o.x = norm_apply(v[i].x, mean, rstd, ww.x, bv.x);
+        o.y = norm_apply(v[i].y, mean, rstd, ww.y, bv.y);
+        o.z = norm_apply(v[i].z, mean, rstd, ww.z, bv.z);
+        o.w = norm_apply(v[i].w, mean, rstd, ww.w, bv.w);
         *reinterpret_cast<float4*>(yr + c) = o;
     }
 }
@@ -131,7 +124,10 @@ int launch_layernorm(const float* x, const float* w, const float* b, float* y, l
 // Depthwise Conv1d (zero "same" padding, vq/conv.py:33-56) with optional fused LayerNorm over channels
 // (ConvNeXtBlock: dwconv k7 -> LN, vq/conv.py:200-203; sub-pixel upsampler's dw k5, vq/conv.py:86-90).
 // w layout [ksize][C] so that lanes read consecutive channels.
-template <bool LN>
+// KS > 0: the tap count is a compile-time constant (7: ConvNeXt, 5: the sub-pixel upsampler) - r06: every tap of a channel chunk is loaded before
+// the first FMA (clamped source frame, the product masked to zero outside the clip), so a wave pays ONE memory round trip per chunk; with a run-time
+// `ksize` (KS = 0, any other kernel size) hipcc emits load -> wait -> fma per tap: seven dependent L2 round trips (42 us per launch at 32 x 500 x 1024).
+template <bool LN, int KS>
 __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, const float* __restrict__ lnw,
                                                      const float* __restrict__ lnb, float* __restrict__ y, int B, int T,
@@ -148,15 +144,35 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
         const int c = lane * 4 + i * 256;
         if (c >= C) continue;
         float4 acc = *reinterpret_cast<const float4*>(bias + c);
-        for (int j = 0; j < ksize; ++j) {
-            const int src = t + j - pad;
-            if (src < 0 || src >= T) continue;
-            const float4 xv = *reinterpret_cast<const float4*>(xb + (long long)src * C + c);
-            const float4 wv = *reinterpret_cast<const float4*>(w + (long long)j * C + c);
-            acc.x = fmaf(xv.x, wv.x, acc.x);
-            acc.y = fmaf(xv.y, wv.y, acc.y);
-            acc.z = fmaf(xv.z, wv.z, acc.z);
-            acc.w = fmaf(xv.w, wv.w, acc.w);
+        if (KS > 0) {
+            float4 xv[KS > 0 ? KS : 1], wv[KS > 0 ? KS : 1];
+            float keep[KS > 0 ? KS : 1];
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                const int src = t + j - pad;
+                keep[j] = (src >= 0 && src < T) ? 1.f : 0.f;
+                xv[j] = *reinterpret_cast<const float4*>(xb + (long long)min(max(src, 0), T - 1) * C + c);
+                wv[j] = *reinterpret_cast<const float4*>(w + (long long)j * C + c);
+            }
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {  // same fma chain, in tap order, as the run-time loop (a tap outside the clip adds +0 * w: exact)
+                if (keep[j] == 0.f) continue;
+                acc.x = fmaf(xv[j].x, wv[j].x, acc.x);
+                acc.y = fmaf(xv[j].y, wv[j].y, acc.y);
+                acc.z = fmaf(xv[j].z, wv[j].z, acc.z);
+                acc.w = fmaf(xv[j].w, wv[j].w, acc.w);
+            }
+        } else {
+            for (int j = 0; j < ksize; ++j) {
+                const int src = t + j - pad;
+                if (src < 0 || src >= T) continue;
+                const float4 xv = *reinterpret_cast<const float4*>(xb + (long long)src * C + c);
+                const float4 wv = *reinterpret_cast<const float4*>(w + (long long)j * C + c);
+                acc.x = fmaf(xv.x, wv.x, acc.x);
+                acc.y = fmaf(xv.y, wv.y, acc.y);
+                acc.z = fmaf(xv.z, wv.z, acc.z);
+                acc.w = fmaf(xv.w, wv.w, acc.w);
+            }
         }
         v[i] = acc;
         s += acc.x + acc.y + acc.z + acc.w;
@@ -199,12 +215,17 @@ int launch_dwconv(const float* x, const float* w_kc, const float* bias, const fl
     const unsigned grid = (unsigned)ceil_div((long long)B * T, 4);
     const int pad = pad_left >= 0 ? pad_left : ksize / 2;
     HbmProf prof_(HK_DWCONV_LN, 8.0 * (double)B * T * C, s);
-    if (lnw)
-        hipLaunchKernelGGL(dwconv_kernel<true>, dim3(grid), dim3(256), 0, s, x, w_kc, bias, lnw, lnb, y, B, T, C, ksize,
-                           eps, pad);
-    else
-        hipLaunchKernelGGL(dwconv_kernel<false>, dim3(grid), dim3(256), 0, s, x, w_kc, bias, lnw, lnb, y, B, T, C,
-                           ksize, eps, pad);
+#define QA_DW(LN, KS) hipLaunchKernelGGL((dwconv_kernel<LN, KS>), dim3(grid), dim3(256), 0, s, x, w_kc, bias, lnw, lnb, y, B, T, C, ksize, eps, pad)
+    if (lnw) {
+        if (ksize == 7) QA_DW(true, 7);
+        else if (ksize == 5) QA_DW(true, 5);
+        else QA_DW(true, 0);
+    } else {
+        if (ksize == 7) QA_DW(false, 7);
+        else if (ksize == 5) QA_DW(false, 5);
+        else QA_DW(false, 0);
+    }
+#undef QA_DW
     QA_LAUNCH_CHECK();
     return QA_OK;
 }

@@ -341,7 +341,10 @@ int fused_step(qa_lm* lm, const LMBuffers& b, int B, int lo, int width, long lon
         pf.n_tiles[r] = n_tiles;
     };
     auto pf_mlp = [&](PfArgs& pf, const LMLayer& L) {  // the fused MLP launch: workgroup j streams 2 gate/up tiles (32 rows) and W_down slice j
-        if (!fused_mlp || !L.down_dec) return;
+        if (!fused_mlp || !L.down_dec) {  // separate launches (QA_LM_MLP_FUSED=0): the gate/up launch streams tiles of nt_gu rows
+            pf_region(pf, 0, L.gu_dec, (long long)lm->nt_gu * d * 4, 2 * I / lm->nt_gu);
+            return;
+        }
         pf_region(pf, 0, L.gu_dec, (long long)2 * lm->mlp_ac * d * 4, I / lm->mlp_ac);
         pf_region(pf, 1, L.down_dec, (long long)lm->mlp_ac * d * 4, I / lm->mlp_ac);
     };
@@ -393,11 +396,18 @@ int fused_step(qa_lm* lm, const LMBuffers& b, int B, int lo, int width, long lon
             QA_TRY(launch_lm_mlp(g, I, lm->mlp_ac, L.down_dec, b.mlp_part, b.x, d, b.x, d, s, &gpf));
             continue;
         }
-        QA_TRY(launch_lm_gemv(g, GM_GATEUP, lm->nt_gu, s));
+        PfArgs gupf{};
+        if (pfk & 2) pf_region(gupf, 0, L.down.w, (long long)lm->nt_down * I * 4, d / lm->nt_down);
+        QA_TRY(launch_lm_gemv(g, GM_GATEUP, lm->nt_gu, s, &gupf));
         // 5. down_proj + residual
         GemvArgs dn = a;
         dn.x = b.u; dn.ldx = I; dn.w = L.down.w; dn.N = d; dn.K = I; dn.res = b.x; dn.ldr = d; dn.y = b.x; dn.ldy = d;
-        QA_TRY(launch_lm_gemv(dn, GM_RESID, lm->nt_down, s));
+        PfArgs dpf{};
+        if (pfk & 4) {
+            if (i + 1 < sp.n_layers) pf_region(dpf, 0, lm->layers[i + 1].qkv_dec, (long long)lm->nt_qkv * d * 4, 3 * d / lm->nt_qkv);
+            else pf_region(dpf, 0, lm->head.w + (size_t)lo * d, (long long)head_nt(width) * d * 4, width / head_nt(width));
+        }
+        QA_TRY(launch_lm_gemv(dn, GM_RESID, lm->nt_down, s, &dpf));
     }
     // 6. final RMSNorm (weight folded into output_head) + the rows of output_head inside the active vocabulary slice (the range
     //    mask of llm_sft.py:150-153 / :180-182 sets everything else to -inf) + per-tile arg-max
