@@ -68,23 +68,21 @@ __device__ __forceinline__ void lm_prefetch(const PfArgs& pf, int id, int count)
 // weight pointer, activation pointer, K, M, row-group size, row stride, number of row groups - travel as leading SCALAR kernel arguments, which gfx950
 // delivers in SGPRs at wave start; a struct argument is never preloaded, so without this every wave begins with an s_load round trip to the kernel-
 // argument segment (and a second one for gridDim.y, a hidden argument) before it can form an address.  16-segment generate 103.4 -> 101.0 ms, 64 segments
-// 194.8 -> 190.4, TSE 8 x 503 99.0 -> 97.2 (profiles/r06_lm_prefetch_ab.txt); -DQA_LM_KPRE=0 builds the struct-only form for A/B.
-#ifndef QA_LM_KPRE
-#define QA_LM_KPRE 1
-#endif
-#if QA_LM_KPRE
+// 194.8 -> 190.4, TSE 8 x 503 99.0 -> 97.2 (profiles/r06_lm_prefetch_ab.txt).
+// r06, second step: the GEMV kernels form their weight addresses and issue the weight batch from those registers alone, BEFORE they touch the argument
+// struct - the struct's scalar loads (row-group pointer shifts of q / k / v caches, RoPE table, residual, state) sat in program order in front of the
+// first global_load (an `s_waitcnt lgkmcnt(0)` ahead of it in the ISA), so the preload had bought the scalars but not the head start: 102.7 -> 100.3 ms
+// at 16 segments on one box (profiles/r06_lm_prefetch_ab.txt, session 10).  Issuing the ACTIVATION batch from the preloaded registers as well (kp_x: the
+// plain rows of x, or the partial-record base of the o_proj launch with S | H << 8 | hd << 16 in kp_ldx) measured 0.3 - 0.4 ms slower than that in all three
+// pairs and is not kept; kp_x / kp_ldx still carry those values so that the kernels read neither from the struct.
 #define QA_KPRE_PARAMS const float *kp_w, const float *kp_x, int kp_K, int kp_M, int kp_rpg, int kp_ldx, int kp_nrg,
 #define QA_KPRE_APPLY(a) \
-    a.w = kp_w; a.x = kp_x; a.K = kp_K; a.M = kp_M; a.rpg = kp_rpg; a.ldx = kp_ldx;
-#define QA_KPRE_ARGS(a, nrg) (a).w, (a).x, (a).K, (a).M, (a).rpg, (int)(a).ldx, (int)(nrg),
+    a.w = kp_w; a.K = kp_K; a.M = kp_M; a.rpg = kp_rpg;
+#define QA_KPRE_APPLY_X(a) \
+    a.x = kp_x; a.ldx = kp_ldx;
+#define QA_KPRE_ARGS(a, nrg) (a).w, ((a).att_part ? (a).att_part : ((a).tok ? nullptr : (a).x)), (a).K, (a).M, (a).rpg, \
+    ((a).att_part ? (int)((a).S | ((a).H << 8) | ((a).hd << 16)) : (int)(a).ldx), (int)(nrg),
 #define QA_N_ROW_GROUPS kp_nrg  // gridDim.y is a hidden kernel argument: one more scalar load before the first address
-#else
-#define QA_KPRE_PARAMS
-#define QA_KPRE_APPLY(a)
-#define QA_KPRE_ARGS(a, nrg)
-#define QA_N_ROW_GROUPS ((int)gridDim.y)
-#endif
-
 #define QA_LM_PF_PLANE(pf)                                                                   \
     if (__builtin_expect(blockIdx.z != 0, 0)) {                                              \
         lm_prefetch(pf, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);         \
@@ -324,18 +322,20 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const float (*p
 template <int MT, int NT, int MODE, bool ATT, int NB>
 __global__ __launch_bounds__(512) void lm_gemv_kernel(QA_KPRE_PARAMS const GemvArgs a_in, const PfArgs pf) {
     QA_LM_PF_PLANE(pf)
-    GemvArgs a = a_in;
-    QA_KPRE_APPLY(a)
-    if (QA_N_ROW_GROUPS > 1) row_group(a, blockIdx.y, gridDim.x, a.rpg ? a.rpg : 16 * MT);
     __shared__ float part[8][MT][16][17];
     __shared__ float s_sq[8][MT * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int tile = blockIdx.x;
-    const int K = a.K, M = a.M;
-    const int kw = K >> 3, k0 = wave * kw, nchunk = kw >> 5;
     LMT_DECL
-    const float* wp = a.w + ((long long)tile * NT + (li & (NT - 1))) * K + k0 + 8 * kq;
+    // ---- from the preloaded scalars alone (no scalar load yet): the row group and the weight batch
+    const int K = kp_K;
+    const int rows_pg = kp_rpg ? kp_rpg : 16 * MT;
+    const int r0 = kp_nrg > 1 ? (int)blockIdx.y * rows_pg : 0;
+    const int M = kp_nrg > 1 ? min(rows_pg, kp_M - r0) : kp_M;
+    const int kw = K >> 3, k0 = wave * kw, nchunk = kw >> 5;
+    const int kbase = k0 + 8 * kq;
+    const float* wp = kp_w + ((long long)tile * NT + (li & (NT - 1))) * K + k0 + 8 * kq;
     // weights do not depend on anything computed here: get the first batch in flight before touching the activations
     float4 wr[NB][2];
 #pragma unroll
@@ -343,11 +343,17 @@ __global__ __launch_bounds__(512) void lm_gemv_kernel(QA_KPRE_PARAMS const GemvA
         wr[c][0] = ldg_nt(wp + c * 32);
         wr[c][1] = ldg_nt(wp + c * 32 + 4);
     }
+    float4 xa[MT][NB][2];
+    __builtin_amdgcn_sched_barrier(0);  // the argument struct (scalar loads) only behind the weight loads
+    GemvArgs a = a_in;
+    QA_KPRE_APPLY(a)
+    if (ATT) { a.S = kp_ldx & 255; a.H = (kp_ldx >> 8) & 255; a.hd = kp_ldx >> 16; a.att_part = kp_x; } else { a.x = kp_x; a.ldx = kp_ldx; }
+    if (QA_N_ROW_GROUPS > 1) row_group(a, blockIdx.y, gridDim.x, rows_pg);
     const float* xrow[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int row = min(m * 16 + li, M - 1);
-        xrow[m] = a.tok ? a.table + a.tok[row] * a.ldx : a.x + (long long)row * a.ldx;
+        xrow[m] = a.tok ? a.table + a.tok[row] * (long long)kp_ldx : a.x + (long long)row * a.ldx;
     }
     EpiPre epi;
     epi_prefetch<MT, NT, MODE>(a, tile, tid, epi);
@@ -358,7 +364,6 @@ __global__ __launch_bounds__(512) void lm_gemv_kernel(QA_KPRE_PARAMS const GemvA
         acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         sq[m] = 0.f;
     }
-    const int kbase = k0 + 8 * kq;
     for (int c0 = 0; c0 < nchunk; c0 += NB) {
         if (c0 > 0) {
 #pragma unroll
@@ -367,7 +372,6 @@ __global__ __launch_bounds__(512) void lm_gemv_kernel(QA_KPRE_PARAMS const GemvA
                 wr[c][1] = ldg_nt(wp + (c0 + c) * 32 + 4);
             }
         }
-        float4 xa[MT][NB][2];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -431,9 +435,6 @@ template <int MT, int C, int MODE, bool ATT, int NS, bool R8 = false>
 __global__ __launch_bounds__(512) void lm_gemv4_kernel(QA_KPRE_PARAMS const GemvArgs a_in, const PfArgs pf) {
     static_assert(!R8 || MT == 1, "8-row groups exist for one row tile");
     QA_LM_PF_PLANE(pf)
-    GemvArgs a = a_in;
-    QA_KPRE_APPLY(a)
-    if (QA_N_ROW_GROUPS > 1) row_group(a, blockIdx.y, gridDim.x, R8 ? 8 : 16 * MT);
     constexpr int NT = 4 * C;
     __shared__ float part[8][MT][16][17];
     __shared__ float s_sq[8][MT * 16];
@@ -441,23 +442,33 @@ __global__ __launch_bounds__(512) void lm_gemv4_kernel(QA_KPRE_PARAMS const Gemv
     constexpr int KS = R8 ? 32 : 16;  // k per step
     const int g = R8 ? (lane >> 4) & 1 : lane >> 4, p = R8 ? ((lane >> 2) & 3) + 4 * (lane >> 5) : (lane >> 2) & 3, i4 = lane & 3;
     const int tile = blockIdx.x;
-    const int K = a.K, M = a.M;
-    const int kw = K >> 3, k0 = wave * kw, nstep = kw / KS;
     LMT_DECL
+    // ---- from the preloaded scalars alone (see lm_gemv_kernel): row group, weight batch
+    const int K = kp_K;
+    constexpr int rows_pg = R8 ? 8 : 16 * MT;
+    const int r0 = kp_nrg > 1 ? (int)blockIdx.y * rows_pg : 0;
+    const int M = kp_nrg > 1 ? min(rows_pg, kp_M - r0) : kp_M;
+    const int kw = K >> 3, k0 = wave * kw, nstep = kw / KS;
     const int kbase = k0 + 4 * p;
     const float* wp[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) wp[c] = a.w + ((long long)tile * NT + c * 4 + i4) * K + kbase;
+    for (int c = 0; c < C; ++c) wp[c] = kp_w + ((long long)tile * NT + c * 4 + i4) * K + kbase;
     float4 wr[NS][C];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int c = 0; c < C; ++c) wr[s][c] = ldg_nt(wp[c] + s * KS);
+    float4 xa[MT][NS];
+    __builtin_amdgcn_sched_barrier(0);  // the argument struct (scalar loads) only behind the weight loads
+    GemvArgs a = a_in;
+    QA_KPRE_APPLY(a)
+    if (ATT) { a.S = kp_ldx & 255; a.H = (kp_ldx >> 8) & 255; a.hd = kp_ldx >> 16; a.att_part = kp_x; } else { a.x = kp_x; a.ldx = kp_ldx; }
+    if (QA_N_ROW_GROUPS > 1) row_group(a, blockIdx.y, gridDim.x, rows_pg);
     const float* xrow[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int row = min(m * 16 + 4 * g + i4, M - 1);
-        xrow[m] = a.tok ? a.table + a.tok[row] * a.ldx : a.x + (long long)row * a.ldx;
+        xrow[m] = a.tok ? a.table + a.tok[row] * (long long)kp_ldx : a.x + (long long)row * a.ldx;
     }
     EpiPre epi;
     epi_prefetch<MT, NT, MODE>(a, tile, tid, epi);
@@ -476,7 +487,6 @@ __global__ __launch_bounds__(512) void lm_gemv4_kernel(QA_KPRE_PARAMS const Gemv
 #pragma unroll
                 for (int c = 0; c < C; ++c) wr[s][c] = ldg_nt(wp[c] + (s0 + s) * KS);
         }
-        float4 xa[MT][NS];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -656,6 +666,7 @@ __global__ __launch_bounds__(512) void lm_mlp_kernel(QA_KPRE_PARAMS const float*
     QA_LM_PF_PLANE(pf)
     GemvArgs a = a_in;
     QA_KPRE_APPLY(a)
+    QA_KPRE_APPLY_X(a)
     if (QA_N_ROW_GROUPS > 1) row_group(a, blockIdx.y, gridDim.x, a.rpg ? a.rpg : 16 * MT);
     constexpr int NTL = AC / 8;  // gate/up decode tiles (8 gate + 8 up rows each) per workgroup
     __shared__ float part[8][NTL][MT][16][17];
@@ -664,7 +675,7 @@ __global__ __launch_bounds__(512) void lm_mlp_kernel(QA_KPRE_PARAMS const float*
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int j = blockIdx.x;
-    const int K = a.K, M = a.M, d = QA_LM_KPRE ? a.K : a.d;  // launch_lm_mlp requires K == d; K is a preloaded argument
+    const int K = a.K, M = a.M, d = a.K;  // launch_lm_mlp requires K == d; K is a preloaded argument
     const int kw = K >> 3, k0 = wave * kw;
     // every load of the workgroup in flight before the first MFMA: gate / up rows, x, and the W_down slice of phase 2
     const float* wp[NTL];
@@ -860,7 +871,7 @@ int launch_lm_mlp(const GemvArgs& a, int I, int ac, const float* wd, float* part
 // device-side loop state (pos < 0) when a captured step is replayed.
 // DEVPOS: the position comes from the device-side loop state (a captured step that is replayed); the eager path passes it as an argument and must not
 // touch `state` at all - hipcc otherwise loads state[ST_POS] speculatively: two dependent scalar loads in front of the first K / V address.
-// Argument order: everything the first K / V loads need sits in the first 14 dwords (kernel-argument preload, see QA_LM_KPRE above).
+// Argument order: everything the first K / V loads need sits in the first 14 dwords (kernel-argument preload, see QA_KPRE_PARAMS above).
 template <int HD, int NW, bool DEVPOS>
 __global__ __launch_bounds__(NW * 64) void lm_attn_kernel(const float* __restrict__ q, const float* __restrict__ kc, const float* __restrict__ vc,
                                                           long long kv_bstride, int pos, int ldq, int ldkv, int S, int H, float scale,
