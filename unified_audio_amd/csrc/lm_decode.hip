@@ -641,6 +641,8 @@ int launch_lm_gemv(const GemvArgs& a, int mode, int nt, hipStream_t s, const PfA
     QA_REQUIRE(a.M >= 1 && a.M <= LM_MAX_ROWS, "lm_gemv: M=%d must be in [1, %d]", a.M, LM_MAX_ROWS);
     QA_REQUIRE(a.K % 256 == 0 && (a.ldx % 4) == 0, "lm_gemv: K=%d must be a multiple of 256", a.K);
     QA_REQUIRE((nt == 16 || nt == 8 || nt == 4) && a.N % nt == 0, "lm_gemv: N=%d not a multiple of the tile width %d", a.N, nt);
+    // the o_proj launch hands (S, H, hd) to its kernel packed into one preloaded scalar (QA_KPRE_ARGS)
+    QA_REQUIRE(!a.att_part || (a.S >= 1 && a.S < 256 && a.H >= 1 && a.H < 256 && a.hd >= 1 && a.hd < 32768), "lm_gemv: S=%d H=%d hd=%d out of range", a.S, a.H, a.hd);
     switch (mode) {
         case GM_QKV: return launch_gemv_mode<GM_QKV, false>(a, nt, s, pf);
         case GM_GATEUP: return launch_gemv_mode<GM_GATEUP, false>(a, nt, s, pf);
