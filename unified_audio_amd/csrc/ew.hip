@@ -124,9 +124,10 @@ int launch_layernorm(const float* x, const float* w, const float* b, float* y, l
 // Depthwise Conv1d (zero "same" padding, vq/conv.py:33-56) with optional fused LayerNorm over channels
 // (ConvNeXtBlock: dwconv k7 -> LN, vq/conv.py:200-203; sub-pixel upsampler's dw k5, vq/conv.py:86-90).
 // w layout [ksize][C] so that lanes read consecutive channels.
-// KS > 0: the tap count is a compile-time constant (7: ConvNeXt, 5: the sub-pixel upsampler) - r06: every tap of a channel chunk is loaded before
-// the first FMA (clamped source frame, the product masked to zero outside the clip), so a wave pays ONE memory round trip per chunk; with a run-time
-// `ksize` (KS = 0, any other kernel size) hipcc emits load -> wait -> fma per tap: seven dependent L2 round trips (42 us per launch at 32 x 500 x 1024).
+// KS > 0: the tap count is a compile-time constant (7: ConvNeXt, 5: the sub-pixel upsampler) - every tap of a channel chunk is loaded before the first
+// FMA (clamped source frame, the product masked to zero outside the clip) instead of load -> wait -> fma per tap.  Measured EQUAL (r06, isolated launch at
+// 32 x 500 x 1024: 42.9 -> 44.9 us, box-to-box noise): the launch is bound by every input row passing through a CU seven times - the taps of neighbouring output
+// rows - not by the dependent round trips; an LDS row tile would be the next step (1.4 % of the H-Codec 2.0 step, 0.4 % of 1.5).  KS = 0: any other kernel size.
 template <bool LN, int KS>
 __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, const float* __restrict__ lnw,
