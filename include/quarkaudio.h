@@ -212,6 +212,12 @@ int qa_conv1d_cl(const qa_conv_args* args, void* stream);
 /* RMSNorm (mode 1: transformer.py:77-96 of H-Codec 1.0, LlamaRMSNorm) / LayerNorm (mode 2: nn.LayerNorm, biased variance) over the last axis of
  * x [rows, C] (C % 4 == 0, C <= 2048); w [C], b [C] or NULL.  Exposed for kernel-level parity tests. */
 int qa_rownorm(const float* x, const float* w, const float* b, float* y, int64_t rows, int32_t C, float eps, int32_t mode, void* stream);
+/* Depthwise Conv1d over channel-last x [B, T, C] with zero padding (pad_left frames in front, ksize - 1 - pad_left behind; -1 = ksize / 2: the "same"
+ * padding of vq/conv.py:33-56), optionally followed by LayerNorm over C (ConvNeXtBlock: dwconv k7 -> LayerNorm, vq/conv.py:200-203):
+ *   y[b, t, c] = LN_c( bias[c] + sum_j w[j, c] * x[b, t + j - pad_left, c] ).  w in the library's [ksize, C] layout (the reference's [C, 1, ksize]
+ * transposed); ln_w / ln_b [C] or both NULL.  C % 4 == 0, C <= 2048, ksize odd.  Exposed for kernel-level parity tests. */
+int qa_dwconv_cl(const float* x, const float* w_kc, const float* bias, const float* ln_w, const float* ln_b, float* y, int64_t B, int64_t T, int32_t C,
+                 int32_t ksize, int32_t pad_left, float eps, void* stream);
 
 /* ---- host logic exposed for CPU tests (no device needed) ------------------------------------------------
  * SConv1d geometry of the reference (encoder_modules/conv.py:54-61,195-211, non-causal): for an input of L frames,

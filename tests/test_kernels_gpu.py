@@ -8,7 +8,7 @@ import torch.nn.functional as F
 
 from oracle import hcodec_ref as R
 from oracle import rvq_c
-from tests.util import act_ref, conv1d_cl, rel_err, rownorm
+from tests.util import act_ref, conv1d_cl, dwconv_cl, rel_err, rownorm
 
 pytestmark = pytest.mark.gpu
 
@@ -143,6 +143,34 @@ def test_rownorm_matches_torch(qa_lib, gpu_device, mode, C, bias):
            else xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + eps) * w.double())
     assert rel_err(y, ref) < 5e-7
     assert (y - ref.float()).abs().max() < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,C,k,ln,pad", [(2, 500, 1024, 7, True, -1), (3, 77, 768, 7, True, -1), (1, 5, 512, 7, True, -1), (2, 131, 256, 5, False, -1),
+                                              (2, 64, 1024, 5, True, 4), (4, 1500, 1024, 7, True, 6), (2, 33, 384, 7, True, -1), (1, 9, 1024, 3, True, -1)])
+def test_dwconv_matches_torch_and_strip_is_bit_identical_to_the_row_kernel(qa_lib, gpu_device, knob, B, T, C, k, ln, pad):
+    """qa_dwconv_cl (depthwise Conv1d with zero padding + LayerNorm: ConvNeXtBlock's dwconv k7 -> norm, vq/conv.py:200-203; the sub-pixel upsampler's k5)
+    against torch's fp32 conv1d(groups = C) + layer_norm, including causal padding, clips shorter than a pass and ragged strip ends; and the r06 row-strip
+    kernel (QA_DWCONV_STRIP, the default where C is whole 256-channel chunks and k = 5 / 7) against the one-wave-per-row kernel BIT FOR BIT."""
+    g = torch.Generator().manual_seed(B * 1000 + T + C + k)
+    x = (torch.randn(B, T, C, generator=g) + torch.randn(B, T, 1, generator=g) * 2).to(gpu_device)
+    w = (torch.randn(k, C, generator=g) / k ** 0.5).to(gpu_device)
+    bias = torch.randn(C, generator=g).to(gpu_device)
+    lw = (torch.rand(C, generator=g) + 0.5).to(gpu_device) if ln else None
+    lb = torch.randn(C, generator=g).to(gpu_device) if ln else None
+    knob("QA_DWCONV_STRIP", 0)
+    rows = dwconv_cl(qa_lib, x, w, bias, lw, lb, pad_left=pad)
+    knob("QA_DWCONV_STRIP", 1)
+    strip = dwconv_cl(qa_lib, x, w, bias, lw, lb, pad_left=pad)
+    torch.cuda.synchronize()
+    assert torch.isfinite(strip).all()
+    assert torch.equal(strip, rows), f"strip kernel differs from the row kernel (max |d| {float((strip - rows).abs().max()):.3e})"
+    pl = k // 2 if pad < 0 else pad
+    xd = F.pad(x.double().cpu().transpose(1, 2), (pl, k - 1 - pl))
+    ref = F.conv1d(xd, w.double().cpu().t().unsqueeze(1).contiguous(), bias.double().cpu(), groups=C).transpose(1, 2)
+    if ln:
+        ref = F.layer_norm(ref, (C,), lw.double().cpu(), lb.double().cpu(), 1e-6)
+    assert rel_err(strip, ref) < 2e-6
 
 
 def _rvq_problem(n, Q, K, D, seed):

@@ -59,6 +59,18 @@ def rownorm(lib, x, w, b=None, *, eps=1e-5, mode=2):
     return y
 
 
+def dwconv_cl(lib, x, w_kc, bias, ln_w=None, ln_b=None, *, pad_left=-1, eps=1e-6):
+    """Call qa_dwconv_cl: x [B, T, C] cuda, w_kc [ksize, C] (library layout), optional LayerNorm over C."""
+    from unified_audio_amd import _lib
+
+    B, T, Cc = x.shape
+    y = torch.full_like(x, float("nan"))
+    _lib.check(lib.qa_dwconv_cl(x.data_ptr(), w_kc.data_ptr(), bias.data_ptr(), ln_w.data_ptr() if ln_w is not None else None,
+                                ln_b.data_ptr() if ln_b is not None else None, y.data_ptr(), B, T, Cc, w_kc.shape[0], pad_left, eps,
+                                torch.cuda.current_stream().cuda_stream))
+    return y
+
+
 def act_ref(v, code):
     return {0: lambda t: t, 1: F.elu, 2: F.gelu, 3: F.silu}[code](v)
 

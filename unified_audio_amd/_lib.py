@@ -112,6 +112,8 @@ SYMBOLS = {
                                 C.c_void_p]),
     "qa_conv1d_cl": (C.c_int, [C.POINTER(qa_conv_args), C.c_void_p]),
     "qa_rownorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "qa_dwconv_cl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                             C.c_float, C.c_void_p]),
     "qa_sconv_geometry": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "qa_resolve_frame": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "qa_profile_begin": (C.c_int, []),

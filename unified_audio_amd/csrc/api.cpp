@@ -320,6 +320,16 @@ int qa_rownorm(const float* x, const float* w, const float* b, float* y, int64_t
     return QA_ERR_INVALID;
 }
 
+int qa_dwconv_cl(const float* x, const float* w_kc, const float* bias, const float* ln_w, const float* ln_b, float* y, int64_t B, int64_t T, int32_t C,
+                 int32_t ksize, int32_t pad_left, float eps, void* stream) {
+    if (!x || !w_kc || !bias || !y || (ln_w == nullptr) != (ln_b == nullptr)) {
+        set_error("qa_dwconv_cl: null argument (ln_w and ln_b come together)");
+        return QA_ERR_INVALID;
+    }
+    QA_REQUIRE(B > 0 && T > 0 && B * T < (1LL << 31) && pad_left >= -1, "qa_dwconv_cl: bad shape");
+    return launch_dwconv(x, w_kc, bias, ln_w, ln_b, y, (int)B, (int)T, C, ksize, eps, static_cast<hipStream_t>(stream), pad_left);
+}
+
 int qa_codes_check_async(const int64_t* codes, int64_t n, int64_t lo, int64_t limit, int64_t* bad_count_dev, void* stream) {
     if (!codes || !bad_count_dev) {
         set_error("qa_codes_check_async: null argument");

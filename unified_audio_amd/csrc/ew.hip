@@ -125,9 +125,9 @@ int launch_layernorm(const float* x, const float* w, const float* b, float* y, l
 // (ConvNeXtBlock: dwconv k7 -> LN, vq/conv.py:200-203; sub-pixel upsampler's dw k5, vq/conv.py:86-90).
 // w layout [ksize][C] so that lanes read consecutive channels.
 // KS > 0: the tap count is a compile-time constant (7: ConvNeXt, 5: the sub-pixel upsampler) - every tap of a channel chunk is loaded before the first
-// FMA (clamped source frame, the product masked to zero outside the clip) instead of load -> wait -> fma per tap.  Measured EQUAL (r06, isolated launch at
-// 32 x 500 x 1024: 42.9 -> 44.9 us, box-to-box noise): the launch is bound by every input row passing through a CU seven times - the taps of neighbouring output
-// rows - not by the dependent round trips; an LDS row tile would be the next step (1.4 % of the H-Codec 2.0 step, 0.4 % of 1.5).  KS = 0: any other kernel size.
+// FMA (clamped source frame, taps outside the clip skipped) instead of load -> wait -> fma per tap; measured equal (42.9 -> 44.9 us at 32 x 500 x 1024):
+// this kernel is bound by every input row passing through a CU once per tap, which dwconv_strip_kernel below removes.  It serves the shapes the strip
+// kernel does not (C not in whole 256-channel chunks, other kernel sizes) and is its bit-exact reference.  KS = 0: any other kernel size.
 template <bool LN, int KS>
 __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, const float* __restrict__ lnw,
@@ -176,20 +176,16 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
             }
         }
         v[i] = acc;
-        s += acc.x + acc.y + acc.z + acc.w;
+        s = norm_add(s, norm_sum4(acc.x, acc.y, acc.z, acc.w));
     }
     float mean = 0.f, rstd = 1.f;
-    if (LN) {
-        mean = wave_sum(s) / C;
+    if (LN) {  // the statements of common.h's norm_* helpers: dwconv_strip_kernel repeats them and produces the same bits
+        mean = norm_mean(wave_sum(s), C);
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAX_V4; ++i) {
-            if (lane * 4 + i * 256 < C) {
-                const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-                q += a * a + bb * bb + cc * cc + d * d;
-            }
-        }
-        rstd = rsqrtf(wave_sum(q) / C + eps);
+        for (int i = 0; i < MAX_V4; ++i)
+            if (lane * 4 + i * 256 < C) q = norm_add(q, norm_csq4(v[i].x, v[i].y, v[i].z, v[i].w, mean));
+        rstd = norm_rstd(wave_sum(q), C, eps);
     }
     float* yr = y + row * C;
 #pragma unroll
@@ -200,12 +196,100 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
         if (LN) {
             const float4 ww = *reinterpret_cast<const float4*>(lnw + c);
             const float4 bv = *reinterpret_cast<const float4*>(lnb + c);
-            o.x = (o.x - mean) * rstd * ww.x + bv.x;
-            o.y = (o.y - mean) * rstd * ww.y + bv.y;
-            o.z = (o.z - mean) * rstd * ww.z + bv.z;
-            o.w = (o.w - mean) * rstd * ww.w + bv.w;
+            o.x = norm_apply(o.x, mean, rstd, ww.x, bv.x);
+            o.y = norm_apply(o.y, mean, rstd, ww.y, bv.y);
+            o.z = norm_apply(o.z, mean, rstd, ww.z, bv.z);
+            o.w = norm_apply(o.w, mean, rstd, ww.w, bv.w);
         }
         *reinterpret_cast<float4*>(yr + c) = o;
+    }
+}
+
+// The same operator as a ROW STRIP (r06): a workgroup of NW waves (wave i = channels 256 i .. 256 i + 255, C = 256 NW) walks RS consecutive output
+// rows of one clip in passes of 8, keeping the last KS - 1 input rows of a pass in registers for the next one - every input row enters a CU once per strip
+// (+ (KS - 1) / RS halo) instead of once per tap.  dwconv_kernel is bound by exactly that: a row norm of the same bytes runs at 6.0 TB/s on this device,
+// dwconv_kernel at 3.0 (tools/copy_floor.py, profiles/r06_dwconv_strip_ab.txt).  Per output element the fma chain (bias, then the taps in order, taps
+// outside the clip skipped) is the one of dwconv_kernel; the LayerNorm sums are formed in its order as well - per lane over the chunks i = 0 .. NW - 1
+// (through LDS: the chunks live in different waves here), then the wave butterfly - so the two kernels agree BIT FOR BIT
+// (tests/test_kernels_gpu.py::test_dwconv_strip_is_bit_identical_to_the_row_kernel).
+constexpr int DW_RB = 8;  // output rows per pass
+template <bool LN, int KS, int NW>
+__global__ __launch_bounds__(64 * NW) void dwconv_strip_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               const float* __restrict__ lnw, const float* __restrict__ lnb, float* __restrict__ y,
+                                                               int T, int C, float eps, int pad, int RS, int strips) {
+    __shared__ float s_sum[LN ? DW_RB : 1][NW][64];
+    __shared__ float s_sq[LN ? DW_RB : 1][NW][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = wv * 256 + lane * 4;
+    const int b = blockIdx.x / strips, t_begin = (blockIdx.x - b * strips) * RS, t_end = min(T, t_begin + RS);
+    const float* xb = x + (long long)b * T * C + c;
+    float* yb = y + (long long)b * T * C + c;
+    float4 wr[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) wr[j] = *reinterpret_cast<const float4*>(w + (long long)j * C + c);
+    const float4 bs = *reinterpret_cast<const float4*>(bias + c);
+    float4 lw = make_float4(1.f, 1.f, 1.f, 1.f), lb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (LN) {
+        lw = *reinterpret_cast<const float4*>(lnw + c);
+        lb = *reinterpret_cast<const float4*>(lnb + c);
+    }
+    // win[k] = input row (t0 - pad + k) of the current pass; rows outside the clip are loaded from a clamped row and never used
+    float4 win[DW_RB + KS - 1];
+#pragma unroll
+    for (int k = 0; k < KS - 1; ++k) win[DW_RB + k] = *reinterpret_cast<const float4*>(xb + (long long)min(max(t_begin - pad + k, 0), T - 1) * C);
+    for (int t0 = t_begin; t0 < t_end; t0 += DW_RB) {
+#pragma unroll
+        for (int k = 0; k < KS - 1; ++k) win[k] = win[DW_RB + k];  // the halo of the previous pass
+#pragma unroll
+        for (int k = KS - 1; k < DW_RB + KS - 1; ++k) win[k] = *reinterpret_cast<const float4*>(xb + (long long)min(max(t0 - pad + k, 0), T - 1) * C);
+        float4 acc[DW_RB];
+#pragma unroll
+        for (int r = 0; r < DW_RB; ++r) {
+            acc[r] = bs;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                const int src = t0 + r + j - pad;  // wave-uniform
+                if (src < 0 || src >= T) continue;
+                acc[r].x = fmaf(win[r + j].x, wr[j].x, acc[r].x);
+                acc[r].y = fmaf(win[r + j].y, wr[j].y, acc[r].y);
+                acc[r].z = fmaf(win[r + j].z, wr[j].z, acc[r].z);
+                acc[r].w = fmaf(win[r + j].w, wr[j].w, acc[r].w);
+            }
+        }
+        float mean[DW_RB], rstd[DW_RB];
+        if (LN) {
+#pragma unroll
+            for (int r = 0; r < DW_RB; ++r) s_sum[r][wv][lane] = norm_sum4(acc[r].x, acc[r].y, acc[r].z, acc[r].w);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < DW_RB; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) s = norm_add(s, s_sum[r][i][lane]);
+                mean[r] = norm_mean(wave_sum(s), C);
+                s_sq[r][wv][lane] = norm_csq4(acc[r].x, acc[r].y, acc[r].z, acc[r].w, mean[r]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < DW_RB; ++r) {
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) q = norm_add(q, s_sq[r][i][lane]);
+                rstd[r] = norm_rstd(wave_sum(q), C, eps);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < DW_RB; ++r) {
+            if (t0 + r >= t_end) break;
+            float4 o = acc[r];
+            if (LN) {
+                o.x = norm_apply(o.x, mean[r], rstd[r], lw.x, lb.x);
+                o.y = norm_apply(o.y, mean[r], rstd[r], lw.y, lb.y);
+                o.z = norm_apply(o.z, mean[r], rstd[r], lw.z, lb.z);
+                o.w = norm_apply(o.w, mean[r], rstd[r], lw.w, lb.w);
+            }
+            *reinterpret_cast<float4*>(yb + (long long)(t0 + r) * C) = o;
+        }
     }
 }
 
@@ -216,6 +300,23 @@ int launch_dwconv(const float* x, const float* w_kc, const float* bias, const fl
     const unsigned grid = (unsigned)ceil_div((long long)B * T, 4);
     const int pad = pad_left >= 0 ? pad_left : ksize / 2;
     HbmProf prof_(HK_DWCONV_LN, 8.0 * (double)B * T * C, s);
+    // the strip kernel (QA_DWCONV_STRIP, default on): C = 256 .. 1024 in whole 256-channel chunks, k = 5 / 7
+    if (knob(K_DWCONV_STRIP) != 0 && C % 256 == 0 && C <= 1024 && (ksize == 7 || ksize == 5) && (!lnw || lnb)) {
+        const long long rows = (long long)B * T;
+        // strip length: ~1000 workgroups per launch (4 per CU: the halo of a longer strip costs less than the parallelism it takes away - sweep of
+        // RS = 8 .. 128 at 4 000 / 16 000 / 24 000 rows, profiles/r06_dwconv_strip_ab.txt: best at 8 / 16 / 24)
+        int RS = (int)(rows / 1000) / DW_RB * DW_RB;
+        RS = RS < DW_RB ? DW_RB : (RS > 64 ? 64 : RS);
+        const int strips = (int)ceil_div(T, RS), NW = C / 256;
+#define QA_DWS(LN, KS, NW) hipLaunchKernelGGL((dwconv_strip_kernel<LN, KS, NW>), dim3((unsigned)(B * strips)), dim3(64 * NW), 0, s, x, w_kc, bias, lnw, lnb, y, T, C, eps, pad, RS, strips)
+#define QA_DWS_NW(LN, KS) do { if (NW == 4) QA_DWS(LN, KS, 4); else if (NW == 3) QA_DWS(LN, KS, 3); else if (NW == 2) QA_DWS(LN, KS, 2); else QA_DWS(LN, KS, 1); } while (0)
+        if (lnw) { if (ksize == 7) QA_DWS_NW(true, 7); else QA_DWS_NW(true, 5); }
+        else { if (ksize == 7) QA_DWS_NW(false, 7); else QA_DWS_NW(false, 5); }
+#undef QA_DWS_NW
+#undef QA_DWS
+        QA_LAUNCH_CHECK();
+        return QA_OK;
+    }
 #define QA_DW(LN, KS) hipLaunchKernelGGL((dwconv_kernel<LN, KS>), dim3(grid), dim3(256), 0, s, x, w_kc, bias, lnw, lnb, y, B, T, C, ksize, eps, pad)
     if (lnw) {
         if (ksize == 7) QA_DW(true, 7);

@@ -18,6 +18,7 @@ namespace qa {
     X(GEMM_XCD, "QA_GEMM_XCD", 1, "XCD-aware tile order")                                                                        \
     X(GEMM_PANEL, "QA_GEMM_PANEL", 8, "conv_gemm tile order: column panels of this many tiles, row tiles fastest inside a panel (0: column tiles fastest over the whole row; 8: +4 % on N >= 4096 shapes, +1.2 % on H-Codec 2.0)") \
     X(ATT_DEBUG, "QA_ATT_DEBUG", 0, "attention_kernel debug bits: 1 always rescale, 2 extra barrier per tile, 4 wait for the prefetch at once") \
+    X(DWCONV_STRIP, "QA_DWCONV_STRIP", 1, "depthwise conv (+ LayerNorm) as row strips with the tap window in registers (0: one wave per output row; same bits)") \
     X(SEANET_FUSED, "QA_SEANET_FUSED", 1, "fused conv0 + first SEANet residual block")                                           \
     X(MIMI_ROPE_WINDOW, "QA_MIMI_ROPE_WINDOW", 8192, "mimi streaming: positions covered by the RoPE table before the rolling window takes over (tests shrink it)") \
     X(LSTM_GRAPH, "QA_LSTM_GRAPH", 1, "replay the T step launches of an LSTM call from a cached hipGraph")                       \
