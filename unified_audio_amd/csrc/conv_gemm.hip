@@ -249,17 +249,36 @@ __global__ __launch_bounds__(256, (BM == 64 && (BK == 16 || BN == 64) ? 4 : (BK 
     // SIMD with back-to-back 64-cycle MFMAs, and then get roughly one issue slot per MFMA (measured: ~55 cycles per
     // instruction, the "address phase" lasted as long as the whole MFMA phase).
     constexpr int NKK = BK / 8;
+    // One barrier per chunk, placed right behind the stores of the NEXT chunk's tile and in front of the LAST MFMA group of this one (r06): a wave leaves the
+    // barrier with that group's operands already in registers, issues the next chunk's first fragment reads and covers their LDS latency with 4 TM TN MFMAs.
+    // At the chunk's END (rounds 1 - 5) the barrier was followed by reads -> wait -> first MFMA: a bubble per chunk and wave that the co-resident waves did
+    // not always fill - 131.1 -> 135.4 TFLOP/s at 16 000 x 3 072 x 1 024, H-Codec 1.5 129.8 -> 128.0 ms, 2.0 470.2 -> 461.8 ms, bit-identical
+    // (profiles/r06_gemm_early_barrier_ab.txt).  Safe with two buffers: a wave's reads of buffer `cur` all precede its arrival at this chunk's barrier, and
+    // nobody writes `cur` before passing it.  Operands swapped on purpose: the W fragment is the MFMA's row operand and the activation fragment its column
+    // operand, so D = (A W^T)^T and every lane ends up with 4 CONSECUTIVE output channels of one output row per register quad -> the epilogue moves float4.
+    static_assert(NKK % 2 == 0, "the fragment buffers alternate: the next chunk's first group lands in slot 0");
+    // Where the NEXT tile's global loads are issued.  64 x 64 tiles (the N = 512 layers of the aggregator stacks): chunk kc + 2's loads right behind chunk kc's
+    // barrier - the staging registers are free again there, and the loads get a whole chunk of MFMAs to arrive (+5 ... 7 % on 9 056 x 512 x 512 / 2 048).  Every
+    // larger tile: chunk kc + 1's loads in MFMA group QA_LOAD_AT of chunk kc - behind the barrier they cost the 128-row tiles 4 % (all waves of a workgroup
+    // issue them in one burst together with the fragment reads; profiles/r06_gemm_early_barrier_ab.txt).
+    constexpr bool LOAD_AHEAD = BM == 64 && BN == 64;
+    if (LOAD_AHEAD) QA_LOAD_GLOBAL(min(1, nk - 1))
+    f32x4 af[2][TM], bf[2][TN];
+    {
+        const float* a0 = sA + (wm * WTM + frag_row) * LDS + frag_k;
+        const float* b0 = sB + (wn * WTN + frag_row) * LDS + frag_k;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(a0 + i * 32 * LDS);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(b0 + j * 32 * LDS);
+    }
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = kc & 1;
         const int nxt = min(kc + 1, nk - 1);
         const float* a = sA + cur * BM * LDS + (wm * WTM + frag_row) * LDS + frag_k;
         const float* b = sB + cur * BN * LDS + (wn * WTN + frag_row) * LDS + frag_k;
-        // fragment double buffering: the ds_read_b128 of k-group kk+1 are issued before the MFMAs of group kk
-        f32x4 af[2][TM], bf[2][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDS);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDS);
+        const float* an = sA + (cur ^ 1) * BM * LDS + (wm * WTM + frag_row) * LDS + frag_k;
+        const float* bn = sB + (cur ^ 1) * BN * LDS + (wn * WTN + frag_row) * LDS + frag_k;
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) {
             const int cb = kk & 1, nb = cb ^ 1;
@@ -269,11 +288,16 @@ __global__ __launch_bounds__(256, (BM == 64 && (BK == 16 || BN == 64) ? 4 : (BK 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[nb][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDS + (kk + 1) * 8);
             }
-            if (kk == QA_LOAD_AT) QA_LOAD_GLOBAL(nxt)
-            if (kk == NKK - 1) QA_STORE_LDS(cur ^ 1)
-            // operands swapped on purpose: the W fragment is the MFMA's row operand and the activation fragment its
-            // column operand, so D = (A W^T)^T and every lane ends up with 4 CONSECUTIVE output channels of one output
-            // row per register quad -> the epilogue moves float4, not scalars
+            if (!LOAD_AHEAD && kk == QA_LOAD_AT) QA_LOAD_GLOBAL(nxt)
+            if (kk == NKK - 1) {
+                QA_STORE_LDS(cur ^ 1)
+                __syncthreads();
+                if (LOAD_AHEAD) QA_LOAD_GLOBAL(min(kc + 2, nk - 1))
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[nb][i] = *reinterpret_cast<const f32x4*>(an + i * 32 * LDS);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[nb][j] = *reinterpret_cast<const f32x4*>(bn + j * 32 * LDS);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -285,7 +309,6 @@ __global__ __launch_bounds__(256, (BM == 64 && (BK == 16 || BN == 64) ? 4 : (BK 
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
     }
 #ifdef QA_TIMING
     const long long tloop = __builtin_readcyclecounter();
