@@ -416,6 +416,50 @@ def rvq_bench(dev, lib, n_vec, Q, K=1024, D=512, reps=5):
                        "dtype": "f32 distances, int64 indices"}}
 
 
+def gemm_calibration(dev, lib):
+    """CALIBRATION, never a product path (tools/gemm_vs_library.py): conv_gemm's LINEAR launches against the vendor library's fp32
+    GEMM (torch.matmul -> hipBLASLt / Tensile assembly, TF32 off) on four shapes that carry the H-Codec FLOPs, back to back on resident operands.  It says how
+    far the hand-written kernel is from the best fp32 GEMM known for this device, which the nominal matrix peak alone does not."""
+    from unified_audio_amd import _lib
+
+    torch.backends.cuda.matmul.allow_tf32 = False
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    out = {}
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for _ in range(2):
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e-3 / reps)
+        return best
+
+    for M, N, K in ((16000, 3072, 1024), (16000, 1024, 3072), (9056, 2048, 512), (9056, 512, 2048)):
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(N, K, device=dev) / K ** 0.5
+        y, y2 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+        a = _lib.qa_conv_args()
+        a.x, a.w, a.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+        a.B, a.T_in, a.C_in, a.T_out, a.N = 1, M, K, M, N
+        a.ldx, a.ldy, a.ldr, a.ldg = K, N, N, N
+        a.ksize, a.stride = 1, 1
+        t_own = timed(lambda: _lib.check(lib.qa_conv1d_cl(C.byref(a), C.c_void_p(stream))))
+        t_lib = timed(lambda: torch.matmul(x, w.t(), out=y2))
+        fl = 2.0 * M * N * K
+        out[f"{M}x{N}x{K}"] = {"conv_gemm_tflops": fl / t_own / 1e12, "vendor_library_tflops": fl / t_lib / 1e12,
+                               "max_abs_diff_over_max_abs": float((y - y2).abs().max() / y2.abs().max())}
+        del x, w, y, y2
+    out["note"] = "calibration only: the vendor library is not linked or called by the product; fp32, TF32 off; TFLOP/s = 2 M N K / best mean launch time"
+    return out
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -989,6 +1033,11 @@ def main():
             extras["rvq_search_48000x16"] = rvq_bench(dev, lib, 48000, 16, reps=3)
         except Exception as e:  # noqa: BLE001
             extras["rvq_search_6000x16"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        try:
+            log("GEMM calibration against the vendor library ...")
+            extras["gemm_calibration"] = gemm_calibration(dev, lib)
+        except Exception as e:  # noqa: BLE001
+            extras["gemm_calibration"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
 
     ssl_line = None
     if world == 1 and not args.lean and not args.no_ssl and args.model != "2.0":
